@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference block API (lib/fse.h, lib/huf.h, lib/hist.h) over libfsehip.so.
+
+Batched functions take / return CUDA (HIP) ``torch.uint8`` tensors and call the C ABI with raw device
+pointers on torch's current stream.  ``results`` tensors are ``torch.int64`` views of the reference's
+``size_t`` return values: a negative value ``-c`` is the error code ``c`` of lib/error_public.h:45-56.
+Single-block functions take numpy arrays (host pointers) and have the reference's exact signatures.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SZ = C.c_size_t
+VP = C.c_void_p
+
+ERROR_NAMES = {1: "GENERIC", 2: "dstSize_tooSmall", 3: "srcSize_wrong", 4: "corruption_detected", 5: "tableLog_tooLarge",
+               6: "maxSymbolValue_tooLarge", 7: "maxSymbolValue_tooSmall", 8: "workSpace_tooSmall"}
+
+
+def fse_compress_bound(n):      # lib/fse.h:290-292
+    return 512 + n + (n >> 7) + 4 + 8
+
+
+def huf_compress_bound(n):      # lib/huf.h:131-133
+    return 129 + n + (n >> 8) + 8
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: hipError %d" % (what, rc))
+
+
+def _stream():
+    return VP(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return VP(t.data_ptr()) if t is not None else VP(0)
+
+
+def _sizes_arg(sizes):
+    """sizes: None | int | int64/uint64 cuda tensor -> (device pointer or NULL, uniform, keepalive)"""
+    if sizes is None or isinstance(sizes, int):
+        return VP(0), SZ(int(sizes or 0)), None
+    t = sizes.to(torch.int64).contiguous()
+    return VP(t.data_ptr()), SZ(0), t
+
+
+class FseHip:
+    def __init__(self):
+        self.lib = _lib.load()
+        L = self.lib
+        for name in ("FSEHIP_HIST_count", "FSEHIP_FSE_compress_usingCTable", "FSEHIP_FSE_decompress_usingDTable",
+                     "FSEHIP_FSE_compress", "FSEHIP_FSE_compress2", "FSEHIP_FSE_decompress",
+                     "FSEHIP_HUF_compress1X_usingCTable", "FSEHIP_HUF_compress4X_usingCTable",
+                     "FSEHIP_HUF_decompress4X_usingDTable", "FSEHIP_HUF_decompress4X1_usingDTable",
+                     "FSEHIP_HUF_compress", "FSEHIP_HUF_compress2", "FSEHIP_HUF_decompress",
+                     "FSEHIP_FSE_compress_batch_workspaceSize", "FSEHIP_FSE_decompress_batch_workspaceSize",
+                     "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize"):
+            if hasattr(L, name):
+                getattr(L, name).restype = SZ
+        L.FSEHIP_getErrorName.restype = C.c_char_p
+        L.FSEHIP_versionString.restype = C.c_char_p
+
+    # ------------------------------------------------------------------ info
+    def device_info(self):
+        class Info(C.Structure):
+            _fields_ = [("deviceOrdinal", C.c_int), ("computeUnits", C.c_int), ("ldsBytesPerCU", C.c_int),
+                        ("wavefrontSize", C.c_int), ("archName", C.c_char * 64)]
+        info = Info()
+        _check(self.lib.FSEHIP_deviceInfo(C.byref(info)), "deviceInfo")
+        return {"device": info.deviceOrdinal, "cus": info.computeUnits, "lds_per_cu": info.ldsBytesPerCU,
+                "wave": info.wavefrontSize, "arch": info.archName.decode()}
+
+    # ------------------------------------------------------------------ workload
+    def probagen_table(self, p):
+        t = np.zeros(4096, dtype=np.uint8)
+        self.lib.FSEHIP_probagen_table(t.ctypes.data_as(VP), C.c_double(p))
+        return t
+
+    def probagen_batch(self, p_percent, n_blocks, block_size=32768, first_seed=1, out=None, device="cuda"):
+        """block b = probagen(block_size, p, seed=first_seed+b)  (programs/probaGenerator.c)"""
+        table = self.probagen_table(p_percent / 100.0)
+        if out is None:
+            out = torch.empty((n_blocks, block_size), dtype=torch.uint8, device=device)
+        _check(self.lib.FSEHIP_probagen_batch(_ptr(out), SZ(out.stride(0)), SZ(block_size), SZ(n_blocks),
+                                              table.ctypes.data_as(VP), C.c_uint32(first_seed), _stream()), "probagen_batch")
+        return out
+
+    # ------------------------------------------------------------------ a1
+    def hist_count_batch(self, src, sizes=None, max_symbol_values=None):
+        n = src.shape[0]
+        counts = torch.zeros((n, 256), dtype=torch.int32, device=src.device)
+        msv = (torch.full((n,), 255, dtype=torch.int32, device=src.device) if max_symbol_values is None
+               else max_symbol_values.to(torch.int32).contiguous().clone())
+        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        _check(self.lib.FSEHIP_HIST_count_batch(_ptr(counts), _ptr(msv), _ptr(res), _ptr(src), SZ(src.stride(0)), ps, uni,
+                                                SZ(n), _stream()), "HIST_count_batch")
+        return counts, msv, res
+
+    # ------------------------------------------------------------------ a2 / a3
+    def fse_compress_using_ctable_batch(self, src, ctables, max_table_log=12, sizes=None, dst_capacity=None, shared_table=False):
+        n = src.shape[0]
+        cap = fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        stride = 0 if shared_table else ctables.stride(0)
+        _check(self.lib.FSEHIP_FSE_compress_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
+                                                              ps, uni, _ptr(ctables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()),
+               "FSE_compress_usingCTable_batch")
+        return dst, res
+
+    def fse_decompress_using_dtable_batch(self, csrc, csizes, dtables, dst_capacity, max_table_log=12, shared_table=False):
+        n = csrc.shape[0]
+        dst = torch.zeros((n, max(dst_capacity, 1)), dtype=torch.uint8, device=csrc.device)
+        res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
+        ps, uni, keep = _sizes_arg(csizes)
+        stride = 0 if shared_table else dtables.stride(0)
+        _check(self.lib.FSEHIP_FSE_decompress_usingDTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(res), _ptr(csrc),
+                                                                SZ(csrc.stride(0)), ps, uni, _ptr(dtables), SZ(stride),
+                                                                C.c_uint(max_table_log), SZ(n), _stream()),
+               "FSE_decompress_usingDTable_batch")
+        return dst, res
+
+    # ------------------------------------------------------------------ one-shot FSE over a batch
+    def fse_workspace(self, n_blocks, table_log=11, decompress=False, device="cuda"):
+        fn = self.lib.FSEHIP_FSE_decompress_batch_workspaceSize if decompress else self.lib.FSEHIP_FSE_compress_batch_workspaceSize
+        nbytes = int(fn(SZ(n_blocks), C.c_uint(table_log)))
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def fse_compress_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
+        n = src.shape[0]
+        cap = (fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity)
+        if dst is None:
+            dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=src.device)
+        if workspace is None:
+            workspace = self.fse_workspace(n, table_log, False, src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        _check(self.lib.FSEHIP_FSE_compress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(src.stride(0)), ps, uni,
+                                                  C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace),
+                                                  SZ(workspace.numel()), _stream()), "FSE_compress_batch")
+        return dst, results
+
+    def fse_decompress_batch(self, csrc, csizes, dst_capacity, max_log=12, dst=None, results=None, workspace=None):
+        n = csrc.shape[0]
+        if dst is None:
+            dst = torch.empty((n, max(dst_capacity, 1)), dtype=torch.uint8, device=csrc.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=csrc.device)
+        if workspace is None:
+            workspace = self.fse_workspace(n, max_log, True, csrc.device)
+        ps, uni, keep = _sizes_arg(csizes)
+        _check(self.lib.FSEHIP_FSE_decompress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(results), _ptr(csrc), SZ(csrc.stride(0)),
+                                                    ps, uni, C.c_uint(max_log), SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()),
+               "FSE_decompress_batch")
+        return dst, results
+
+    # ------------------------------------------------------------------ layer 1 (host pointers, reference signatures)
+    def _single(self, fname, cap, src, *extra):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        out = np.zeros(max(cap, 1) + 16, dtype=np.uint8)
+        out[cap:] = 0xA5
+        r = int(getattr(self.lib, fname)(out.ctypes.data_as(VP), SZ(cap), src.ctypes.data_as(VP), SZ(src.size), *extra))
+        assert (out[cap:] == 0xA5).all(), "%s wrote past dstCapacity" % fname
+        return r, out[:cap]
+
+    def hist_count(self, src, max_sv=255):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        count = np.zeros(256, dtype=np.uint32)
+        msv = C.c_uint(max_sv)
+        r = int(self.lib.FSEHIP_HIST_count(count.ctypes.data_as(VP), C.byref(msv), src.ctypes.data_as(VP), SZ(src.size)))
+        return r, int(msv.value), count
+
+    def fse_compress_using_ctable(self, src, ct, cap=None):
+        ct = np.ascontiguousarray(ct, dtype=np.uint32)
+        return self._single("FSEHIP_FSE_compress_usingCTable", fse_compress_bound(len(src)) if cap is None else cap, src, ct.ctypes.data_as(VP))
+
+    def fse_decompress_using_dtable(self, csrc, dt, cap):
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        return self._single("FSEHIP_FSE_decompress_usingDTable", cap, csrc, dt.ctypes.data_as(VP))
+
+    def fse_compress2(self, src, max_sv=255, table_log=11, cap=None):
+        return self._single("FSEHIP_FSE_compress2", fse_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(table_log))
+
+    def fse_decompress(self, csrc, cap):
+        return self._single("FSEHIP_FSE_decompress", cap, csrc)

@@ -1,0 +1,356 @@
+// capi.hip -- the C ABI of libfsehip.so (include/fsehip.h): host-side mirror of the reference's block API
+// (lib/fse.h, lib/huf.h, lib/hist.h) on top of the HIP kernels.  No CPU compute path exists here: every
+// result is produced by a kernel; without a usable device the calls fail.
+#include "internal.h"
+#include <string.h>
+#include <stdlib.h>
+#include <new>
+
+#define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+extern "C" unsigned FSEHIP_isError(size_t code) { return code > FSEHIP_ERROR(maxCode); }
+
+extern "C" const char* FSEHIP_getErrorName(size_t code)   // lib/error_private.h:88-104
+{
+    if (!FSEHIP_isError(code)) return "No error detected";
+    switch ((int)(0 - code)) {
+        case FSEHIP_error_GENERIC: return "Error (generic)";
+        case FSEHIP_error_dstSize_tooSmall: return "Destination buffer is too small";
+        case FSEHIP_error_srcSize_wrong: return "Src size is incorrect";
+        case FSEHIP_error_corruption_detected: return "Corrupted block detected";
+        case FSEHIP_error_tableLog_tooLarge: return "tableLog requires too much memory : unsupported";
+        case FSEHIP_error_maxSymbolValue_tooLarge: return "Unsupported max Symbol Value : too large";
+        case FSEHIP_error_maxSymbolValue_tooSmall: return "Specified maxSymbolValue is too small";
+        case FSEHIP_error_workSpace_tooSmall: return "workspace buffer is too small";
+        default: return "Unspecified error code";
+    }
+}
+
+extern "C" const char* FSEHIP_versionString(void) { return "fsehip 0.1 (gfx950)"; }
+
+const DevProps& dev_props()
+{
+    static DevProps p = { 0, 0, false };
+    if (!p.ok) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            p.cus = prop.multiProcessorCount;
+            p.ldsPerCU = (int)prop.maxSharedMemoryPerMultiProcessor;
+            p.ok = true;
+        }
+    }
+    return p;
+}
+
+extern "C" int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info)
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CK(hipGetDevice(&dev));
+    CK(hipGetDeviceProperties(&prop, dev));
+    info->deviceOrdinal = dev;
+    info->computeUnits = prop.multiProcessorCount;
+    info->ldsBytesPerCU = (int)prop.maxSharedMemoryPerMultiProcessor;
+    info->wavefrontSize = prop.warpSize;
+    strncpy(info->archName, prop.gcnArchName, sizeof(info->archName) - 1);
+    info->archName[sizeof(info->archName) - 1] = 0;
+    return 0;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline BlockView mkview(const void* base, size_t stride, const size_t* sizes, size_t uniform)
+{
+    BlockView v; v.base = (const u8*)base; v.stride = stride; v.sizes = sizes; v.uniform = uniform; return v;
+}
+
+// =====================================================================================================
+//  workload generator
+// =====================================================================================================
+extern "C" void FSEHIP_probagen_table(uint8_t table[4096], double p)   // programs/probaGenerator.c:95-118
+{
+    int remaining = 4096;
+    unsigned pos = 0, s = 0;
+    if (p == 0.0) p = 0.005;
+    while (remaining) {
+        unsigned n = (unsigned)(remaining * p);
+        if (!n) n = 1;
+        memset(table + pos, (int)(uint8_t)s, n);
+        pos += n; s++; remaining -= (int)n;
+    }
+}
+
+extern "C" int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
+                                     const uint8_t h_table[4096], uint32_t firstSeed, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    u8* d_table = nullptr;
+    CK(hipMalloc(&d_table, 4096));
+    hipError_t e = hipMemcpyAsync(d_table, h_table, 4096, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_probagen((u8*)d_dst, dstStride, blockSize, nBlocks, d_table, firstSeed, s);
+    hipError_t e2 = hipStreamSynchronize(s);   // the table must outlive the kernel
+    (void)hipFree(d_table);
+    return (int)(e != hipSuccess ? e : e2);
+}
+
+// =====================================================================================================
+//  a1: HIST_count
+// =====================================================================================================
+extern "C" int FSEHIP_HIST_count_batch(unsigned* d_counts, unsigned* d_maxSymbolValues, size_t* d_results,
+                                       const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                       size_t nBlocks, void* stream)
+{
+    HistArgs a;
+    a.counts = d_counts; a.maxSVs = d_maxSymbolValues; a.uniformMaxSV = 255; a.useUniformIn = 0;
+    a.results = d_results; a.src = mkview(d_src, srcStride, d_sizes, uniformSize); a.nBlocks = nBlocks;
+    return (int)launch_hist(a, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+//  a2 / a3: FSE hot loops over a batch
+// =====================================================================================================
+extern "C" int FSEHIP_FSE_compress_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                     const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                                     const FSEHIP_FSE_CTable* d_ctables, size_t ctableStrideU32, unsigned maxTableLog,
+                                                     size_t nBlocks, void* stream)
+{
+    if (maxTableLog == 0 || maxTableLog > FSEHIP_FSE_MAX_TABLELOG) maxTableLog = FSEHIP_FSE_MAX_TABLELOG;
+    FseEncArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
+    a.src = mkview(d_src, srcStride, d_sizes, uniformSize);
+    a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks;
+    return (int)launch_fse_encode(a, (hipStream_t)stream);
+}
+
+extern "C" int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                       const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                       const FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                       size_t nBlocks, void* stream)
+{
+    if (maxTableLog == 0 || maxTableLog > FSEHIP_FSE_MAX_TABLELOG) maxTableLog = FSEHIP_FSE_MAX_TABLELOG;
+    FseDecArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
+    a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
+    a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks;
+    return (int)launch_fse_decode(a, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+//  one-shot FSE block API over a batch
+// =====================================================================================================
+struct FseCWs { size_t perBlock; size_t ctU32; size_t ts; unsigned maxTl; };
+static FseCWs fse_cws(unsigned tableLog)
+{
+    FseCWs w;
+    unsigned tl = tableLog ? tableLog : FSEHIP_FSE_DEFAULT_TABLELOG;
+    if (tl < 9) tl = 9;                  // FSE_optimalTableLog may raise a small request up to highbit(255)+2 (fse_compress.c:316-333)
+    if (tl > FSEHIP_FSE_MAX_TABLELOG) tl = FSEHIP_FSE_MAX_TABLELOG;
+    w.maxTl = tl;
+    w.ctU32 = FSEHIP_FSE_CTABLE_SIZE_U32(tl, 255);
+    w.ts = (size_t)1 << tl;
+    w.perBlock = 1024 + 4 + 8 + sizeof(FseMeta) + 4 * w.ctU32 + w.ts;
+    return w;
+}
+#define WS_SLACK 2048
+#define WS_MAX_CHUNK 16384
+
+extern "C" size_t FSEHIP_FSE_compress_batch_workspaceSize(size_t nBlocks, unsigned tableLog)
+{
+    const FseCWs w = fse_cws(tableLog);
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    if (c == 0) c = 1;
+    return c * w.perBlock + WS_SLACK;
+}
+
+extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                         const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                         unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                         void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) return 0;
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return (int)hipErrorInvalidValue;   // FSE_compress2 -> tableLog_tooLarge (fse_compress.c:691); see single-block wrapper
+    const FseCWs w = fse_cws(tableLog);
+    if (workspaceBytes < w.perBlock + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / w.perBlock;
+    if (chunk > nBlocks) chunk = nBlocks;
+    // carve the workspace
+    u8* p = (u8*)d_workspace;
+    auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
+    unsigned* counts = (unsigned*)carve(chunk * 1024);
+    unsigned* maxSVs = (unsigned*)carve(chunk * 4);
+    size_t* hres = (size_t*)carve(chunk * 8);
+    FseMeta* meta = (FseMeta*)carve(chunk * sizeof(FseMeta));
+    u32* ctables = (u32*)carve(chunk * 4 * w.ctU32);
+    u8* cellSym = (u8*)p;
+    if ((size_t)(cellSym + chunk * w.ts - (u8*)d_workspace) > workspaceBytes) {
+        // alignment slack exhausted: shrink the chunk by one (WS_SLACK covers 5 x 256 of padding)
+        return (int)hipErrorInvalidValue;
+    }
+    unsigned msv = maxSymbolValue ? maxSymbolValue : 255;        // fse_compress.c:648
+    if (msv > 255) msv = 255;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        const BlockView src = mkview((const u8*)d_src + b0 * srcStride, srcStride, d_sizes ? d_sizes + b0 : nullptr, uniformSize);
+        HistArgs h;
+        h.counts = counts; h.maxSVs = maxSVs; h.uniformMaxSV = msv; h.useUniformIn = 1; h.results = hres; h.src = src; h.nBlocks = nb;
+        CK(launch_hist(h, s));
+        FseCPrepArgs c;
+        c.counts = counts; c.maxSVs = maxSVs; c.histResults = hres; c.src = src;
+        c.dst = (u8*)d_dst + b0 * dstStride; c.dstStride = dstStride; c.dstCapacity = dstCapacity;
+        c.maxSVReq = msv; c.tableLogReq = tableLog;
+        c.ctables = ctables; c.ctStrideU32 = w.ctU32; c.cellSym = cellSym; c.cellSymStride = w.ts;
+        c.meta = meta; c.results = d_results + b0; c.nBlocks = nb;
+        CK(launch_fse_cprep(c, s));
+        FseEncArgs e;
+        e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
+        e.src = src; e.ctables = ctables; e.ctStrideU32 = w.ctU32; e.meta = meta;
+        e.maxTableLog = w.maxTl; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
+        CK(launch_fse_encode(e, s));
+    }
+    return 0;
+}
+
+static size_t fse_dws_per_block(unsigned maxLog) { return sizeof(FseMeta) + 4 * (size_t)FSEHIP_FSE_DTABLE_SIZE_U32(maxLog); }
+static unsigned clamp_maxlog(unsigned maxLog) { return (maxLog == 0 || maxLog > FSEHIP_FSE_MAX_TABLELOG) ? FSEHIP_FSE_MAX_TABLELOG : maxLog; }
+
+extern "C" size_t FSEHIP_FSE_decompress_batch_workspaceSize(size_t nBlocks, unsigned maxLog)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    if (c == 0) c = 1;
+    return c * fse_dws_per_block(clamp_maxlog(maxLog)) + WS_SLACK;
+}
+
+extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                           const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                           unsigned maxLog, size_t nBlocks,
+                                           void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) return 0;
+    maxLog = clamp_maxlog(maxLog);
+    const size_t per = fse_dws_per_block(maxLog);
+    if (workspaceBytes < per + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / per;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
+    u32* dtables = (u32*)p;
+    const size_t dtU32 = FSEHIP_FSE_DTABLE_SIZE_U32(maxLog);
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
+        FseDPrepArgs d;
+        d.csrc = cs; d.maxLog = maxLog; d.dtables = dtables; d.dtStrideU32 = dtU32; d.meta = meta; d.results = d_results + b0; d.nBlocks = nb;
+        CK(launch_fse_dprep(d, s));
+        FseDecArgs e;
+        e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
+        e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
+        e.maxTableLog = maxLog; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
+        CK(launch_fse_decode(e, s));
+    }
+    return 0;
+}
+
+// =====================================================================================================
+//  Layer 1: single-block calls on host pointers = batch of one (H2D, kernels, D2H)
+// =====================================================================================================
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}
+
+// result transport for one block: returns GENERIC when the device path itself fails
+#define HK(x) do { if ((x) != hipSuccess) return FSEHIP_ERROR(GENERIC); } while (0)
+
+extern "C" size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize)
+{
+    DevBuf dsrc, dcnt, dmsv, dres;
+    HK(dsrc.alloc(srcSize)); HK(dcnt.alloc(1024)); HK(dmsv.alloc(4)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dmsv.p, maxSymbolValuePtr, 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HIST_count_batch((unsigned*)dcnt.p, (unsigned*)dmsv.p, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize, 1, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (FSEHIP_isError(r)) return r;
+    const unsigned in = *maxSymbolValuePtr;
+    const unsigned nOut = in < 255 ? in + 1 : 256;
+    HK(hipMemcpy(count, dcnt.p, nOut * 4, hipMemcpyDeviceToHost));
+    HK(hipMemcpy(maxSymbolValuePtr, dmsv.p, 4, hipMemcpyDeviceToHost));
+    return r;
+}
+
+extern "C" size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const FSEHIP_FSE_CTable* ct)
+{
+    const u16* h = (const u16*)ct;
+    const unsigned tl = h[0], msv = h[1];
+    if (tl > FSEHIP_FSE_MAX_TABLELOG || msv > 255) return FSEHIP_ERROR(tableLog_tooLarge);
+    const size_t words = 1 + (tl ? ((size_t)1 << (tl - 1)) : 1) + 2 * ((size_t)msv + 1);
+    DevBuf dsrc, ddst, dct, dres;
+    HK(dsrc.alloc(srcSize)); HK(ddst.alloc(dstCapacity)); HK(dct.alloc(words * 4)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dct.p, ct, words * 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_compress_usingCTable_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize,
+                                                         (const unsigned*)dct.p, 0, FSEHIP_FSE_MAX_TABLELOG, 1, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r, hipMemcpyDeviceToHost));
+    return r;
+}
+
+extern "C" size_t FSEHIP_FSE_decompress_usingDTable(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize, const FSEHIP_FSE_DTable* dt)
+{
+    const u16* h = (const u16*)dt;
+    const unsigned tl = h[0];
+    if (tl > FSEHIP_FSE_MAX_TABLELOG) return FSEHIP_ERROR(tableLog_tooLarge);
+    const size_t words = 1 + ((size_t)1 << tl);
+    DevBuf dsrc, ddst, ddt, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstCapacity)); HK(ddt.alloc(words * 4)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK(hipMemcpy(ddt.p, dt, words * 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_decompress_usingDTable_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
+                                                           (const unsigned*)ddt.p, 0, FSEHIP_FSE_MAX_TABLELOG, 1, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
+    return r;
+}
+
+extern "C" size_t FSEHIP_FSE_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)
+{
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return FSEHIP_ERROR(tableLog_tooLarge);   // fse_compress.c:691
+    const size_t wsBytes = FSEHIP_FSE_compress_batch_workspaceSize(1, tableLog);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(srcSize)); HK(ddst.alloc(dstCapacity)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_compress_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize,
+                                             maxSymbolValue, tableLog, 1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 1) HK(hipMemcpy(dst, ddst.p, r, hipMemcpyDeviceToHost));
+    return r;
+}
+
+extern "C" size_t FSEHIP_FSE_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)   // fse_compress.c:695-698
+{
+    return FSEHIP_FSE_compress2(dst, dstCapacity, src, srcSize, 255, FSEHIP_FSE_DEFAULT_TABLELOG);
+}
+
+extern "C" size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize)   // fse_decompress.c:279-283
+{
+    const size_t wsBytes = FSEHIP_FSE_decompress_batch_workspaceSize(1, FSEHIP_FSE_MAX_TABLELOG);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstCapacity)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_decompress_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
+                                               FSEHIP_FSE_MAX_TABLELOG, 1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
+    return r;
+}

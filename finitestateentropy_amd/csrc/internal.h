@@ -1,0 +1,138 @@
+// internal.h -- kernel argument blocks and host-side launchers (one per kernel family).
+#pragma once
+#include "dev_common.h"
+
+// ---- a1: HIST_count ------------------------------------------------------------------------------
+struct HistArgs {
+    unsigned* counts;            // nBlocks x 256
+    unsigned* maxSVs;            // in/out per block, or nullptr (255 in)
+    unsigned uniformMaxSV;       // used when maxSVs == nullptr or useUniformIn
+    int useUniformIn;            // 1: limit = uniformMaxSV for every block, maxSVs (if any) is output only
+    size_t* results;
+    BlockView src;
+    size_t nBlocks;
+};
+hipError_t launch_hist(const HistArgs& a, hipStream_t s);
+
+// ---- FSE ------------------------------------------------------------------------------------------
+// per-block record shared by the prepare and the hot-loop kernels
+struct FseMeta {
+    u32 state;      // 0 = final result already in results[b]; 1 = run the hot loop
+    u32 hdrSize;    // bytes of NCount header in front of the payload
+    u32 tableLog;
+    u32 maxSV;
+};
+
+struct FseCPrepArgs {            // glue g1-g4 (compress side): lib/fse_compress.c:632-677 minus the hot loops
+    const unsigned* counts;      // from k_hist, nBlocks x 256
+    const unsigned* maxSVs;      // from k_hist
+    const size_t* histResults;
+    BlockView src;
+    u8* dst; size_t dstStride; size_t dstCapacity;
+    unsigned maxSVReq, tableLogReq;
+    u32* ctables; size_t ctStrideU32;
+    u8* cellSym; size_t cellSymStride;   // scratch: tableSize bytes per block
+    FseMeta* meta;
+    size_t* results;
+    size_t nBlocks;
+};
+hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s);
+
+struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per block
+    u8* dst; size_t dstStride; size_t dstCapacity;
+    size_t* results;
+    BlockView src;
+    const u32* ctables; size_t ctStrideU32;
+    const FseMeta* meta;         // nullptr for the plain usingCTable batch
+    unsigned maxTableLog;
+    int G;                       // blocks per workgroup
+    unsigned slotU32;            // LDS words per table slot
+    size_t nBlocks;
+};
+hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
+
+struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
+    BlockView csrc;
+    unsigned maxLog;
+    u32* dtables; size_t dtStrideU32;
+    FseMeta* meta;
+    size_t* results;
+    size_t nBlocks;
+};
+hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s);
+
+struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per block
+    u8* dst; size_t dstStride; size_t dstCapacity;
+    size_t* results;
+    BlockView csrc;
+    const u32* dtables; size_t dtStrideU32;
+    const FseMeta* meta;         // nullptr for the plain usingDTable batch
+    unsigned maxTableLog;
+    int G;
+    unsigned slotU32;
+    size_t nBlocks;
+};
+hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s);
+
+// ---- Huff0 ----------------------------------------------------------------------------------------
+struct HufMeta {
+    u32 state;      // 0 = final, 1 = run the hot loop
+    u32 hdrSize;
+    u32 tableLog;
+    u32 maxSV;
+};
+
+struct HufCPrepArgs {            // glue g5-g7: lib/huf_compress.c:637-724 minus the hot loop
+    const unsigned* counts; const unsigned* maxSVs; const size_t* histResults;
+    BlockView src;
+    u8* dst; size_t dstStride; size_t dstCapacity;
+    unsigned maxSVReq, huffLogReq;
+    u32* ctables; size_t ctStrideU32;    // 256 HUF_CElt per block
+    HufMeta* meta;
+    size_t* results;
+    size_t nBlocks;
+};
+hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s);
+
+struct HufEncArgs {              // a4: HUF_compress4X_usingCTable (streams = 4) / 1X (streams = 1), one workgroup per block
+    u8* dst; size_t dstStride; size_t dstCapacity;
+    size_t* results;
+    BlockView src;
+    const u32* ctables; size_t ctStrideU32;
+    const HufMeta* meta;
+    int streams;
+    size_t nBlocks;
+};
+hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s);
+
+struct HufDPrepArgs {            // glue g6: HUF_readStats + HUF_readDTableX1 (+ raw / RLE decisions of HUF_decompress)
+    BlockView csrc;
+    BlockView dstSizes;          // only sizes/uniform used
+    u8* dst; size_t dstStride;
+    u32* dtables; size_t dtStrideU32;
+    HufMeta* meta;
+    size_t* results;
+    size_t nBlocks;
+};
+hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s);
+
+struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes per block (one per stream)
+    u8* dst; size_t dstStride;
+    BlockView dstSizes;
+    size_t* results;
+    BlockView csrc;
+    const u32* dtables; size_t dtStrideU32;
+    const HufMeta* meta;
+    unsigned maxTableLog;
+    int G; unsigned slotU32;
+    int streams;                 // 4 (4X1) or 1 (1X1)
+    size_t nBlocks;
+};
+hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
+
+// ---- workload generator -----------------------------------------------------------------------------
+hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, hipStream_t s);
+
+// device properties cache
+struct DevProps { int cus; int ldsPerCU; bool ok; };
+const DevProps& dev_props();

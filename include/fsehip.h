@@ -1,0 +1,200 @@
+/* fsehip.h -- C ABI of libfsehip.so: the MI355X (gfx950) block-entropy-coding hot path.
+ *
+ * Drop-in boundary for the reference library's block API (Cyan4973/FiniteStateEntropy):
+ *   lib/hist.h:30-31      HIST_count
+ *   lib/fse.h:67-105      FSE_compress / FSE_decompress / FSE_compress2 (one-shot block API)
+ *   lib/fse.h:142-247     FSE_compress_usingCTable (:174), FSE_decompress_usingDTable (:247)
+ *   lib/huf.h:54-98       HUF_compress / HUF_decompress / HUF_compress2
+ *   lib/huf.h:190,290     HUF_compress4X_usingCTable, HUF_compress1X_usingCTable
+ *   lib/huf.h:275-277     HUF_decompress4X_usingDTable, HUF_decompress4X1_usingDTable
+ *
+ * Every function keeps the reference's signature, argument meaning, in-memory table layouts
+ * (FSE_CTable / FSE_DTable = unsigned[], HUF_CElt = {U16 val; BYTE nbBits;} stride 4,
+ * HUF_DTable = U32[] with a 4-byte DTableDesc), bitstream/header format and the size_t error
+ * convention (lib/error_private.h:77-79: (size_t)-code, code in FSEHIP_ErrorCode).  Encoders
+ * return 0 ("not compressible / does not fit") and, for the one-shot forms, 1 ("single repeated
+ * byte") exactly where the reference does (lib/fse.h:62-65, lib/huf.h:50-52).
+ *
+ * All computation happens in hand-written HIP kernels; there is NO CPU fallback: if no gfx950
+ * device is usable the single-block calls return FSEHIP_ERROR(GENERIC) and the batch calls return
+ * the failing hipError_t.
+ *
+ * Two layers:
+ *   1. single-block calls on HOST pointers (same signatures as the reference, prefix FSEHIP_;
+ *      define FSEHIP_DROPIN_NAMES before including this header to also get the original names
+ *      as macros so reference callers such as programs/fuzzer.c or programs/fullbench.c link
+ *      against this library unchanged);
+ *   2. batched calls on DEVICE pointers (many independent blocks per launch -- the data-parallel
+ *      axis of programs/bench.c:353-364,389-424), which is what reaches throughput.
+ */
+#ifndef FSEHIP_H
+#define FSEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSEHIP_API __attribute__((visibility("default")))
+
+/* ---- error convention (lib/error_public.h:45-56, lib/error_private.h:77-79) ------------------ */
+typedef enum {
+    FSEHIP_error_no_error = 0,
+    FSEHIP_error_GENERIC = 1,
+    FSEHIP_error_dstSize_tooSmall = 2,
+    FSEHIP_error_srcSize_wrong = 3,
+    FSEHIP_error_corruption_detected = 4,
+    FSEHIP_error_tableLog_tooLarge = 5,
+    FSEHIP_error_maxSymbolValue_tooLarge = 6,
+    FSEHIP_error_maxSymbolValue_tooSmall = 7,
+    FSEHIP_error_workSpace_tooSmall = 8,
+    FSEHIP_error_maxCode = 9
+} FSEHIP_ErrorCode;
+#define FSEHIP_ERROR(name) ((size_t)0 - (size_t)FSEHIP_error_##name)
+FSEHIP_API unsigned FSEHIP_isError(size_t code);            /* FSE_isError / HUF_isError / HIST_isError */
+FSEHIP_API const char* FSEHIP_getErrorName(size_t code);    /* FSE_getErrorName */
+
+/* ---- sizes (lib/fse.h:290-296, lib/huf.h:131-145) --------------------------------------------- */
+#define FSEHIP_FSE_MAX_TABLELOG 12
+#define FSEHIP_FSE_DEFAULT_TABLELOG 11
+#define FSEHIP_FSE_MIN_TABLELOG 5
+#define FSEHIP_FSE_NCOUNTBOUND 512
+#define FSEHIP_FSE_BLOCKBOUND(size) ((size) + ((size) >> 7) + 4 + sizeof(size_t))
+#define FSEHIP_FSE_COMPRESSBOUND(size) (FSEHIP_FSE_NCOUNTBOUND + FSEHIP_FSE_BLOCKBOUND(size))
+#define FSEHIP_FSE_CTABLE_SIZE_U32(maxTableLog, maxSymbolValue) (1 + (1 << ((maxTableLog)-1)) + (((maxSymbolValue) + 1) * 2))
+#define FSEHIP_FSE_DTABLE_SIZE_U32(maxTableLog) (1 + (1 << (maxTableLog)))
+#define FSEHIP_HUF_TABLELOG_MAX 12
+#define FSEHIP_HUF_TABLELOG_DEFAULT 11
+#define FSEHIP_HUF_BLOCKSIZE_MAX (128 * 1024)
+#define FSEHIP_HUF_COMPRESSBOUND(size) (129 + ((size) + ((size) >> 8) + 8))
+#define FSEHIP_HUF_CTABLE_SIZE_U32(maxSymbolValue) ((maxSymbolValue) + 1)
+#define FSEHIP_HUF_DTABLE_SIZE_U32(maxTableLog) (1 + (1 << (maxTableLog)))
+
+typedef unsigned FSEHIP_FSE_CTable;   /* lib/fse.h:160 */
+typedef unsigned FSEHIP_FSE_DTable;   /* lib/fse.h:233 */
+typedef uint32_t FSEHIP_HUF_CElt;     /* lib/huf.h:187 + lib/huf_compress.c:106-109 : {U16 val; BYTE nbBits; pad} */
+typedef uint32_t FSEHIP_HUF_DTable;   /* lib/huf.h:144 */
+
+/* =================================================================================================
+ *  Layer 1 -- single-block, HOST pointers, reference signatures
+ * ================================================================================================= */
+/* lib/hist.h:30  (semantics lib/hist.c:163-180) */
+FSEHIP_API size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize);
+
+/* lib/fse.h:174 */
+FSEHIP_API size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const FSEHIP_FSE_CTable* ct);
+/* lib/fse.h:247 */
+FSEHIP_API size_t FSEHIP_FSE_decompress_usingDTable(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize, const FSEHIP_FSE_DTable* dt);
+/* lib/fse.h:76, :104, :90 */
+FSEHIP_API size_t FSEHIP_FSE_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+FSEHIP_API size_t FSEHIP_FSE_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);
+FSEHIP_API size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize);
+
+/* lib/huf.h:290, :190 */
+FSEHIP_API size_t FSEHIP_HUF_compress1X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable);
+FSEHIP_API size_t FSEHIP_HUF_compress4X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable);
+/* lib/huf.h:275-277 (tableType 0 = X1 cells; an X2 table (tableType 1) is rejected with GENERIC,
+ * exactly as HUF_decompress4X1_usingDTable does, lib/huf_decompress.c:411-412) */
+FSEHIP_API size_t FSEHIP_HUF_decompress4X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
+FSEHIP_API size_t FSEHIP_HUF_decompress4X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
+/* lib/huf.h:66, :95, :82 */
+FSEHIP_API size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+FSEHIP_API size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);
+FSEHIP_API size_t FSEHIP_HUF_decompress(void* dst, size_t originalSize, const void* cSrc, size_t cSrcSize);
+
+/* =================================================================================================
+ *  Layer 2 -- batched, DEVICE pointers.  Block b lives at base + b*stride.  `d_sizes` may be
+ *  NULL, in which case every block has `uniformSize` bytes.  `d_results[b]` receives exactly what
+ *  the corresponding single-block reference call would return for block b.  `stream` is a
+ *  hipStream_t (NULL = default stream).  Return value: 0 (hipSuccess) or a hipError_t.
+ *  Launches are asynchronous on `stream`; the library never allocates on these paths.
+ * ================================================================================================= */
+/* HIST_count over a batch.  d_counts: nBlocks x 256 unsigned (entries 0..min(maxSV_in,255) written).
+ * d_maxSymbolValues: nBlocks in/out values (NULL = 255 in, not reported). */
+FSEHIP_API int FSEHIP_HIST_count_batch(unsigned* d_counts, unsigned* d_maxSymbolValues, size_t* d_results,
+                                       const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                       size_t nBlocks, void* stream);
+
+/* FSE_compress_usingCTable over a batch.  Table of block b: d_ctables + b*ctableStrideU32 (reference
+ * layout; pass ctableStrideU32 = 0 to share one table).  maxTableLog bounds the tableLog found in the
+ * tables (<= 12; smaller values raise occupancy); a table exceeding it yields ERROR(tableLog_tooLarge). */
+FSEHIP_API int FSEHIP_FSE_compress_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                     const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                                     const FSEHIP_FSE_CTable* d_ctables, size_t ctableStrideU32, unsigned maxTableLog,
+                                                     size_t nBlocks, void* stream);
+/* FSE_decompress_usingDTable over a batch (d_cSizes: exact compressed size per block). */
+FSEHIP_API int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                       const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                       const FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                       size_t nBlocks, void* stream);
+
+/* One-shot block API over a batch: FSE_compress2 (histogram, normalisation, NCount header, CTable,
+ * payload) and FSE_decompress_wksp(maxLog) entirely on the device.  d_workspace/workspaceBytes: scratch,
+ * at least FSEHIP_*_workspaceSize(1,...) bytes; larger workspaces process more blocks per pass (the
+ * *_workspaceSize(nBlocks, ...) value never needs to be exceeded). */
+FSEHIP_API size_t FSEHIP_FSE_compress_batch_workspaceSize(size_t nBlocks, unsigned tableLog);
+FSEHIP_API int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                         const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                         unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                         void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API size_t FSEHIP_FSE_decompress_batch_workspaceSize(size_t nBlocks, unsigned maxLog);
+FSEHIP_API int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                           const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                           unsigned maxLog, size_t nBlocks,
+                                           void* d_workspace, size_t workspaceBytes, void* stream);
+
+/* Huff0: HUF_compress4X_usingCTable / HUF_decompress4X1_usingDTable over a batch, and the one-shot
+ * HUF_compress2 / HUF_decompress (4X1 decoder) over a batch.  For the one-shot decoder d_dstSizes (or
+ * uniformDstSize) is the exact regenerated size of each block, as HUF_decompress requires. */
+FSEHIP_API int FSEHIP_HUF_compress4X_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                       const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                                       const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
+                                                       size_t nBlocks, void* stream);
+FSEHIP_API int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                          size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                          const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                          size_t nBlocks, void* stream);
+FSEHIP_API size_t FSEHIP_HUF_compress_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                         const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                         unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                         void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API size_t FSEHIP_HUF_decompress_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                           size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                           size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+
+/* Workload generator of the reference's benchmark (programs/probaGenerator.c:70-74,95-126), on the
+ * device: block b = generate(blockSize bytes, table, seed = firstSeed + b).  h_table4096 is the
+ * HOST 4096-entry symbol table built by FSEHIP_probagen_table(). */
+FSEHIP_API void FSEHIP_probagen_table(uint8_t table4096[4096], double p);
+FSEHIP_API int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
+                                     const uint8_t h_table4096[4096], uint32_t firstSeed, void* stream);
+
+/* build / device info: returns 0 and fills the fields when a gfx950 device is current */
+typedef struct { int deviceOrdinal; int computeUnits; int ldsBytesPerCU; int wavefrontSize; char archName[64]; } FSEHIP_DeviceInfo;
+FSEHIP_API int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info);
+FSEHIP_API const char* FSEHIP_versionString(void);
+
+#ifdef FSEHIP_DROPIN_NAMES
+#define HIST_count FSEHIP_HIST_count
+#define FSE_compress FSEHIP_FSE_compress
+#define FSE_compress2 FSEHIP_FSE_compress2
+#define FSE_decompress FSEHIP_FSE_decompress
+#define FSE_compress_usingCTable FSEHIP_FSE_compress_usingCTable
+#define FSE_decompress_usingDTable FSEHIP_FSE_decompress_usingDTable
+#define HUF_compress FSEHIP_HUF_compress
+#define HUF_compress2 FSEHIP_HUF_compress2
+#define HUF_decompress FSEHIP_HUF_decompress
+#define HUF_compress1X_usingCTable FSEHIP_HUF_compress1X_usingCTable
+#define HUF_compress4X_usingCTable FSEHIP_HUF_compress4X_usingCTable
+#define HUF_decompress4X_usingDTable FSEHIP_HUF_decompress4X_usingDTable
+#define HUF_decompress4X1_usingDTable FSEHIP_HUF_decompress4X1_usingDTable
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSEHIP_H */

@@ -30,3 +30,13 @@ def ref():
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product: libfsehip.so through its C ABI.  GPU tests fail (not skip) if the library is missing."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from finitestateentropy_amd.api import FseHip
+    return FseHip()
