@@ -4,18 +4,24 @@
 // tANS decoding is one loop-carried chain per block (two interleaved states sharing one bit cursor), so
 // the mapping is "one lane per block, many blocks per CU": a 64-lane workgroup stages G DTables into LDS
 // (verbatim reference layout, coalesced copy) and lane g walks block g's stream.  Throughput comes from
-// the number of blocks resident per CU (bounded by LDS: 160 KiB / 8 KiB tables at tableLog 11).
+// the number of blocks resident per CU (bounded by LDS: 160 KiB / 8 KiB tables at tableLog 11) and from
+// the instruction count of the per-symbol step, because a wavefront issues one instruction every few
+// cycles no matter how many of its lanes are active.
 //
-// Exactness: the reference's result -- also on truncated / corrupt input -- is defined through its
-// 64-bit window mechanics (BIT_reloadDStream status codes).  The kernel therefore has two parts:
-//   * `BitReader`: a literal device restatement of that window (used for init and for the last few
-//     symbols of every stream), and
-//   * a bulk loop that fast-forwards whole 4-symbol iterations of lib/fse_decompress.c:201-218 while it is
-//     provable that the reference's loop condition holds (>= 128 unread bits, >= 4 output bytes left);
-//     inside that region the bits read are a pure function of the absolute bit position.
+// The kernel keeps the reference's own decoder state -- a 64-bit little-endian window at byte offset
+// `at` plus a consumed-bit count `used` (lib/bitstream.h:91-97) -- so results are identical by
+// construction, including on truncated / corrupt input:
+//   * `BitReader` is a literal device restatement of BIT_initDStream / BIT_readBits / BIT_reloadDStream;
+//   * the bulk loop is lib/fse_decompress.c:201-218 (4 symbols per reload) for as long as the window is at
+//     least 24 bytes above the stream start.  There the reload is always the "fast" one (:378-388), and
+//     the new window is not loaded but funnel-shifted out of two speculatively prefetched 8-byte words
+//     below it, so no memory latency sits on the dependent chain (gfx950 global memory accepts the
+//     unaligned 8-byte accesses this needs).
 #include "internal.h"
 
 enum { BR_UNFINISHED = 0, BR_END_OF_BUFFER = 1, BR_COMPLETED = 2, BR_OVERFLOW = 3 };   // bitstream.h:99-102
+
+DEV u64 ldg64u(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }           // unaligned global load
 
 struct BitReader {                                   // bitstream.h:91-97
     const u8* base; size_t size; size_t at; u64 win; u32 used;
@@ -25,7 +31,7 @@ struct BitReader {                                   // bitstream.h:91-97
         if (n < 1) return FERR(srcSize_wrong);
         const u32 last = src[n - 1];
         if (n >= 8) {
-            at = n - 8; win = ld64(src + at);
+            at = n - 8; win = ldg64u(src + at);
             if (last == 0) return FERR(GENERIC);
             used = 8 - hibit32(last);
         } else {
@@ -48,11 +54,11 @@ struct BitReader {                                   // bitstream.h:91-97
     DEV int reload()                                 // BIT_reloadDStream, :400-439
     {
         if (used > 64) return BR_OVERFLOW;
-        if (at >= 8) { at -= used >> 3; used &= 7; win = ld64(base + at); return BR_UNFINISHED; }
+        if (at >= 8) { at -= used >> 3; used &= 7; win = ldg64u(base + at); return BR_UNFINISHED; }
         if (at == 0) return used < 64 ? BR_END_OF_BUFFER : BR_COMPLETED;
         u32 nbytes = used >> 3; int res = BR_UNFINISHED;
         if (at < nbytes) { nbytes = (u32)at; res = BR_END_OF_BUFFER; }
-        at -= nbytes; used -= nbytes * 8; win = ld64(base + at);
+        at -= nbytes; used -= nbytes * 8; win = ldg64u(base + at);
         return res;
     }
 };
@@ -65,6 +71,17 @@ DEV u32 fse_step(u32& state, BitReader& r, const u32* cells, bool fast)   // FSE
     state = (c & 0xFFFFu) + low;
     return (c >> 16) & 0xFFu;
 }
+
+// one bulk step: cell lookup, take nb bits from the top of `t` (the not-yet-consumed window, MSB aligned),
+// next state = newState + bits, symbol byte inserted into `word` with one v_perm.
+#define FSE_BULK_STEP(state, SEL)                                                          \
+    {   const u32 c = cells[state];                                                        \
+        const u32 nb = c >> 24;                                                            \
+        const u32 bits = __builtin_amdgcn_ubfe((u32)(t >> 32), 32u - nb, nb);              \
+        t <<= nb; used += nb;                                                              \
+        state = (c & 0xFFFFu) + bits;                                                      \
+        word = __builtin_amdgcn_perm(c, word, SEL);                                        \
+    }
 
 __global__ __launch_bounds__(64) void k_fse_decode(FseDecArgs a)
 {
@@ -108,53 +125,32 @@ __global__ __launch_bounds__(64) void k_fse_decode(FseDecArgs a)
     u32 s1 = r.read(tl); r.reload();                 // FSE_initDState x2, fse.h:577-584
     u32 s2 = r.read(tl); r.reload();
 
-    // ------------------------------------------------------------------------------------------------
-    // bulk fast-forward.  C = bits consumed from the end of the stream (pad + end mark included),
-    // R = 8*S - C unread bits.  Start of an iteration with R >= 128 implies the reference's window
-    // pointer stays >= start+8 (reload "unfinished"), and op < omax-3 is its second loop condition.
-    // ------------------------------------------------------------------------------------------------
-    if (S >= 16) {
-        long R = (long)(8 * S) - (long)(8 * (S - 8 - r.at) + r.used);
-        if (R >= 128 && op < omax - 3) {
-            const u64 topbit = 8 * (u64)(uintptr_t)in + (u64)R;         // absolute bit address one above the next unread bit
-            const u32* const wmin = (const u32*)((uintptr_t)in & ~(uintptr_t)3);
-            const u32* w = (const u32*)(uintptr_t)(((topbit - 1) >> 5) << 2);   // aligned word holding the next unread bit
-            const u32 sh = (u32)(32 * ((u64)((uintptr_t)w >> 2) + 1) - topbit);  // bits of *w above the cursor (0..31)
-            u64 win = (((u64)w[0] << 32) | (u64)w[-1]) << sh;             // next unread bit sits at bit 63
-            u32 avail = 64 - sh;
-            w -= 2;
-            u32 nxt = *(w >= wmin ? w : wmin);
-            const bool al4 = (((uintptr_t)out) & 3u) == 0;
-            do {
-                u32 c, nb, word;
-                // state1
-                c = cells[s1]; nb = c >> 24;
-                s1 = (c & 0xFFFFu) + (u32)((win >> 1) >> (63 - nb)); win <<= nb; avail -= nb; R -= nb;
-                word = (c >> 16) & 0xFFu;
-                // state2
-                c = cells[s2]; nb = c >> 24;
-                s2 = (c & 0xFFFFu) + (u32)((win >> 1) >> (63 - nb)); win <<= nb; avail -= nb; R -= nb;
-                word |= ((c >> 16) & 0xFFu) << 8;
-                if (avail <= 32) { win |= (u64)nxt << (32 - avail); avail += 32; --w; nxt = *(w >= wmin ? w : wmin); }
-                // state1
-                c = cells[s1]; nb = c >> 24;
-                s1 = (c & 0xFFFFu) + (u32)((win >> 1) >> (63 - nb)); win <<= nb; avail -= nb; R -= nb;
-                word |= ((c >> 16) & 0xFFu) << 16;
-                // state2
-                c = cells[s2]; nb = c >> 24;
-                s2 = (c & 0xFFFFu) + (u32)((win >> 1) >> (63 - nb)); win <<= nb; avail -= nb; R -= nb;
-                word |= (c >> 16) << 24;        // nbBits is shifted out of the top
-                if (avail <= 32) { win |= (u64)nxt << (32 - avail); avail += 32; --w; nxt = *(w >= wmin ? w : wmin); }
-                if (al4) *(u32*)(out + op) = word;
-                else { out[op] = (u8)word; out[op + 1] = (u8)(word >> 8); out[op + 2] = (u8)(word >> 16); out[op + 3] = (u8)(word >> 24); }
-                op += 4;
-            } while (R >= 128 && op < omax - 3);
-            // hand the exact (normalised) window back to the literal reader
-            const u64 C = 8 * (u64)S - (u64)R;
-            r.at = S - 8 - (size_t)(C >> 3);
-            r.used = (u32)(C & 7);
-            r.win = ld64(in + r.at);
-        }
+    // ---- bulk: iterations of fse_decompress.c:201-218 whose loop-head reload is provably the fast one
+    if (r.at >= 24 && op < omax - 3 && r.used <= 64) {
+        u64 at = r.at;
+        u32 used = r.used;
+        u64 win = r.win;
+        u64 lo1 = ldg64u(in + at - 8);               // bytes [at-8, at)
+        u64 lo2 = ldg64u(in + at - 16);              // bytes [at-16, at-8)
+        long groups = (omax - 3 - op + 3) >> 2;      // iterations allowed by "op < olimit"
+        do {
+            // BIT_reloadDStreamFast: at -= used>>3; used &= 7; window = 8 bytes at `at`
+            const u32 k8 = used & ~7u;               // whole consumed bytes, in bits (0..48)
+            at -= used >> 3; used &= 7;
+            win = (win << k8) | ((lo1 >> 1) >> (63 - k8));
+            lo1 = (lo1 << k8) | ((lo2 >> 1) >> (63 - k8));
+            lo2 = ldg64u(in + at - 16);              // needed two reloads from now
+            u64 t = win << used;
+            u32 word = 0;
+            FSE_BULK_STEP(s1, 0x03020106u)           // v_perm: {c = bytes 4..7, word = bytes 0..3}; byte k <- c.byte2 (index 6)
+            FSE_BULK_STEP(s2, 0x03020600u)
+            FSE_BULK_STEP(s1, 0x03060100u)
+            FSE_BULK_STEP(s2, 0x06020100u)
+            __builtin_memcpy(out + op, &word, 4);
+            op += 4;
+            --groups;
+        } while (at >= 24 && groups > 0);
+        r.at = (size_t)at; r.used = used; r.win = win;
     }
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
