@@ -58,6 +58,55 @@ extern "C" int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info)
     return 0;
 }
 
+// ---- kernel timing probe ------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct Probe {
+    bool on = false;
+    std::vector<hipEvent_t> pool;            // reusable events
+    size_t used = 0;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    hipEvent_t pending[PK_COUNT] = {};
+    hipEvent_t get()
+    {
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[used++];
+    }
+} g_probe;
+}
+void probe_before(int id, hipStream_t s)
+{
+    if (!g_probe.on) return;
+    hipEvent_t e = g_probe.get();
+    g_probe.pending[id] = e;
+    if (e) (void)hipEventRecord(e, s);
+}
+void probe_after(int id, hipStream_t s)
+{
+    if (!g_probe.on) return;
+    hipEvent_t e = g_probe.get();
+    if (e && g_probe.pending[id]) { (void)hipEventRecord(e, s); g_probe.recs.push_back({ id, g_probe.pending[id], e }); }
+}
+extern "C" int FSEHIP_probe_begin(void)
+{
+    g_probe.on = true; g_probe.used = 0; g_probe.recs.clear();
+    return 0;
+}
+extern "C" int FSEHIP_probe_collect(double* totalMs, unsigned* launches)
+{
+    for (int i = 0; i < 16; ++i) { totalMs[i] = 0; launches[i] = 0; }
+    g_probe.on = false;
+    for (auto& r : g_probe.recs) {
+        CK(hipEventSynchronize(r.b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, r.a, r.b));
+        totalMs[r.id] += ms; launches[r.id] += 1;
+    }
+    g_probe.recs.clear(); g_probe.used = 0;
+    return 0;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline BlockView mkview(const void* base, size_t stride, const size_t* sizes, size_t uniform)
 {

@@ -190,6 +190,8 @@ hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
     if (a.G > 64) a.G = 64;
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
+    probe_before(PK_FSE_DECODE, s);
     hipLaunchKernelGGL(k_fse_decode, dim3((unsigned)groups), dim3(64), ldsBytes, s, a);
+    probe_after(PK_FSE_DECODE, s);
     return hipGetLastError();
 }

@@ -168,6 +168,8 @@ hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s)
     if (a.nBlocks > 1 && ((a.src.stride > 0x3FFFFFFu) || (a.dstStride > 0x3FFFFFFu))) return hipErrorInvalidValue;
     if (a.dstCapacity > 0x7FFFFFF0u) a.dstCapacity = 0x7FFFFFF0u;   // blocks are < 2 GiB on this path (see kernel)
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
+    probe_before(PK_FSE_ENCODE, s);
     hipLaunchKernelGGL(k_fse_encode, dim3((unsigned)groups), dim3(64), ldsBytes, s, a);
+    probe_after(PK_FSE_ENCODE, s);
     return hipGetLastError();
 }

@@ -371,12 +371,16 @@ __global__ __launch_bounds__(64) void k_fse_dprep(FseDPrepArgs a)
 hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    probe_before(PK_FSE_CPREP, s);
     hipLaunchKernelGGL(k_fse_cprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    probe_after(PK_FSE_CPREP, s);
     return hipGetLastError();
 }
 hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    probe_before(PK_FSE_DPREP, s);
     hipLaunchKernelGGL(k_fse_dprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    probe_after(PK_FSE_DPREP, s);
     return hipGetLastError();
 }

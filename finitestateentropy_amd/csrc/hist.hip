@@ -108,6 +108,8 @@ __global__ __launch_bounds__(64) void k_hist(HistArgs a)
 hipError_t launch_hist(const HistArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    probe_before(PK_HIST, s);
     hipLaunchKernelGGL(k_hist, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    probe_after(PK_HIST, s);
     return hipGetLastError();
 }

@@ -173,6 +173,13 @@ FSEHIP_API void FSEHIP_probagen_table(uint8_t table4096[4096], double p);
 FSEHIP_API int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
                                      const uint8_t h_table4096[4096], uint32_t firstSeed, void* stream);
 
+/* Kernel timing probe for benchmarks: between probe_begin and probe_collect every kernel launch of the library is
+ * bracketed by HIP events on its own stream.  probe_collect synchronises and returns, per kernel id
+ * (0 hist, 1 fse_cprep, 2 fse_encode, 3 fse_dprep, 4 fse_decode, 5 huf_cprep, 6 huf_encode, 7 huf_dprep,
+ * 8 huf_decode), the summed duration in milliseconds and the number of launches.  Arrays hold 16 entries. */
+FSEHIP_API int FSEHIP_probe_begin(void);
+FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
+
 /* build / device info: returns 0 and fills the fields when a gfx950 device is current */
 typedef struct { int deviceOrdinal; int computeUnits; int ldsBytesPerCU; int wavefrontSize; char archName[64]; } FSEHIP_DeviceInfo;
 FSEHIP_API int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info);
