@@ -190,3 +190,95 @@ class FseHip:
 
     def fse_decompress(self, csrc, cap):
         return self._single("FSEHIP_FSE_decompress", cap, csrc)
+
+
+# ---------------------------------------------------------------------------------------------------------
+#  Huff0 (lib/huf.h)
+# ---------------------------------------------------------------------------------------------------------
+def _huf_methods():
+    def huf_workspace(self, n_blocks, decompress=False, device="cuda"):
+        fn = self.lib.FSEHIP_HUF_decompress_batch_workspaceSize if decompress else self.lib.FSEHIP_HUF_compress_batch_workspaceSize
+        return torch.empty(int(fn(SZ(n_blocks))), dtype=torch.uint8, device=device)
+
+    def huf_compress_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
+        n = src.shape[0]
+        cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        if dst is None:
+            dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=src.device)
+        if workspace is None:
+            workspace = self.huf_workspace(n, False, src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        _check(self.lib.FSEHIP_HUF_compress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(src.stride(0)), ps, uni,
+                                                  C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace),
+                                                  SZ(workspace.numel()), _stream()), "HUF_compress_batch")
+        return dst, results
+
+    def huf_decompress_batch(self, csrc, csizes, dst_sizes, dst=None, results=None, workspace=None):
+        n = csrc.shape[0]
+        width = dst_sizes if isinstance(dst_sizes, int) else int(dst_sizes.max().item())
+        if dst is None:
+            dst = torch.empty((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=csrc.device)
+        if workspace is None:
+            workspace = self.huf_workspace(n, True, csrc.device)
+        pc, unic, keepc = _sizes_arg(csizes)
+        pd, unid, keepd = _sizes_arg(dst_sizes)
+        _check(self.lib.FSEHIP_HUF_decompress_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(results), _ptr(csrc), SZ(csrc.stride(0)), pc, unic,
+                                                    SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()), "HUF_decompress_batch")
+        return dst, results
+
+    def huf_compress4x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
+        """ctables: (n, 256) int32/uint32 HUF_CElt entries (val | nbBits << 16)"""
+        n = src.shape[0]
+        cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        stride = 0 if shared_table else ctables.stride(0)
+        _check(self.lib.FSEHIP_HUF_compress4X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
+                                                                ps, uni, _ptr(ctables), SZ(stride), SZ(n), _stream()),
+               "HUF_compress4X_usingCTable_batch")
+        return dst, res
+
+    def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
+        n = csrc.shape[0]
+        width = dst_sizes if isinstance(dst_sizes, int) else int(dst_sizes.max().item())
+        dst = torch.zeros((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
+        res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
+        pc, unic, keepc = _sizes_arg(csizes)
+        pd, unid, keepd = _sizes_arg(dst_sizes)
+        stride = 0 if shared_table else dtables.stride(0)
+        _check(self.lib.FSEHIP_HUF_decompress4X1_usingDTable_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(res), _ptr(csrc), SZ(csrc.stride(0)),
+                                                                   pc, unic, _ptr(dtables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()),
+               "HUF_decompress4X1_usingDTable_batch")
+        return dst, res
+
+    # layer 1
+    def huf_compress2(self, src, max_sv=255, huff_log=11, cap=None):
+        return self._single("FSEHIP_HUF_compress2", huf_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(huff_log))
+
+    def huf_decompress(self, csrc, dst_size):
+        return self._single("FSEHIP_HUF_decompress", dst_size, csrc)
+
+    def huf_compress1x_using_ctable(self, src, celt, cap=None):
+        celt = np.ascontiguousarray(celt, dtype=np.uint32)
+        return self._single("FSEHIP_HUF_compress1X_usingCTable", huf_compress_bound(len(src)) if cap is None else cap, src, celt.ctypes.data_as(VP))
+
+    def huf_compress4x_using_ctable(self, src, celt, cap=None):
+        celt = np.ascontiguousarray(celt, dtype=np.uint32)
+        return self._single("FSEHIP_HUF_compress4X_usingCTable", huf_compress_bound(len(src)) if cap is None else cap, src, celt.ctypes.data_as(VP))
+
+    def huf_decompress4x1_using_dtable(self, csrc, dt, dst_size):
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        return self._single("FSEHIP_HUF_decompress4X1_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
+
+    for f in (huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch,
+              huf_decompress4x1_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
+              huf_compress4x_using_ctable, huf_decompress4x1_using_dtable):
+        setattr(FseHip, f.__name__, f)
+
+
+_huf_methods()

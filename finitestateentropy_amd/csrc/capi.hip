@@ -403,3 +403,215 @@ extern "C" size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const voi
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
     return r;
 }
+
+// =====================================================================================================
+//  a4 / a5: Huff0 hot loops over a batch
+// =====================================================================================================
+extern "C" int FSEHIP_HUF_compress4X_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                       const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                                       const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
+                                                       size_t nBlocks, void* stream)
+{
+    HufEncArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
+    a.src = mkview(d_src, srcStride, d_sizes, uniformSize);
+    a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr; a.streams = 4; a.nBlocks = nBlocks;
+    return (int)launch_huf_encode(a, (hipStream_t)stream);
+}
+
+extern "C" int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                          size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                          const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                          size_t nBlocks, void* stream)
+{
+    if (maxTableLog == 0 || maxTableLog > FSEHIP_HUF_TABLELOG_MAX) maxTableLog = FSEHIP_HUF_TABLELOG_MAX;
+    HufDecArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
+    a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
+    a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.nBlocks = nBlocks;
+    return (int)launch_huf_decode(a, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+//  one-shot Huff0 block API over a batch
+// =====================================================================================================
+static const size_t HUF_CWS_PER_BLOCK = 1024 + 4 + 8 + sizeof(HufMeta) + 1024 + 4096;
+extern "C" size_t FSEHIP_HUF_compress_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    if (c == 0) c = 1;
+    return c * HUF_CWS_PER_BLOCK + WS_SLACK;
+}
+
+extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                         const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                         unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                         void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) return 0;
+    if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255) return (int)hipErrorInvalidValue;   // huf_compress.c:659-660 (see single-block wrapper)
+    if (workspaceBytes < HUF_CWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / HUF_CWS_PER_BLOCK;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
+    unsigned* counts = (unsigned*)carve(chunk * 1024);
+    unsigned* maxSVs = (unsigned*)carve(chunk * 4);
+    size_t* hres = (size_t*)carve(chunk * 8);
+    HufMeta* meta = (HufMeta*)carve(chunk * sizeof(HufMeta));
+    u32* ctables = (u32*)carve(chunk * 1024);
+    void* nodes = (void*)p;
+    const unsigned msv = maxSymbolValue ? maxSymbolValue : 255;   // huf_compress.c:661
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        const BlockView src = mkview((const u8*)d_src + b0 * srcStride, srcStride, d_sizes ? d_sizes + b0 : nullptr, uniformSize);
+        HistArgs h;
+        h.counts = counts; h.maxSVs = maxSVs; h.uniformMaxSV = msv; h.useUniformIn = 1; h.results = hres; h.src = src; h.nBlocks = nb;
+        CK(launch_hist(h, s));
+        HufCPrepArgs c;
+        c.counts = counts; c.maxSVs = maxSVs; c.histResults = hres; c.src = src;
+        c.dst = (u8*)d_dst + b0 * dstStride; c.dstStride = dstStride; c.dstCapacity = dstCapacity;
+        c.maxSVReq = msv; c.huffLogReq = tableLog; c.ctables = ctables; c.ctStrideU32 = 256;
+        c.meta = meta; c.results = d_results + b0; c.nBlocks = nb;
+        CK(launch_huf_cprep(c, s, nodes));
+        HufEncArgs e;
+        e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
+        e.src = src; e.ctables = ctables; e.ctStrideU32 = 256; e.meta = meta; e.streams = 4; e.nBlocks = nb;
+        CK(launch_huf_encode(e, s));
+    }
+    return 0;
+}
+
+static const size_t HUF_DWS_PER_BLOCK = sizeof(HufMeta) + 4 * (size_t)FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1);
+extern "C" size_t FSEHIP_HUF_decompress_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    if (c == 0) c = 1;
+    return c * HUF_DWS_PER_BLOCK + WS_SLACK;
+}
+
+extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                           size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                           size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) return 0;
+    if (workspaceBytes < HUF_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / HUF_DWS_PER_BLOCK;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
+    u32* dtables = (u32*)p;
+    const size_t dtU32 = FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1);      // 2-byte cells: 2^tableLog cells = 2^(tableLog-1) words
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
+        const BlockView ds = mkview(nullptr, 0, d_dstSizes ? d_dstSizes + b0 : nullptr, uniformDstSize);
+        HufDPrepArgs d;
+        d.csrc = cs; d.dstSizes = ds; d.dst = (u8*)d_dst + b0 * dstStride; d.dstStride = dstStride;
+        d.dtables = dtables; d.dtStrideU32 = dtU32; d.meta = meta; d.results = d_results + b0; d.nBlocks = nb;
+        CK(launch_huf_dprep(d, s));
+        HufDecArgs e;
+        e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstSizes = ds; e.results = d_results + b0;
+        e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
+        e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.nBlocks = nb;
+        CK(launch_huf_decode(e, s));
+    }
+    return 0;
+}
+
+// ---- Layer 1, Huff0 ---------------------------------------------------------------------------------
+static size_t huf_using_ctable_host(int streams, void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable)
+{
+    // the opaque HUF_CElt table holds maxSymbolValue+1 entries; only entries of symbols present in src are read
+    unsigned maxByte = 0;
+    for (size_t i = 0; i < srcSize; i++) { const unsigned v = ((const u8*)src)[i]; if (v > maxByte) maxByte = v; }
+    u32 table[256];
+    memset(table, 0, sizeof(table));
+    memcpy(table, CTable, ((size_t)maxByte + 1) * 4);
+    DevBuf dsrc, ddst, dct, dres;
+    HK(dsrc.alloc(srcSize)); HK(ddst.alloc(dstSize)); HK(dct.alloc(1024)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dct.p, table, 1024, hipMemcpyHostToDevice));
+    HufEncArgs a;
+    a.dst = (u8*)ddst.p; a.dstStride = dstSize; a.dstCapacity = dstSize; a.results = (size_t*)dres.p;
+    a.src = mkview(dsrc.p, srcSize, nullptr, srcSize);
+    a.ctables = (const u32*)dct.p; a.ctStrideU32 = 0; a.meta = nullptr; a.streams = streams; a.nBlocks = 1;
+    HK(launch_huf_encode(a, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r, hipMemcpyDeviceToHost));
+    return r;
+}
+extern "C" size_t FSEHIP_HUF_compress1X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable)
+{
+    return huf_using_ctable_host(1, dst, dstSize, src, srcSize, CTable);
+}
+extern "C" size_t FSEHIP_HUF_compress4X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable)
+{
+    return huf_using_ctable_host(4, dst, dstSize, src, srcSize, CTable);
+}
+
+extern "C" size_t FSEHIP_HUF_decompress4X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+{
+    const u32 desc = DTable[0];
+    if (((desc >> 8) & 0xFF) != 0) return FSEHIP_ERROR(GENERIC);              // huf_decompress.c:411-412
+    const unsigned tl = (desc >> 16) & 0xFF;
+    if (tl > FSEHIP_HUF_TABLELOG_MAX) return FSEHIP_ERROR(tableLog_tooLarge);
+    const size_t words = 1 + (tl ? ((size_t)1 << (tl - 1)) : 1);
+    DevBuf dsrc, ddst, ddt, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(maxDstSize)); HK(ddt.alloc(words * 4)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK(hipMemcpy(ddt.p, DTable, words * 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HUF_decompress4X1_usingDTable_batch(ddst.p, maxDstSize, nullptr, maxDstSize, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
+                                                              (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= maxDstSize ? r : maxDstSize, hipMemcpyDeviceToHost));
+    return r;
+}
+extern "C" size_t FSEHIP_HUF_decompress4X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+{
+    // lib/huf_decompress.c:980-997 dispatches on tableType; the device decoder implements X1 cells (tableType 0).
+    return FSEHIP_HUF_decompress4X1_usingDTable(dst, maxDstSize, cSrc, cSrcSize, DTable);
+}
+
+extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)
+{
+    // argument checks in the reference's order (huf_compress.c:654-660)
+    if (!srcSize) return 0;
+    if (!dstCapacity) return 0;
+    if (srcSize > FSEHIP_HUF_BLOCKSIZE_MAX) return FSEHIP_ERROR(srcSize_wrong);
+    if (tableLog > FSEHIP_HUF_TABLELOG_MAX) return FSEHIP_ERROR(tableLog_tooLarge);
+    if (maxSymbolValue > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);
+    const size_t wsBytes = FSEHIP_HUF_compress_batch_workspaceSize(1);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(srcSize)); HK(ddst.alloc(dstCapacity)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HUF_compress_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize,
+                                             maxSymbolValue, tableLog, 1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r, hipMemcpyDeviceToHost));   // r == 1: the RLE byte sits in dst[0] (:673)
+    return r;
+}
+extern "C" size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)   // huf_compress.c:795-798
+{
+    return FSEHIP_HUF_compress2(dst, dstCapacity, src, srcSize, 255, FSEHIP_HUF_TABLELOG_DEFAULT);
+}
+extern "C" size_t FSEHIP_HUF_decompress(void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize)   // huf_decompress.c:1056-1081 (4X1 branch)
+{
+    if (dstSize == 0) return FSEHIP_ERROR(dstSize_tooSmall);
+    const size_t wsBytes = FSEHIP_HUF_decompress_batch_workspaceSize(1);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstSize)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HUF_decompress_batch(ddst.p, dstSize, nullptr, dstSize, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
+                                               1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstSize ? r : dstSize, hipMemcpyDeviceToHost));
+    return r;
+}

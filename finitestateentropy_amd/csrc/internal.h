@@ -92,7 +92,7 @@ struct HufCPrepArgs {            // glue g5-g7: lib/huf_compress.c:637-724 minus
     size_t* results;
     size_t nBlocks;
 };
-hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s);
+hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* nodeScratch /* 4 KiB per block */);
 
 struct HufEncArgs {              // a4: HUF_compress4X_usingCTable (streams = 4) / 1X (streams = 1), one workgroup per block
     u8* dst; size_t dstStride; size_t dstCapacity;

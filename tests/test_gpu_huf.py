@@ -1,0 +1,198 @@
+"""GPU parity tests for Huff0 (C ABI of libfsehip.so vs the CPU oracle): 4-stream encode, X1 decode, one-shot."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import huf_compress_bound, is_error
+from test_gpu_fse import mixed_blocks, s64
+
+pytestmark = pytest.mark.gpu
+
+
+def _huf_tables(oracle, blk, req):
+    mx, msv, cnt = oracle.hist_count(blk)
+    n = len(blk)
+    if mx == n or msv == 0 or n < 2:
+        return None
+    hl = oracle.fse_optimal_tablelog(req, n, msv, 1)
+    mb, celt = oracle.huf_build_ctable(cnt, msv, hl)
+    if is_error(mb):
+        return None
+    hs, hdr = oracle.huf_write_ctable(256, celt, msv, mb)
+    if is_error(hs):
+        return None
+    r, dt = oracle.huf_read_dtable_x1(hdr[:hs], 11)
+    if is_error(r):
+        return None
+    celt = celt.copy(); celt[msv + 1:] = 0
+    return mb, celt, dt
+
+
+@pytest.mark.parametrize("size", [12, 13, 14, 15, 16, 100, 1001, 4097, 32767, 32768, 65536, 131072])
+def test_huf_using_tables_batch(hip, oracle, size):
+    for req in (11, 12, 6, 8):
+        blocks = mixed_blocks(oracle, 20, size, seed=7 * req)
+        keep, cts, dts = [], [], []
+        for b in range(20):
+            t = _huf_tables(oracle, blocks[b], req)
+            if t is None:
+                continue
+            keep.append(b); cts.append(t[1]); dts.append(t[2])
+        if not keep:
+            continue
+        src = torch.from_numpy(blocks[keep]).cuda()
+        d_ct = torch.from_numpy(np.stack(cts).view(np.int32)).cuda()
+        d_dt = torch.from_numpy(np.stack(dts).view(np.int32)).cuda()
+        full = [oracle.huf_compress4x_using_ctable(blocks[b], cts[i]) for i, b in enumerate(keep)]
+        c0 = full[0][0]
+        for cap in [huf_compress_bound(size), 0, 16, 17, 18] + ([c0 - 1, c0, c0 + 7, c0 + 8, c0 + 9] if c0 else []):
+            if cap < 0:
+                continue
+            dst, res = hip.huf_compress4x_using_ctable_batch(src, d_ct, dst_capacity=cap)
+            dst, res = dst.cpu().numpy(), res.cpu().numpy()
+            for i, b in enumerate(keep):
+                r, out = oracle.huf_compress4x_using_ctable(blocks[b], cts[i], cap)
+                assert res[i] == s64(r), (size, req, cap, b, res[i], r)
+                if r:
+                    assert (dst[i][:r] == out[:r]).all(), (size, req, cap, b)
+        cbuf = np.zeros((len(keep), huf_compress_bound(size)), np.uint8)
+        csz = np.zeros(len(keep), np.int64)
+        for i, (r, out) in enumerate(full):
+            cbuf[i, :r] = out[:r]; csz[i] = r
+        ok = csz > 0
+        if not ok.any():
+            continue
+        d_c = torch.from_numpy(cbuf[ok]).cuda(); d_sz = torch.from_numpy(csz[ok]).cuda()
+        d_dt_ok = d_dt[torch.from_numpy(ok).cuda()]
+        idx = [k for k, f in zip(keep, ok) if f]
+        dts_ok = [d for d, f in zip(dts, ok) if f]
+        for dsz in (size, size - 1, size + 1, size + 4):
+            dst, res = hip.huf_decompress4x1_using_dtable_batch(d_c, d_sz, d_dt_ok, dsz)
+            dst, res = dst.cpu().numpy(), res.cpu().numpy()
+            for i, b in enumerate(idx):
+                r, out = oracle.huf_decompress4x1_using_dtable(cbuf[ok][i][:csz[ok][i]], dts_ok[i], dsz)
+                assert res[i] == s64(r), (size, req, dsz, b, res[i], r)
+                if dsz == size:
+                    assert r == size and (dst[i][:size] == blocks[b]).all(), (size, req, b)
+
+
+@pytest.mark.parametrize("size", [0, 1, 11, 12, 13, 100, 1000, 4097, 32767, 32768, 131072, 131073])
+def test_huf_oneshot_batch(hip, oracle, size):
+    for tl in (11, 12, 0, 6, 8):
+        blocks = mixed_blocks(oracle, 30, size, seed=31 + tl)
+        src = torch.from_numpy(blocks).cuda() if size else torch.zeros((30, 1), dtype=torch.uint8, device="cuda")
+        for cap in (huf_compress_bound(size), max(size // 2, 1), 20):
+            dst, res = hip.huf_compress_batch(src, table_log=tl, sizes=size, dst_capacity=cap)
+            dst, res = dst.cpu().numpy(), res.cpu().numpy()
+            if size:
+                _, ores, odst = oracle.compress_batch(1, blocks, table_log=tl, cap=cap)
+            else:
+                ores, odst = np.zeros(30, np.uint64), None
+            for b in range(30):
+                r = int(ores[b])
+                assert res[b] == s64(r), (size, tl, cap, b, res[b], r)
+                if not is_error(r) and r >= 1 and odst is not None:
+                    assert (dst[b][:r] == odst[b][:r]).all(), (size, tl, cap, b)
+            if cap != huf_compress_bound(size) or size == 0:
+                continue
+            ok = np.array([(not is_error(int(r))) and int(r) > 1 for r in ores])
+            if not ok.any():
+                continue
+            d_c = torch.from_numpy(odst[ok]).cuda(); d_sz = torch.from_numpy(ores[ok].astype(np.int64)).cuda()
+            out, dres = hip.huf_decompress_batch(d_c, d_sz, size)
+            out, dres = out.cpu().numpy(), dres.cpu().numpy()
+            for i, b in enumerate(np.nonzero(ok)[0]):
+                r, o = oracle.huf_decompress(odst[b][:int(ores[b])], size)
+                assert dres[i] == s64(r), (size, tl, b, dres[i], r)
+                if not is_error(r):
+                    assert (out[i][:size] == blocks[b]).all(), (size, tl, b)
+
+
+def test_huf_raw_and_rle_blocks(hip, oracle):
+    """HUF_decompress: cSrcSize == dstSize -> stored raw, cSrcSize == 1 -> RLE (lib/huf_decompress.c:1065-1066)."""
+    raw = np.arange(100, dtype=np.uint8)
+    buf = np.zeros((3, 128), np.uint8)
+    buf[0, :100] = raw; buf[1, 0] = 77; buf[2, :5] = 1
+    sizes = torch.tensor([100, 1, 200], dtype=torch.int64, device="cuda")
+    out, res = hip.huf_decompress_batch(torch.from_numpy(buf).cuda(), sizes, 100)
+    res = res.cpu().numpy(); out = out.cpu().numpy()
+    assert res[0] == 100 and (out[0][:100] == raw).all()
+    assert res[1] == 100 and (out[1][:100] == 77).all()
+    assert res[2] == s64(oracle.huf_decompress(buf[2][:128], 100)[0]) or res[2] == -4      # cSrcSize > dstSize
+
+
+def test_huf_decode_garbage_batch(hip, oracle):
+    """programs/fuzzerHuff0.c:228-250 on the device."""
+    rng = np.random.default_rng(23)
+    cases = []
+    for P in (2, 14, 80):
+        blk = oracle.probagen_batch(P, 1, 4096, P + 1)[0]
+        cs, comp = oracle.huf_compress2(blk)
+        comp = comp[:cs]
+        for trial in range(100):
+            bad = comp.copy()
+            kind = trial % 4
+            if kind == 0:
+                bad = bad[:int(rng.integers(2, cs))]
+            elif kind == 1:
+                bad[int(rng.integers(0, cs))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2:
+                bad = rng.integers(0, 256, int(rng.integers(2, 300)), dtype=np.uint8)
+            else:
+                bad[-1] = 0
+            cases.append(bad)
+    width = max(len(c) for c in cases) + 16
+    buf = np.zeros((len(cases), width), np.uint8)
+    for i, c in enumerate(cases):
+        buf[i, :len(c)] = c
+    sizes = np.array([len(c) for c in cases], np.int64)
+    d_c = torch.from_numpy(buf).cuda(); d_sz = torch.from_numpy(sizes).cuda()
+    for dsz in (4096, 4000, 5000):
+        out, res = hip.huf_decompress_batch(d_c, d_sz, dsz)
+        res = res.cpu().numpy(); out = out.cpu().numpy()
+        for i, c in enumerate(cases):
+            r, o = oracle.huf_decompress(c, dsz)
+            assert res[i] == s64(r), (i, dsz, len(c), res[i], r)
+            if not is_error(r):
+                assert (out[i][:r] == o[:r]).all(), (i, dsz)
+
+
+def test_huf_single_block_host_api(hip, oracle):
+    for P, n in ((14, 32768), (80, 4097), (2, 1000), (14, 13)):
+        blk = oracle.probagen_batch(P, 1, n, 3)[0]
+        a, b = hip.huf_compress2(blk), oracle.huf_compress2(blk)
+        assert a[0] == b[0] and (a[1][:a[0]] == b[1][:b[0]]).all()
+        if a[0] > 1:
+            x = hip.huf_decompress(a[1][:a[0]], n)
+            assert x[0] == n and (x[1] == blk).all()
+        t = _huf_tables(oracle, blk, 11)
+        if t:
+            for name in ("huf_compress1x_using_ctable", "huf_compress4x_using_ctable"):
+                e1, e2 = getattr(hip, name)(blk, t[1]), getattr(oracle, name)(blk, t[1])
+                assert e1[0] == e2[0] and (e1[1][:e1[0]] == e2[1][:e2[0]]).all(), name
+            e4 = oracle.huf_compress4x_using_ctable(blk, t[1])
+            if e4[0]:
+                d1 = hip.huf_decompress4x1_using_dtable(e4[1][:e4[0]], t[2], n)
+                assert d1[0] == n and (d1[1] == blk).all()
+    rle = np.full(500, 9, np.uint8)
+    a, b = hip.huf_compress2(rle), oracle.huf_compress2(rle)
+    assert a[0] == b[0] == 1 and a[1][0] == 9
+
+
+def test_huf_full_size_roundtrip_config4(hip, oracle):
+    """BASELINE config 4 shape (Proba14, 32 KB blocks, Huff0 4 streams): bytes == oracle, decode == source;
+    checksum of sizes over the first 1000 blocks == 17,266,350 (measured on the reference)."""
+    n = 1000
+    src = hip.probagen_batch(14, n, 32768, first_seed=1)
+    dst, res = hip.huf_compress_batch(src, table_log=11)
+    res_h = res.cpu().numpy()
+    assert int(res_h.sum()) == 17266350
+    host = src.cpu().numpy()
+    _, ores, odst = oracle.compress_batch(1, host, table_log=11)
+    assert (res_h == ores.astype(np.int64)).all()
+    dh = dst.cpu().numpy()
+    for b in range(n):
+        assert (dh[b][:res_h[b]] == odst[b][:res_h[b]]).all(), b
+    out, dres = hip.huf_decompress_batch(dst, res, 32768)
+    assert (dres.cpu().numpy() == 32768).all()
+    assert torch.equal(out, src)
