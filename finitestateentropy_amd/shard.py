@@ -1,0 +1,87 @@
+"""Block sharding across the GPUs of one node (one process per GPU, torch.distributed; "nccl" = RCCL on ROCm).
+
+Every 32 KB block is coded with its own table and shares no state with its neighbours (the reference's
+serial chunk loop, programs/bench.c:353-364,389-424, has no carried dependence), so the path shards by
+contiguous block ranges with NO collective on the data path.  Collectives appear only where a caller keeps
+the corpus on one rank: `scatter_blocks` (root -> ranks) before and `gather_blocks` (ranks -> root) after.
+Both use fixed-stride slots like the reference bench's output buffers (programs/bench.c:514-516,545), one
+point-to-point transfer per peer so that a root drives its xGMI links concurrently (a star, not a ring).
+
+Everything here is backend-agnostic (`gloo` on CPU tensors in the tests, `nccl`/RCCL on device tensors).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_blocks, rank, world):
+    """Contiguous range [lo, hi) of rank `rank`; sizes differ by at most one block."""
+    base, rem = divmod(n_blocks, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def scatter_blocks(blocks_root, n_blocks, block_bytes, rank, world, device, root=0, group=None):
+    """Root holds (n_blocks, block_bytes) uint8; every rank receives its shard_range rows."""
+    lo, hi = shard_range(n_blocks, rank, world)
+    mine = torch.empty((hi - lo, block_bytes), dtype=torch.uint8, device=device)
+    if world == 1:
+        mine.copy_(blocks_root[lo:hi])
+        return mine
+    if rank == root:
+        reqs = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_blocks, r, world)
+            if r == root:
+                mine.copy_(blocks_root[rlo:rhi])
+            elif rhi > rlo:
+                reqs.append(dist.isend(blocks_root[rlo:rhi].contiguous(), dst=r, group=group))
+        for q in reqs:
+            q.wait()
+    elif hi > lo:
+        dist.recv(mine, src=root, group=group)
+    return mine
+
+
+def gather_blocks(slots_mine, sizes_mine, n_blocks, rank, world, root=0, group=None):
+    """Fixed-stride result slots (rows, stride) + per-block result values -> root gets (n_blocks, stride) and sizes.
+    Non-root ranks return (None, None)."""
+    stride = slots_mine.shape[1]
+    if world == 1:
+        return slots_mine, sizes_mine
+    if rank == root:
+        out = torch.empty((n_blocks, stride), dtype=slots_mine.dtype, device=slots_mine.device)
+        sizes = torch.empty(n_blocks, dtype=sizes_mine.dtype, device=sizes_mine.device)
+        reqs = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_blocks, r, world)
+            if r == root:
+                out[rlo:rhi].copy_(slots_mine); sizes[rlo:rhi].copy_(sizes_mine)
+            elif rhi > rlo:
+                reqs.append(dist.irecv(out[rlo:rhi], src=r, group=group))
+                reqs.append(dist.irecv(sizes[rlo:rhi], src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return out, sizes
+    if slots_mine.shape[0]:
+        dist.send(slots_mine.contiguous(), dst=root, group=group)
+        dist.send(sizes_mine.contiguous(), dst=root, group=group)
+    return None, None
+
+
+def max_over_ranks(values, device, world, group=None):
+    """bench.py timing rule: the slowest rank defines the step time."""
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [float(x) for x in t.tolist()]
+
+
+def sharded_roundtrip(blocks_root, n_blocks, block_bytes, rank, world, device, compress_fn, decompress_fn, root=0):
+    """scatter -> per-rank compress -> per-rank decompress -> gather (compressed slots + sizes, decoded blocks).
+    compress_fn(blocks) -> (slots, sizes); decompress_fn(slots, sizes, block_bytes) -> (blocks, results)."""
+    mine = scatter_blocks(blocks_root, n_blocks, block_bytes, rank, world, device, root)
+    slots, sizes = compress_fn(mine)
+    back, results = decompress_fn(slots, sizes, block_bytes)
+    g_slots, g_sizes = gather_blocks(slots, sizes, n_blocks, rank, world, root)
+    g_back, g_res = gather_blocks(back, results, n_blocks, rank, world, root)
+    return g_slots, g_sizes, g_back, g_res

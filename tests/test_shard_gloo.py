@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes exercise the shard / scatter / gather plumbing of
+finitestateentropy_amd.shard with the CPU oracle standing in for the device codec (test infrastructure only)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_blocks, block_bytes, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from finitestateentropy_amd import shard
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    blocks_root = None
+    if rank == 0:
+        mix = [orc.probagen_batch(P, n_blocks // 3 + 1, block_bytes, 1)[:n_blocks // 3 + 1] for P in (2, 14, 80)]
+        allb = np.empty((n_blocks, block_bytes), np.uint8)
+        for b in range(n_blocks):
+            allb[b] = mix[b % 3][b // 3]
+        blocks_root = torch.from_numpy(allb)
+
+    def comp(x):
+        _, res, dst = orc.compress_batch(0, x.numpy(), table_log=11, nthreads=1)
+        return torch.from_numpy(dst), torch.from_numpy(res.astype(np.int64))
+
+    def decomp(slots, sizes, bs):
+        _, res, out = orc.decompress_batch(0, slots.numpy(), sizes.numpy().astype(np.uint64), bs, nthreads=1)
+        return torch.from_numpy(out), torch.from_numpy(res.astype(np.int64))
+
+    g_slots, g_sizes, g_back, g_res = shard.sharded_roundtrip(blocks_root, n_blocks, block_bytes, rank, world, "cpu", comp, decomp)
+    t = shard.max_over_ranks([float(rank + 1), 0.5], "cpu", world)
+    assert t == [float(world), 0.5]
+    if rank == 0:
+        s_slots, s_sizes = comp(blocks_root)
+        ok = bool((g_sizes == s_sizes).all()) and all(
+            bool((g_slots[b, :int(s_sizes[b])] == s_slots[b, :int(s_sizes[b])]).all()) for b in range(n_blocks))
+        ok = ok and bool((g_res == block_bytes).all()) and bool((g_back == blocks_root).all())
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges():
+    sys.path.insert(0, ROOT)
+    from finitestateentropy_amd.shard import shard_range
+    for n in (0, 1, 7, 8, 100000, 1000003):
+        for w in (1, 2, 3, 4, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_scatter_compress_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 37, 4096, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
