@@ -203,7 +203,13 @@ static FseCWs fse_cws(unsigned tableLog)
     return w;
 }
 #define WS_SLACK 2048
-#define WS_MAX_CHUNK 16384
+#define WS_MAX_CHUNK 24576
+// largest chunk <= limit that is a whole number of device-filling rounds of the hot-loop kernel (no ragged last wave of workgroups)
+static size_t round_chunk(size_t limit, size_t perRound)
+{
+    if (perRound == 0 || limit < perRound) return limit;
+    return limit / perRound * perRound;
+}
 
 extern "C" size_t FSEHIP_FSE_compress_batch_workspaceSize(size_t nBlocks, unsigned tableLog)
 {
@@ -225,6 +231,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     if (workspaceBytes < w.perBlock + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / w.perBlock;
     if (chunk > nBlocks) chunk = nBlocks;
+    else chunk = round_chunk(chunk, fse_encode_blocks_per_round(w.maxTl));
     // carve the workspace
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
@@ -284,6 +291,7 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     if (workspaceBytes < per + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / per;
     if (chunk > nBlocks) chunk = nBlocks;
+    else chunk = round_chunk(chunk, fse_decode_blocks_per_round(maxLog));
     u8* p = (u8*)d_workspace;
     FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
     u32* dtables = (u32*)p;

@@ -18,91 +18,290 @@
 //     below it, so no memory latency sits on the dependent chain (gfx950 global memory accepts the
 //     unaligned 8-byte accesses this needs).
 #include "internal.h"
+#include <stdlib.h>
 
 #include "bitreader.h"
 
-// one bulk step: cell lookup, take nb bits from the top of `t` (the not-yet-consumed window, MSB aligned),
-// next state = newState + bits, symbol byte inserted into `word` with one v_perm.
-#define FSE_BULK_STEP(state, SEL)                                                          \
-    {   const u32 c = cells[state];                                                        \
-        const u32 nb = c >> 24;                                                            \
-        const u32 bits = __builtin_amdgcn_ubfe((u32)(t >> 32), 32u - nb, nb);              \
-        t <<= nb; used += nb;                                                              \
-        state = (c & 0xFFFFu) + bits;                                                      \
-        word = __builtin_amdgcn_perm(c, word, SEL);                                        \
-    }
+// one bulk step against the compact LDS table: A[x] = newState (12 bits) | nbBits << 12.
+// The unread window is {thi:tlo}, MSB aligned, handled with full-rate 32-bit ops (64-bit shifts are quarter rate):
+//   bits = top nb bits of thi;  {thi:tlo} <<= nb via one v_alignbit;  next state = newState | bits
+// (FSE_buildDTable makes the low nbBits of newState zero, lib/fse_decompress.c:121-122; tables that violate this are
+// decoded by the literal path).  NB0 = some cell of some table in this wave has nbBits == 0 (fastMode 0):
+// v_alignbit with a shift of 32 would return tlo, so the window update is made conditional.
+template <bool NB0>
+DEV void fse_bulk_consume(u32 c, u32& state, u32& thi, u32& tlo, u32& u)
+{
+    const u32 nb = c >> 12;
+    const u32 m = 32u - nb;
+    const u32 bits = __builtin_amdgcn_ubfe(thi, m, nb);
+    const u32 nhi = __builtin_amdgcn_alignbit(thi, tlo, m);
+    thi = NB0 ? (nb ? nhi : thi) : nhi;
+    tlo <<= nb;
+    u += nb;
+    state = (c & 0xFFFu) | bits;
+}
 
+// 8 bytes at (byte offset - k) of the 16-byte little-endian value {a3:a2:a1:a0} whose upper half {a3:a2} sits at the
+// current offset, k = 0..7: two v_perm with a computed selector after a word-level select.
+DEV void funnel_bytes(u32 a3, u32 a2, u32 a1, u32 a0, u32 k, u32& hi, u32& lo)
+{
+    const bool far = k > 4u;
+    const u32 b2 = far ? a2 : a3, b1 = far ? a1 : a2, b0 = far ? a0 : a1;
+    const u32 r = 4u - (far ? k - 4u : k);              // byte offset inside the selected pair, 0..4
+    const u32 sel = 0x03020100u + r * 0x01010101u;
+    hi = __builtin_amdgcn_perm(b2, b1, sel);
+    lo = __builtin_amdgcn_perm(b1, b0, sel);
+}
+
+#define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration
+#define FSE_IN_RING 512          // per-block LDS input ring (bytes of compressed stream, direct-mapped by offset mod 512)
+#define FSE_IN_CHUNK 256         // refill granule: one coalesced 4-byte load per lane
+#define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so 12-byte reads never wrap
+#define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
+#define FSE_MAXG 16              // blocks per workgroup (one pending refill register per block)
+
+struct BulkState { u32 s1, s2, pofs, u, whi, wlo, l1hi, l1lo, l2hi, l2lo; };
+
+// One phase = FSE_CHECK_EVERY iterations of lib/fse_decompress.c:201-218 for one lane, registers + LDS only.
+// The table lookups of the two interleaved states are issued together so each pair costs one LDS round trip.
+template <bool NB0>
+DEV void fse_bulk_phase(BulkState& b, const u16* A, const u8* myIn, uint2* myRing, u32 iters)
+{
+    u32 s1 = b.s1, s2 = b.s2, pofs = b.pofs, u = b.u, whi = b.whi, wlo = b.wlo, l1hi = b.l1hi, l1lo = b.l1lo, l2hi = b.l2hi, l2lo = b.l2lo;
+#pragma unroll 2
+    for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
+        const u32 c1 = A[s1], c2 = A[s2];            // first pair of lookups in flight during the reload arithmetic
+        // BIT_reloadDStreamFast (at -= used>>3; used &= 7) in the shifted convention: k = used>>3 = 0..6 bytes
+        const u32 k = (u >> 3) - 1u;
+        pofs -= k; u = (u & 7u) + 8u;
+        u32 nwhi, nwlo, n1hi, n1lo;
+        funnel_bytes(whi, wlo, l1hi, l1lo, k, nwhi, nwlo);
+        funnel_bytes(l1hi, l1lo, l2hi, l2lo, k, n1hi, n1lo);
+        whi = nwhi; wlo = nwlo; l1hi = n1hi; l1lo = n1lo;
+        {   // bytes [p-16, p-8) from the input ring (needed at the next reload)
+            const u32 j = (pofs - 16u) & (FSE_IN_RING - 1);
+            const u32* rp = (const u32*)(myIn + (j & ~3u));
+            const u32 w0 = rp[0], w1 = rp[1], w2 = rp[2];
+            const u32 sh = (j & 3u) * 8u;
+            l2lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+            l2hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        }
+        u32 thi = __builtin_amdgcn_alignbit(whi, wlo, 32u - u), tlo = wlo << u;   // window << u, u in [8,15]
+        uint2 rec;
+        rec.x = s1 | (s2 << 16);
+        fse_bulk_consume<NB0>(c1, s1, thi, tlo, u);
+        fse_bulk_consume<NB0>(c2, s2, thi, tlo, u);
+        const u32 c3 = A[s1], c4 = A[s2];            // second pair
+        rec.y = s1 | (s2 << 16);
+        fse_bulk_consume<NB0>(c3, s1, thi, tlo, u);
+        fse_bulk_consume<NB0>(c4, s2, thi, tlo, u);
+        myRing[(iters + it) & (FSE_DEC_RING - 1)] = rec;
+    }
+    b.s1 = s1; b.s2 = s2; b.pofs = pofs; b.u = u; b.whi = whi; b.wlo = wlo; b.l1hi = l1hi; b.l1lo = l1lo; b.l2hi = l2hi; b.l2lo = l2lo;
+}
+
+// LDS per block: A[2^maxTableLog] (u16) | state ring (64 x 8 B) | input ring (512 + 16 B)
 __global__ __launch_bounds__(64) void k_fse_decode(FseDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int lane = threadIdx.x;
     const size_t first = (size_t)blockIdx.x * a.G;
+    const u32 slotBytes = a.slotU32 * 4u;                        // multiple of 8
+    const u32 ringOff = 2u << a.maxTableLog;                     // state ring offset inside a slot
+    const u32 inOff = ringOff + FSE_DEC_RING * 8;                // input ring offset inside a slot
+    u8* const ldsb = (u8*)lds;
 
-    for (int g = 0; g < a.G; ++g) {                  // stage DTables: wave-uniform control flow, coalesced
+    // ---- stage: reference cells {u16 newState; u8 symbol; u8 nbBits} -> compact u16 (wave-uniform control flow).
+    //      A table whose fields do not fit 12+4 bits (cannot come from FSE_buildDTable) is flagged and decoded
+    //      by the literal path only.
+    unsigned long long badMask = 0;
+    bool anyNb0 = false;
+    for (int g = 0; g < a.G; ++g) {
         const size_t b = first + g;
         if (b >= a.nBlocks) break;
         if (a.meta && a.meta[b].state == 0) continue;
         const u32* t = a.dtables + b * a.dtStrideU32;
         const u32 tl = t[0] & 0xFFFFu;
         if (tl > a.maxTableLog) continue;
-        const u32 words = 1 + (1u << tl);
-        u32* s = lds + (size_t)g * a.slotU32;
-        for (u32 i = lane; i < words; i += 64) s[i] = t[i];
+        const u32 ts = 1u << tl;
+        u16* A = (u16*)(ldsb + (size_t)g * slotBytes);
+        bool bad = false;
+        for (u32 i = lane; i < ts; i += 64) {
+            const u32 c = t[1 + i];
+            const u32 ns = c & 0xFFFFu, nb = c >> 24;
+            bad |= (ns > 0xFFFu) | (nb > 15u) | ((ns & ((1u << (nb & 15u)) - 1u)) != 0);
+            anyNb0 |= (nb == 0);
+            A[i] = (u16)((ns & 0xFFFu) | (nb << 12));
+        }
+        if (__any(bad)) badMask |= 1ull << g;
     }
     __syncthreads();
-    if (lane >= a.G) return;
-    const size_t b = first + lane;
-    if (b >= a.nBlocks) return;
-    u32 hdr = 0;
-    if (a.meta) { if (a.meta[b].state == 0) return; hdr = a.meta[b].hdrSize; }
-    const u32 h0 = a.dtables[b * a.dtStrideU32];
-    const u32 tl = h0 & 0xFFFFu;
-    if (tl > a.maxTableLog) { a.results[b] = FERR(tableLog_tooLarge); return; }
-    const bool fast = (h0 >> 16) != 0;
-    const u32* const cells = lds + (size_t)lane * a.slotU32 + 1;
 
-    const u8* const in = view_ptr(a.csrc, b) + hdr;
-    const size_t S = view_size(a.csrc, b) - hdr;     // hdr <= cSrcSize (FSE_readNCount never returns more)
-    u8* const out = a.dst + b * a.dstStride;
+    // ---- per-lane set-up.  Every lane stays in the kernel (ring service is wave-cooperative);
+    //      `owner` lanes carry one block each.
+    const size_t b = first + (size_t)lane;
+    bool owner = lane < a.G && b < a.nBlocks;
+    u32 hdr = 0;
+    if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
+    u32 tl = 0; bool fast = false;
+    const u32* const gtab = a.dtables + (owner ? b : 0) * a.dtStrideU32;   // reference-layout table in global memory
+    if (owner) {
+        const u32 h0 = gtab[0];
+        tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0;
+        if (tl > a.maxTableLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; }
+    }
+    const u32* const cells = gtab + 1;                          // literal path reads the reference cells
+    const u16* const A = (const u16*)(ldsb + (size_t)lane * slotBytes);
+    const u8* in = nullptr; size_t S = 0; u8* out = nullptr;
     const long omax = (long)a.dstCapacity;
     long op = 0;
-
-    BitReader r;
-    {   const size_t e = r.init(in, S);
-        if (is_err(e)) { a.results[b] = e; return; }
-    }
-    u32 s1 = r.read(tl); r.reload();                 // FSE_initDState x2, fse.h:577-584
-    u32 s2 = r.read(tl); r.reload();
-
-    // ---- bulk: iterations of fse_decompress.c:201-218 whose loop-head reload is provably the fast one
-    if (r.at >= 24 && op < omax - 3 && r.used <= 64) {
-        u64 at = r.at;
-        u32 used = r.used;
-        u64 win = r.win;
-        u64 lo1 = ldg64u(in + at - 8);               // bytes [at-8, at)
-        u64 lo2 = ldg64u(in + at - 16);              // bytes [at-16, at-8)
-        long groups = (omax - 3 - op + 3) >> 2;      // iterations allowed by "op < olimit"
-        do {
-            // BIT_reloadDStreamFast: at -= used>>3; used &= 7; window = 8 bytes at `at`
-            const u32 k8 = used & ~7u;               // whole consumed bytes, in bits (0..48)
-            at -= used >> 3; used &= 7;
-            win = (win << k8) | ((lo1 >> 1) >> (63 - k8));
-            lo1 = (lo1 << k8) | ((lo2 >> 1) >> (63 - k8));
-            lo2 = ldg64u(in + at - 16);              // needed two reloads from now
-            u64 t = win << used;
-            u32 word = 0;
-            FSE_BULK_STEP(s1, 0x03020106u)           // v_perm: {c = bytes 4..7, word = bytes 0..3}; byte k <- c.byte2 (index 6)
-            FSE_BULK_STEP(s2, 0x03020600u)
-            FSE_BULK_STEP(s1, 0x03060100u)
-            FSE_BULK_STEP(s2, 0x06020100u)
-            __builtin_memcpy(out + op, &word, 4);
-            op += 4;
-            --groups;
-        } while (at >= 24 && groups > 0);
-        r.at = (size_t)at; r.used = used; r.win = win;
+    BitReader r; r.base = nullptr; r.size = 0; r.at = 0; r.win = 0; r.used = 0;
+    u32 s1 = 0, s2 = 0;
+    if (owner) {
+        in = view_ptr(a.csrc, b) + hdr;
+        S = view_size(a.csrc, b) - hdr;              // hdr <= cSrcSize (FSE_readNCount never returns more)
+        out = a.dst + b * a.dstStride;
+        const size_t e = r.init(in, S);
+        if (is_err(e)) { a.results[b] = e; owner = false; }
+        else {
+            s1 = r.read(tl); r.reload();             // FSE_initDState x2, fse.h:577-584
+            s2 = r.read(tl); r.reload();
+        }
     }
 
-    // ---- literal tail: remaining iterations of :201-218, then :222-235
+    // ---- bulk: iterations of fse_decompress.c:201-218 whose loop-head reload is provably the fast one.
+    //      The per-lane loop touches only registers and LDS:
+    //        * input: the 8 bytes below the window come from this block's LDS input ring, which the whole wave
+    //          refills 256 bytes at a time with coalesced loads (requested one service point ahead, so the
+    //          HBM/L2 latency is covered by 16 iterations of decoding);
+    //        * output: each iteration appends the 4 states it decoded FROM to the block's state ring; every 64
+    //          iterations the wave turns the rings into bytes (symbol = cell[state].symbol, gathered from the
+    //          L2-resident reference table) and writes them with coalesced 256-byte stores.
+    //      A per-lane global load would cost one cache-line access per active lane per iteration, and mixing
+    //      loads with stores forces s_waitcnt vmcnt(0) on gfx950.
+    // Phase structure: a lane takes part in a phase only if FSE_CHECK_EVERY more iterations are certainly valid for it
+    // (>= 16 output groups left and the window stays >= 24 bytes above the stream start: at >= 24 + 16*6), so the
+    // 16 iterations of a phase run without any per-iteration bookkeeping; whatever is left goes to the literal tail.
+    // Bulk state uses p = at+1, u = used+8 (u in [8,16) after a reload), so no shift amount is ever 0 or 32.
+    const bool nb0 = __any(anyNb0);
+    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> lane) & 1ull);
+    BulkState bs; bs.s1 = s1; bs.s2 = s2; bs.pofs = (u32)r.at + 1u; bs.u = r.used + 8u;
+    bs.whi = bs.wlo = bs.l1hi = bs.l1lo = bs.l2hi = bs.l2lo = 0;
+    long groups = 0;
+    u32 iters = 0, flushed = 0;
+    int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + 512)
+    if (can) {
+        const u64 w = ldg64u(in + bs.pofs), a1 = ldg64u(in + bs.pofs - 8), a2 = ldg64u(in + bs.pofs - 16);
+        bs.whi = (u32)(w >> 32); bs.wlo = (u32)w; bs.l1hi = (u32)(a1 >> 32); bs.l1lo = (u32)a1; bs.l2hi = (u32)(a2 >> 32); bs.l2lo = (u32)a2;
+        groups = (omax - 3 - op + 3) >> 2;
+        validLo = ((int)bs.pofs - 16 - 208) & ~255;  // two service periods of slack below the lowest byte read next
+    }
+    uint2* const myRing = (uint2*)(ldsb + (size_t)lane * slotBytes + ringOff);
+    const u8* const myIn = ldsb + (size_t)lane * slotBytes + inOff;
+    const unsigned long long outBits = (unsigned long long)(uintptr_t)out;
+    const unsigned long long tabBits = (unsigned long long)(uintptr_t)cells;
+    const unsigned long long inBits = (unsigned long long)(uintptr_t)in;
+    const int S32 = (int)(S < (1ull << 31) ? S : 0);
+
+    // initial fill of the input rings: two chunks per participating block
+    {   const unsigned long long am = __ballot(can);
+        for (int g = 0; g < a.G; ++g) {
+            if (!((am >> g) & 1ull)) continue;       // uniform
+            const int vlo = __shfl(validLo, g, WAVE), Sg = __shfl(S32, g, WAVE);
+            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, g, WAVE);
+            u32* const rg = (u32*)(ldsb + (size_t)g * slotBytes + inOff);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int off = vlo + FSE_IN_CHUNK * c + 4 * lane;
+                if (off >= 0 && off + 4 <= Sg) {
+                    u32 w; __builtin_memcpy(&w, ig + off, 4);
+                    const u32 j = (u32)off & (FSE_IN_RING - 1);
+                    rg[j >> 2] = w;
+                    if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    u32 pend[FSE_MAXG];
+#pragma unroll
+    for (int g = 0; g < FSE_MAXG; ++g) pend[g] = 0;
+    unsigned long long pendMask = 0;
+    u32 phase = 0;
+    while (__any(can)) {
+        if (can) {
+            if (nb0) fse_bulk_phase<true>(bs, A, myIn, myRing, iters);
+            else     fse_bulk_phase<false>(bs, A, myIn, myRing, iters);
+            iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
+            can = bs.pofs - 1u >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
+        }
+        ++phase;
+        const bool done = !__any(can);
+        if (!done) {
+            // ---- input ring service.  (1) install the chunks requested at the previous service point
+#pragma unroll
+            for (int g = 0; g < FSE_MAXG; ++g) {
+                if (!((pendMask >> g) & 1ull)) continue;                 // uniform
+                const int nlo = __shfl(validLo, g, WAVE) - FSE_IN_CHUNK;
+                const u32 j = (u32)(nlo + 4 * lane) & (FSE_IN_RING - 1);
+                u32* const rg = (u32*)(ldsb + (size_t)g * slotBytes + inOff);
+                rg[j >> 2] = pend[g];
+                if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = pend[g];
+            }
+            if ((pendMask >> lane) & 1ull) validLo -= FSE_IN_CHUNK;
+            // (2) request the next chunk for every block that could run below its ring before the next-but-one
+            //     service point: the lowest byte read is p-16, <= 96 bytes are consumed per period
+            //     (invariant at every service point: p-16-96 >= validLo)
+            const bool want = can && ((int)bs.pofs - 16 < validLo + 208) && validLo > 0;
+            pendMask = __ballot(want);
+#pragma unroll
+            for (int g = 0; g < FSE_MAXG; ++g) {
+                if (!((pendMask >> g) & 1ull)) continue;                 // uniform
+                const int off = __shfl(validLo, g, WAVE) - FSE_IN_CHUNK + 4 * lane;
+                const int Sg = __shfl(S32, g, WAVE);
+                const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, g, WAVE);
+                u32 w = 0;
+                if (off >= 0 && off + 4 <= Sg) __builtin_memcpy(&w, ig + off, 4);
+                pend[g] = w;
+            }
+        }
+        if ((phase & (FSE_DEC_RING / FSE_CHECK_EVERY - 1)) == 0 || done) {
+            // ---- output service: ring entries [flushed, iters) of every block -> 4 symbols each -> out + 4*flushed ...
+            //      4 blocks per batch so that 16 gathers are in flight before the first is consumed
+            for (int g0 = 0; g0 < a.G; g0 += 4) {
+                u32 y[4][4]; u32 cntv[4]; u8* ogv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = g0 + q < a.G ? g0 + q : a.G - 1;
+                    const u32 it_g = (u32)__shfl((int)iters, g, WAVE), fl_g = (u32)__shfl((int)flushed, g, WAVE);
+                    cntv[q] = g0 + q < a.G ? it_g - fl_g : 0u;
+                    const unsigned long long ob = __shfl(outBits, g, WAVE);
+                    const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, g, WAVE);
+                    ogv[q] = (u8*)(uintptr_t)ob + 4ull * fl_g;
+                    y[q][0] = y[q][1] = y[q][2] = y[q][3] = 0;
+                    if ((u32)lane < cntv[q]) {
+                        const uint2 rec = ((const uint2*)(ldsb + (size_t)g * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
+                        y[q][0] = tg[4u * (rec.x & 0xFFFFu) + 2]; y[q][1] = tg[4u * (rec.x >> 16) + 2];
+                        y[q][2] = tg[4u * (rec.y & 0xFFFFu) + 2]; y[q][3] = tg[4u * (rec.y >> 16) + 2];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((u32)lane < cntv[q]) {
+                        const u32 w = y[q][0] | (y[q][1] << 8) | (y[q][2] << 16) | (y[q][3] << 24);
+                        __builtin_memcpy(ogv[q] + 4u * lane, &w, 4);
+                    }
+                }
+            }
+            flushed = iters;
+        }
+    }
+    if (!owner) return;
+    op = 4 * (long)iters;
+    if (iters) { r.at = (size_t)bs.pofs - 1; r.used = bs.u - 8u; r.win = ldg64u(in + r.at); s1 = bs.s1; s2 = bs.s2; }   // back to the reference's (at, used, window)
+
+    // ---- literal tail: remaining iterations of :201-218, then :222-235 (cells read from the reference table)
     for (;;) {
         const int st = r.reload();
         if (!((st == BR_UNFINISHED) & (op < omax - 3))) break;
@@ -124,19 +323,35 @@ __global__ __launch_bounds__(64) void k_fse_decode(FseDecArgs a)
     a.results[b] = result;
 }
 
+static void fse_decode_geometry(unsigned maxTableLog, size_t ldsBytes, unsigned* slotU32, int* G)
+{
+    *slotU32 = ((2u << maxTableLog) + FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 8) / 4;   // table + rings (+8: rotating banks)
+    int g = (int)(ldsBytes / (*slotU32 * 4));
+    if (g > FSE_MAXG) g = FSE_MAXG;
+    if (const char* dbg = getenv("FSEHIP_DEBUG_G")) { int v = atoi(dbg); if (v >= 1 && v < g) g = v; }   // tuning aid
+    *G = g;
+}
+#define FSE_DEC_LDS (80 * 1024)   // two workgroups per CU (measured: 2 x 80 KiB are co-resident on gfx950)
+size_t fse_decode_blocks_per_round(unsigned maxTableLog)
+{
+    unsigned slot; int G;
+    fse_decode_geometry(maxTableLog, FSE_DEC_LDS, &slot, &G);
+    const int cus = dev_props().ok ? dev_props().cus : 256;
+    return (size_t)G * 2 * cus;
+}
+
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     static bool attrSet = false;
-    const size_t ldsBytes = 80 * 1024;
+    size_t ldsBytes = FSE_DEC_LDS;
+    if (const char* dbg = getenv("FSEHIP_DEBUG_LDS")) ldsBytes = (size_t)atoi(dbg);   // tuning aid
     if (!attrSet) {
         hipError_t e = hipFuncSetAttribute((const void*)k_fse_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) return e;
         attrSet = true;
     }
-    a.slotU32 = 1 + (1u << a.maxTableLog);           // odd word stride: slots start on rotating banks
-    a.G = (int)(ldsBytes / (a.slotU32 * 4));
-    if (a.G > 64) a.G = 64;
+    fse_decode_geometry(a.maxTableLog, ldsBytes, &a.slotU32, &a.G);
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
     probe_before(PK_FSE_DECODE, s);

@@ -150,20 +150,33 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
     } else a.results[b] = csize;
 }
 
+#define FSE_ENC_LDS (80 * 1024)   // two workgroups per CU (measured: 2 x 80 KiB are co-resident on gfx950)
+static void fse_encode_geometry(unsigned maxTableLog, unsigned* slotU32, int* G)
+{
+    *slotU32 = (1 + (1u << (maxTableLog - 1)) + 512) | 1u;           // odd word stride: slots start on rotating banks
+    int g = (int)(FSE_ENC_LDS / (*slotU32 * 4));
+    if (g > 64) g = 64;
+    *G = g;
+}
+size_t fse_encode_blocks_per_round(unsigned maxTableLog)
+{
+    unsigned slot; int G;
+    fse_encode_geometry(maxTableLog, &slot, &G);
+    const int cus = dev_props().ok ? dev_props().cus : 256;
+    return (size_t)G * 2 * cus;
+}
+
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     static bool attrSet = false;
-    const size_t ldsBytes = 80 * 1024;
+    const size_t ldsBytes = FSE_ENC_LDS;
     if (!attrSet) {
         hipError_t e = hipFuncSetAttribute((const void*)k_fse_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) return e;
         attrSet = true;
     }
-    const u32 tl = a.maxTableLog;
-    a.slotU32 = (1 + (1u << (tl - 1)) + 512) | 1u;                   // odd word stride: slots start on rotating banks
-    a.G = (int)(ldsBytes / (a.slotU32 * 4));
-    if (a.G > 64) a.G = 64;
+    fse_encode_geometry(a.maxTableLog, &a.slotU32, &a.G);
     // 32-bit lane offsets inside a group
     if (a.nBlocks > 1 && ((a.src.stride > 0x3FFFFFFu) || (a.dstStride > 0x3FFFFFFu))) return hipErrorInvalidValue;
     if (a.dstCapacity > 0x7FFFFFF0u) a.dstCapacity = 0x7FFFFFF0u;   // blocks are < 2 GiB on this path (see kernel)

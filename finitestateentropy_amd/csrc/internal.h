@@ -50,6 +50,7 @@ struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per b
     size_t nBlocks;
 };
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
+size_t fse_encode_blocks_per_round(unsigned maxTableLog);
 
 struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
     BlockView csrc;
@@ -73,6 +74,7 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     size_t nBlocks;
 };
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s);
+size_t fse_decode_blocks_per_round(unsigned maxTableLog);   // blocks that fill the device once (for chunk sizing)
 
 // ---- Huff0 ----------------------------------------------------------------------------------------
 struct HufMeta {
