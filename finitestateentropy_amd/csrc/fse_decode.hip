@@ -229,6 +229,11 @@ __global__ __launch_bounds__(64) void k_fse_decode(FseDecArgs a)
     for (int g = 0; g < FSE_MAXG; ++g) pend[g] = 0;
     unsigned long long pendMask = 0;
     u32 phase = 0;
+    u32 yq[FSE_MAXG][4];                             // gathered symbols in flight (static indices: registers)
+#pragma unroll
+    for (int g = 0; g < FSE_MAXG; ++g) { yq[g][0] = yq[g][1] = yq[g][2] = yq[g][3] = 0; }
+    u32 pFl = 0, pIt = 0;                            // per lane: [flushed, iters) of the gathers in flight
+    bool gatherPending = false;
     while (__any(can)) {
         if (can) {
             if (nb0) fse_bulk_phase<true>(bs, A, myIn, myRing, iters);
@@ -266,35 +271,48 @@ __global__ __launch_bounds__(64) void k_fse_decode(FseDecArgs a)
                 pend[g] = w;
             }
         }
-        if ((phase & (FSE_DEC_RING / FSE_CHECK_EVERY - 1)) == 0 || done) {
-            // ---- output service: ring entries [flushed, iters) of every block -> 4 symbols each -> out + 4*flushed ...
-            //      4 blocks per batch so that 16 gathers are in flight before the first is consumed
-            for (int g0 = 0; g0 < a.G; g0 += 4) {
-                u32 y[4][4]; u32 cntv[4]; u8* ogv[4];
+        // ---- output service, split in two so that the gathers are never waited for:
+        //      "issue"  (every 4th phase, or at the end): ring entries [flushed, iters) of every block -> 4 symbol
+        //               gathers per lane (symbol = cell[state].symbol from the L2-resident reference table);
+        //      "commit" (at the next service point, i.e. one phase of decoding later): pack + coalesced 256-byte stores.
+        if (gatherPending) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int g = g0 + q < a.G ? g0 + q : a.G - 1;
-                    const u32 it_g = (u32)__shfl((int)iters, g, WAVE), fl_g = (u32)__shfl((int)flushed, g, WAVE);
-                    cntv[q] = g0 + q < a.G ? it_g - fl_g : 0u;
-                    const unsigned long long ob = __shfl(outBits, g, WAVE);
-                    const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, g, WAVE);
-                    ogv[q] = (u8*)(uintptr_t)ob + 4ull * fl_g;
-                    y[q][0] = y[q][1] = y[q][2] = y[q][3] = 0;
-                    if ((u32)lane < cntv[q]) {
-                        const uint2 rec = ((const uint2*)(ldsb + (size_t)g * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
-                        y[q][0] = tg[4u * (rec.x & 0xFFFFu) + 2]; y[q][1] = tg[4u * (rec.x >> 16) + 2];
-                        y[q][2] = tg[4u * (rec.y & 0xFFFFu) + 2]; y[q][3] = tg[4u * (rec.y >> 16) + 2];
-                    }
+            for (int g = 0; g < FSE_MAXG; ++g) {
+                const u32 cnt = g < a.G ? (u32)__shfl((int)pIt, g, WAVE) - (u32)__shfl((int)pFl, g, WAVE) : 0u;   // uniform
+                u8* const og = (u8*)(uintptr_t)__shfl(outBits, g, WAVE) + 4ull * (u32)__shfl((int)pFl, g, WAVE);
+                if ((u32)lane < cnt) {
+                    const u32 w = yq[g][0] | (yq[g][1] << 8) | (yq[g][2] << 16) | (yq[g][3] << 24);
+                    __builtin_memcpy(og + 4u * lane, &w, 4);
                 }
+            }
+            gatherPending = false;
+        }
+        if ((phase & (FSE_DEC_RING / FSE_CHECK_EVERY - 1)) == 0 || done) {
+            pFl = flushed; pIt = iters;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((u32)lane < cntv[q]) {
-                        const u32 w = y[q][0] | (y[q][1] << 8) | (y[q][2] << 16) | (y[q][3] << 24);
-                        __builtin_memcpy(ogv[q] + 4u * lane, &w, 4);
-                    }
+            for (int g = 0; g < FSE_MAXG; ++g) {
+                const u32 it_g = (u32)__shfl((int)iters, g, WAVE), fl_g = (u32)__shfl((int)flushed, g, WAVE);
+                const u32 cnt = g < a.G ? it_g - fl_g : 0u;              // uniform
+                const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, g, WAVE);
+                if ((u32)lane < cnt) {
+                    const uint2 rec = ((const uint2*)(ldsb + (size_t)g * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
+                    yq[g][0] = tg[4u * (rec.x & 0xFFFFu) + 2]; yq[g][1] = tg[4u * (rec.x >> 16) + 2];
+                    yq[g][2] = tg[4u * (rec.y & 0xFFFFu) + 2]; yq[g][3] = tg[4u * (rec.y >> 16) + 2];
                 }
             }
             flushed = iters;
+            gatherPending = true;
+        }
+    }
+    if (gatherPending) {                             // commit the last batch (uniform)
+#pragma unroll
+        for (int g = 0; g < FSE_MAXG; ++g) {
+            const u32 cnt = g < a.G ? (u32)__shfl((int)pIt, g, WAVE) - (u32)__shfl((int)pFl, g, WAVE) : 0u;
+            u8* const og = (u8*)(uintptr_t)__shfl(outBits, g, WAVE) + 4ull * (u32)__shfl((int)pFl, g, WAVE);
+            if ((u32)lane < cnt) {
+                const u32 w = yq[g][0] | (yq[g][1] << 8) | (yq[g][2] << 16) | (yq[g][3] << 24);
+                __builtin_memcpy(og + 4u * lane, &w, 4);
+            }
         }
     }
     if (!owner) return;
