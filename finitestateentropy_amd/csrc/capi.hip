@@ -169,7 +169,7 @@ extern "C" int FSEHIP_FSE_compress_usingCTable_batch(void* d_dst, size_t dstStri
     a.src = mkview(d_src, srcStride, d_sizes, uniformSize);
     a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr;
     a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks;
-    return (int)launch_fse_encode(a, (hipStream_t)stream);
+    return (int)launch_fse_encode_auto(a, (hipStream_t)stream);
 }
 
 extern "C" int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
@@ -264,7 +264,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
         e.src = src; e.ctables = ctables; e.ctStrideU32 = w.ctU32; e.meta = meta;
         e.maxTableLog = w.maxTl; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
-        CK(launch_fse_encode(e, s));
+        CK(launch_fse_encode_auto(e, s));
     }
     return 0;
 }

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
     for (int g = 0; g < a.G; ++g) {
         const size_t b = first + g;
         if (b >= a.nBlocks) break;
-        if (a.meta && a.meta[b].state == 0) continue;
+        if (a.meta && fse_enc_skip(a.meta[b].state, a.onlyState)) continue;
         const u32* t = a.ctables + b * a.ctStrideU32;
         const u32 h = t[0];
         const u32 tl = h & 0xFFFFu, msv = h >> 16;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
     const size_t b = first + lane;
     if (b >= a.nBlocks) return;
     u32 hdr = 0;
-    if (a.meta) { if (a.meta[b].state == 0) return; hdr = a.meta[b].hdrSize; }
+    if (a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) return; hdr = a.meta[b].hdrSize; }
 
     const u32 h0 = a.ctables[b * a.ctStrideU32];
     const u32 tl = h0 & 0xFFFFu;

@@ -37,7 +37,12 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a)
         const size_t h = fse_write_ncount(dst, a.dstCapacity, norm, maxSV, tl);   // :662
         if (is_err(h)) { result = h; break; }
         fse_build_ctable(a.ctables + b * a.ctStrideU32, a.cellSym + b * a.cellSymStride, norm, maxSV, tl);   // :667
-        m.state = 1; m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
+        // Encoder choice (fse_encode_par.hip): the block-parallel kernel relies on two encoder states fed the same symbols
+        // merging quickly; per step that happens with probability ~ sum_s p_s / norm_s = present / tableSize.
+        u32 present = 0;
+        for (u32 s = 0; s <= maxSV; ++s) present += norm[s] != 0;
+        m.state = (present * 40u >= (1u << tl)) ? FSE_ENC_PAR : FSE_ENC_LANE;
+        m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
     } while (0);
     a.meta[b] = m;
     if (m.state == 0) a.results[b] = result;

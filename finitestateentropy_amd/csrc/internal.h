@@ -48,9 +48,28 @@ struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per b
     int G;                       // blocks per workgroup
     unsigned slotU32;            // LDS words per table slot
     size_t nBlocks;
+    unsigned onlyState;          // with meta: 0 = every prepared block, else only blocks whose meta.state equals it
 };
+// meta.state on the compress side: 0 = finished by the prepare kernel, FSE_ENC_PAR / FSE_ENC_LANE = table ready, preferred kernel
+enum { FSE_ENC_PAR = 1, FSE_ENC_LANE = 2 };
+__host__ __device__ inline bool fse_enc_skip(unsigned state, unsigned onlyState) { return state == 0 || (onlyState != 0 && state != onlyState); }
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
 size_t fse_encode_blocks_per_round(unsigned maxTableLog);
+hipError_t launch_fse_encode_par(FseEncArgs a, hipStream_t s);   // block-parallel variant (one workgroup per block)
+// picks the block-parallel kernel for uniformly sized blocks of >= 2 KiB, the lane-per-block kernel otherwise (both exact)
+// With prepare-kernel metadata the choice is per block (k_fse_cprep marks slowly-mixing tables FSE_ENC_LANE): both kernels
+// are launched and each one skips the other's blocks.
+inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
+{
+    a.onlyState = 0;
+    if (a.src.sizes || a.src.uniform < 2048 || a.dstCapacity > 0x7FFFFFF0u) return launch_fse_encode(a, s);
+    if (!a.meta) return launch_fse_encode_par(a, s);
+    a.onlyState = FSE_ENC_PAR;
+    hipError_t e = launch_fse_encode_par(a, s);
+    if (e != hipSuccess) return e;
+    a.onlyState = FSE_ENC_LANE;
+    return launch_fse_encode(a, s);
+}
 
 struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
     BlockView csrc;
