@@ -181,7 +181,7 @@ extern "C" int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstSt
     FseDecArgs a;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
     a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
-    a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
+    a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.atab = nullptr; a.symtab = nullptr; a.meta = nullptr;
     a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks;
     return (int)launch_fse_decode(a, (hipStream_t)stream);
 }
@@ -269,7 +269,8 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     return 0;
 }
 
-static size_t fse_dws_per_block(unsigned maxLog) { return sizeof(FseMeta) + 4 * (size_t)FSEHIP_FSE_DTABLE_SIZE_U32(maxLog); }
+// per block: meta, 256 counters, and the decoder-format table (2 + 1 bytes per cell)
+static size_t fse_dws_per_block(unsigned maxLog) { return sizeof(FseMeta) + 512 + 3 * ((size_t)1 << maxLog); }
 static unsigned clamp_maxlog(unsigned maxLog) { return (maxLog == 0 || maxLog > FSEHIP_FSE_MAX_TABLELOG) ? FSEHIP_FSE_MAX_TABLELOG : maxLog; }
 
 extern "C" size_t FSEHIP_FSE_decompress_batch_workspaceSize(size_t nBlocks, unsigned maxLog)
@@ -294,17 +295,18 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     else chunk = round_chunk(chunk, fse_decode_blocks_per_round(maxLog));
     u8* p = (u8*)d_workspace;
     FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
-    u32* dtables = (u32*)p;
-    const size_t dtU32 = FSEHIP_FSE_DTABLE_SIZE_U32(maxLog);
+    s16* norms = (s16*)p; p += align_up(chunk * 512, 256);
+    u16* atab = (u16*)p; p += align_up((chunk * 2) << maxLog, 256);
+    u8* symtab = p;
     for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
         const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
         const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
         FseDPrepArgs d;
-        d.csrc = cs; d.maxLog = maxLog; d.dtables = dtables; d.dtStrideU32 = dtU32; d.meta = meta; d.results = d_results + b0; d.nBlocks = nb;
+        d.csrc = cs; d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.results = d_results + b0; d.nBlocks = nb;
         CK(launch_fse_dprep(d, s));
         FseDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
-        e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
+        e.csrc = cs; e.dtables = nullptr; e.dtStrideU32 = 0; e.atab = atab; e.symtab = symtab; e.meta = meta;
         e.maxTableLog = maxLog; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
         CK(launch_fse_decode(e, s));
     }

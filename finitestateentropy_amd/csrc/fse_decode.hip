@@ -22,82 +22,74 @@
 
 #include "bitreader.h"
 
-// one bulk step against the compact LDS table: A[x] = newState (12 bits) | nbBits << 12.
-// The unread window is {thi:tlo}, MSB aligned, handled with full-rate 32-bit ops (64-bit shifts are quarter rate):
-//   bits = top nb bits of thi;  {thi:tlo} <<= nb via one v_alignbit;  next state = newState | bits
-// (FSE_buildDTable makes the low nbBits of newState zero, lib/fse_decompress.c:121-122; tables that violate this are
-// decoded by the literal path).  NB0 = some cell of some table in this wave has nbBits == 0 (fastMode 0):
-// v_alignbit with a shift of 32 would return tlo, so the window update is made conditional.
-template <bool NB0>
-DEV void fse_bulk_consume(u32 c, u32& state, u32& thi, u32& tlo, u32& u)
-{
-    const u32 nb = c >> 12;
-    const u32 m = 32u - nb;
-    const u32 bits = __builtin_amdgcn_ubfe(thi, m, nb);
-    const u32 nhi = __builtin_amdgcn_alignbit(thi, tlo, m);
-    thi = NB0 ? (nb ? nhi : thi) : nhi;
-    tlo <<= nb;
-    u += nb;
-    state = (c & 0xFFFu) | bits;
-}
-
-// 8 bytes at (byte offset - k) of the 16-byte little-endian value {a3:a2:a1:a0} whose upper half {a3:a2} sits at the
-// current offset, k = 0..7: two v_perm with a computed selector after a word-level select.
-DEV void funnel_bytes(u32 a3, u32 a2, u32 a1, u32 a0, u32 k, u32& hi, u32& lo)
-{
-    const bool far = k > 4u;
-    const u32 b2 = far ? a2 : a3, b1 = far ? a1 : a2, b0 = far ? a0 : a1;
-    const u32 r = 4u - (far ? k - 4u : k);              // byte offset inside the selected pair, 0..4
-    const u32 sel = 0x03020100u + r * 0x01010101u;
-    hi = __builtin_amdgcn_perm(b2, b1, sel);
-    lo = __builtin_amdgcn_perm(b1, b0, sel);
-}
-
+// Bulk decoding against the compact LDS table A[x] = newState (12 bits) | nbBits << 12, full-rate 32-bit ops only
+// (64-bit shifts are quarter rate on gfx950).  FSE_buildDTable makes the low nbBits of newState zero
+// (lib/fse_decompress.c:121-122), so "newState + bits" is an OR; tables that violate this take the literal path.
+//
+// Window: bq = number of still unread bits of stream dword dp (its low bits; 0..31); q = 4*dp - 8 is the payload byte
+// offset of the lowest of the three dwords {d2:d1:d0} = dwords dp, dp-1, dp-2 (dword-aligned with respect to the payload
+// start, which is how the LDS input ring is laid out).  One iteration of lib/fse_decompress.c:201-218 = 4 symbols = at
+// most 48 bits:
+//   the three dwords are read from the input ring together with the two table cells (same LDS round trip);
+//   {thi:tlo} = the next 64 unread bits (two v_alignbit);
+//   symbol 1 reads the top of thi, symbol 2 the top of thi << nb1 (>= 20 valid bits), symbols 3/4 the same from
+//   t3 = the 32 bits that follow the first two symbols (one more v_alignbit) -- no per-symbol window shifting;
+//   then bq -= consumed, carrying into q.
+// The reference's (ptr, bitsConsumed) pair is a function of the absolute bit position alone while its reloads are
+// the fast ones (bitstream.h:378-388), so it is reconstructed from (q, bq) when the bulk loop ends.
+// NB0 = some cell of some table staged by this workgroup has nbBits == 0: a v_alignbit by 32 would return the low
+// word, so that one select is made explicit.
 #define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration
 #define FSE_IN_RING 512          // per-block LDS input ring (bytes of compressed stream, direct-mapped by offset mod 512)
 #define FSE_IN_CHUNK 256         // refill granule: one coalesced 4-byte load per lane
-#define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so 12-byte reads never wrap
+#define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so reads of 2 dwords never wrap
 #define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
-#define FSE_MAXG 16              // blocks per workgroup (one pending refill register per block)
+#define FSE_MAXG 16              // blocks per workgroup
 
-struct BulkState { u32 s1, s2, pofs, u, whi, wlo, l1hi, l1lo, l2hi, l2lo; };
+#ifdef FSE_DEC_TIMING       // development aid: per-workgroup cycle accounting of the decoder and service waves
+__device__ unsigned long long g_decTiming[4096 * 8];
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_decTiming), sizeof(g_decTiming)); }
+#define TIMING(x) x
+#else
+#define TIMING(x)
+#endif
+struct BulkState { u32 s1, s2, q, bq; };
 
-// One phase = FSE_CHECK_EVERY iterations of lib/fse_decompress.c:201-218 for one lane, registers + LDS only.
-// The table lookups of the two interleaved states are issued together so each pair costs one LDS round trip.
+#define FSE_BULK_SYM(c, state, t, nb)                                                     \
+    {   nb = (c) >> 12;                                                                   \
+        const u32 bits_ = __builtin_amdgcn_ubfe((t), 32u - nb, nb);                       \
+        state = ((c) & 0xFFFu) | bits_; }
+
+// One phase = FSE_CHECK_EVERY iterations for one lane, registers + LDS only.
 template <bool NB0>
-DEV void fse_bulk_phase(BulkState& b, const u16* A, const u8* myIn, uint2* myRing, u32 iters)
+DEV void fse_bulk_phase(BulkState& b, const u16* A, const u8* myIn, uint2* ring)
 {
-    u32 s1 = b.s1, s2 = b.s2, pofs = b.pofs, u = b.u, whi = b.whi, wlo = b.wlo, l1hi = b.l1hi, l1lo = b.l1lo, l2hi = b.l2hi, l2lo = b.l2lo;
+    u32 s1 = b.s1, s2 = b.s2, q = b.q, bq = b.bq;
 #pragma unroll 2
     for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
-        const u32 c1 = A[s1], c2 = A[s2];            // first pair of lookups in flight during the reload arithmetic
-        // BIT_reloadDStreamFast (at -= used>>3; used &= 7) in the shifted convention: k = used>>3 = 0..6 bytes
-        const u32 k = (u >> 3) - 1u;
-        pofs -= k; u = (u & 7u) + 8u;
-        u32 nwhi, nwlo, n1hi, n1lo;
-        funnel_bytes(whi, wlo, l1hi, l1lo, k, nwhi, nwlo);
-        funnel_bytes(l1hi, l1lo, l2hi, l2lo, k, n1hi, n1lo);
-        whi = nwhi; wlo = nwlo; l1hi = n1hi; l1lo = n1lo;
-        {   // bytes [p-16, p-8) from the input ring (needed at the next reload)
-            const u32 j = (pofs - 16u) & (FSE_IN_RING - 1);
-            const u32* rp = (const u32*)(myIn + (j & ~3u));
-            const u32 w0 = rp[0], w1 = rp[1], w2 = rp[2];
-            const u32 sh = (j & 3u) * 8u;
-            l2lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-            l2hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        }
-        u32 thi = __builtin_amdgcn_alignbit(whi, wlo, 32u - u), tlo = wlo << u;   // window << u, u in [8,15]
+        const u32 c1 = A[s1], c2 = A[s2];
+        const u32* const wp = (const u32*)(myIn + (q & (FSE_IN_RING - 4)));
+        const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        const u32 thi = __builtin_amdgcn_alignbit(d2, d1, bq), tlo = __builtin_amdgcn_alignbit(d1, d0, bq);
         uint2 rec;
-        rec.x = s1 | (s2 << 16);
-        fse_bulk_consume<NB0>(c1, s1, thi, tlo, u);
-        fse_bulk_consume<NB0>(c2, s2, thi, tlo, u);
-        const u32 c3 = A[s1], c4 = A[s2];            // second pair
-        rec.y = s1 | (s2 << 16);
-        fse_bulk_consume<NB0>(c3, s1, thi, tlo, u);
-        fse_bulk_consume<NB0>(c4, s2, thi, tlo, u);
-        myRing[(iters + it) & (FSE_DEC_RING - 1)] = rec;
+        rec.x = __builtin_amdgcn_perm(s2, s1, 0x05040100u);      // s1 | s2 << 16
+        u32 nb1, nb2, nb3, nb4;
+        FSE_BULK_SYM(c1, s1, thi, nb1)
+        const u32 c3 = A[s1];
+        FSE_BULK_SYM(c2, s2, thi << nb1, nb2)
+        const u32 c4 = A[s2];
+        const u32 s12 = nb1 + nb2;
+        u32 t3 = __builtin_amdgcn_alignbit(thi, tlo, 32u - s12);
+        if (NB0) t3 = s12 ? t3 : thi;
+        rec.y = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
+        FSE_BULK_SYM(c3, s1, t3, nb3)
+        FSE_BULK_SYM(c4, s2, t3 << nb3, nb4)
+        const int left = (int)bq - (int)(s12 + nb3 + nb4);       // unread bits of dword dp after this iteration (>= -48)
+        q += (u32)((left >> 5) << 2);                            // arithmetic shift: 0, -1 or -2 dwords
+        bq = (u32)left & 31u;
+        ring[it] = rec;
     }
-    b.s1 = s1; b.s2 = s2; b.pofs = pofs; b.u = u; b.whi = whi; b.wlo = wlo; b.l1hi = l1hi; b.l1lo = l1lo; b.l2hi = l2hi; b.l2lo = l2lo;
+    b.s1 = s1; b.s2 = s2; b.q = q; b.bq = bq;
 }
 
 // Per-block control words in LDS: the decoder wave and the service wave of a workgroup talk through these only.
@@ -111,7 +103,7 @@ struct DecCtl {
     u32 inLo, inHi, outLo, outHi, symLo, symHi;
     u32 pad[4];
 };
-#define FSE_DEC_THREADS 128
+#define FSE_DEC_THREADS (64 * (1 + FSE_SRV_WAVES))     // wave 0 decodes, the others serve
 #define FSE_CTL_BYTES (FSE_MAXG * (u32)sizeof(DecCtl))
 
 DEV u32 ctl_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -119,113 +111,162 @@ DEV int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, _
 DEV void ctl_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// ---- service wave: keeps the input rings filled and turns state-ring records into output bytes, so that the decoder
-//      wave spends its cycles on the dependent chains only.  Everything here is wave-cooperative and coalesced:
+// ---- service waves: keep the input rings filled and turn state-ring records into output bytes, so that the decoder
+//      wave spends its cycles on the dependent chains only.  Each of the FSE_SRV_WAVES service waves looks after
+//      FSE_SRV_G of the workgroup's blocks; everything here is wave-cooperative and coalesced:
 //        * input : 256-byte chunks, one 4-byte load per lane, written below the bytes the decoder is reading;
-//        * output: record i of a block = the 4 states iteration i decoded FROM; symbol = cell[state].symbol, gathered
-//                  from the L2-resident table in global memory, packed, stored as one 256-byte row per 64 records.
-DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane)
+//        * output: record i of a block = the 4 states iteration i decoded FROM; symbol = symbolOf[state], gathered
+//                  from the L2-resident table in global memory (byte table from k_fse_dbuild, or the symbol bytes of the
+//                  reference-layout cells: stride 1 << symShift), packed, stored as one 256-byte row per 64 records.
+#define FSE_SRV_WAVES 4
+#define FSE_SRV_G (FSE_MAXG / FSE_SRV_WAVES)
+DEV void fse_ring_put(u32* rg, int off, u32 w)
 {
-    DecCtl* const ctl = ctlAll + (lane < FSE_MAXG ? lane : 0);
-    const bool mineValid = lane < a.G;
-    // per-block constants live in the registers of lane g of this wave
+    const u32 j = (u32)off & (FSE_IN_RING - 1);
+    rg[j >> 2] = w;
+    if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = w;
+}
+DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0)
+{
+    const u32 symShift = a.atab ? 0u : 2u;
+    const int myG = g0 + (lane < FSE_SRV_G ? lane : 0);      // lane l of this wave keeps the books of block g0 + l
+    DecCtl* const ctl = ctlAll + myG;
+    // per-block constants live in the registers of lane l of this wave
     const unsigned long long inBits = ((unsigned long long)ctl->inHi << 32) | ctl->inLo;
     const unsigned long long outBits = ((unsigned long long)ctl->outHi << 32) | ctl->outLo;
     const unsigned long long tabBits = ((unsigned long long)ctl->symHi << 32) | ctl->symLo;
     const int S32 = ctl->S32;
     int validLo = ctl->initValidLo;
     u32 flushed = 0;
-    bool live = mineValid && !(ctl->pubPofs >> 31);          // blocks that never enter the bulk loop need no service
+    bool live = lane < FSE_SRV_G && myG < a.G && !(ctl->pubPofs >> 31);   // blocks that never enter the bulk loop need no service
 
-    // initial fill: two chunks per live block, then publish
+    // initial fill: two chunks per live block (the topmost dword may straddle the end of the payload), then publish
     {   const unsigned long long am = __ballot(live);
 #pragma unroll
-        for (int g = 0; g < FSE_MAXG; ++g) {
-            if (!((am >> g) & 1ull)) continue;               // uniform
-            const int vlo = __shfl(validLo, g, WAVE), Sg = __shfl(S32, g, WAVE);
-            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, g, WAVE);
-            u32* const rg = (u32*)(ldsb + (size_t)g * slotBytes + inOff);
+        for (int l = 0; l < FSE_SRV_G; ++l) {
+            if (!((am >> l) & 1ull)) continue;               // uniform
+            const int vlo = __shfl(validLo, l, WAVE), Sg = __shfl(S32, l, WAVE);
+            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
+            u32* const rg = (u32*)(ldsb + (size_t)(g0 + l) * slotBytes + inOff);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int off = vlo + FSE_IN_CHUNK * c + 4 * lane;
-                if (off >= 0 && off + 4 <= Sg) {
-                    u32 w; __builtin_memcpy(&w, ig + off, 4);
-                    const u32 j = (u32)off & (FSE_IN_RING - 1);
-                    rg[j >> 2] = w;
-                    if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = w;
+                if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); fse_ring_put(rg, off, w); }
+                else if (off >= 0 && off < Sg) {
+                    u32 w = 0;
+                    for (int i = 0; i < 3; ++i) if (off + i < Sg) w |= (u32)ig[off + i] << (8 * i);
+                    fse_ring_put(rg, off, w);
                 }
             }
         }
         if (live) ctl_store(&ctl->srvValidLo, validLo);
     }
 
-    u32 pend[FSE_MAXG];
-    u32 yq[FSE_MAXG][4];
+    u32 pend[FSE_SRV_G];
+    u32 yq[FSE_SRV_G][4];
 #pragma unroll
-    for (int g = 0; g < FSE_MAXG; ++g) { pend[g] = 0; yq[g][0] = yq[g][1] = yq[g][2] = yq[g][3] = 0; }
+    for (int l = 0; l < FSE_SRV_G; ++l) { pend[l] = 0; yq[l][0] = yq[l][1] = yq[l][2] = yq[l][3] = 0; }
+    TIMING(unsigned long long sBusy = 0; unsigned long long sIdle = 0; unsigned long long nBusy = 0; unsigned long long sA = __builtin_readcyclecounter();)
     for (;;) {
         // snapshot of the decoder's progress (the finished flag is read before the iteration count it guards)
         u32 pp = 0x80000000u, it = flushed;
         if (live) { pp = ctl_load(&ctl->pubPofs); it = ctl_load(&ctl->pubIters); }
         const bool fin = (pp >> 31) != 0;
-        const int pofs = (int)(pp & 0x7FFFFFFFu);
+        const int P = (int)(pp & 0x7FFFFFFFu);               // byte offset of the topmost dword the decoder still reads
         const u32 avail = it - flushed;
         const bool wantFlush = live && (avail >= 32u || (fin && avail > 0));
-        const bool wantFill = live && !fin && validLo > 0 && pofs <= validLo + FSE_IN_CHUNK + 8;
+        // the chunk [validLo-256, validLo) lands on the ring bytes of [validLo+256, validLo+512): the decoder must be below
+        const bool wantFill = live && !fin && validLo > 0 && P + 4 <= validLo + FSE_IN_CHUNK;
         const unsigned long long fm = __ballot(wantFlush), rm = __ballot(wantFill);
         if (live && fin && avail == 0) live = false;
         if (!(fm | rm)) {
             if (!__any(live)) break;
             __builtin_amdgcn_s_sleep(4);
+            TIMING({ const unsigned long long sB = __builtin_readcyclecounter(); sIdle += sB - sA; sA = sB; })
             continue;
         }
         // (1) request the next input chunk of every block that is about to need it
 #pragma unroll
-        for (int g = 0; g < FSE_MAXG; ++g) {
-            if (!((rm >> g) & 1ull)) continue;               // uniform
-            const int off = __shfl(validLo, g, WAVE) - FSE_IN_CHUNK + 4 * lane;
-            const int Sg = __shfl(S32, g, WAVE);
-            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, g, WAVE);
+        for (int l = 0; l < FSE_SRV_G; ++l) {
+            if (!((rm >> l) & 1ull)) continue;               // uniform
+            const int off = __shfl(validLo, l, WAVE) - FSE_IN_CHUNK + 4 * lane;
+            const int Sg = __shfl(S32, l, WAVE);
+            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
             u32 w = 0;
             if (off >= 0 && off + 4 <= Sg) __builtin_memcpy(&w, ig + off, 4);
-            pend[g] = w;
+            pend[l] = w;
         }
         // (2) issue the symbol gathers of every block with enough records
 #pragma unroll
-        for (int g = 0; g < FSE_MAXG; ++g) {
-            if (!((fm >> g) & 1ull)) continue;               // uniform
-            const u32 cnt = (u32)__shfl((int)avail, g, WAVE), fl_g = (u32)__shfl((int)flushed, g, WAVE);
-            const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, g, WAVE);
+        for (int l = 0; l < FSE_SRV_G; ++l) {
+            if (!((fm >> l) & 1ull)) continue;               // uniform
+            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
+            const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, l, WAVE);
             if ((u32)lane < cnt) {
-                const uint2 rec = ((const uint2*)(ldsb + (size_t)g * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
-                yq[g][0] = tg[4u * (rec.x & 0xFFFFu) + 2]; yq[g][1] = tg[4u * (rec.x >> 16) + 2];
-                yq[g][2] = tg[4u * (rec.y & 0xFFFFu) + 2]; yq[g][3] = tg[4u * (rec.y >> 16) + 2];
+                const uint2 rec = ((const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
+                yq[l][0] = tg[(rec.x & 0xFFFFu) << symShift]; yq[l][1] = tg[(rec.x >> 16) << symShift];
+                yq[l][2] = tg[(rec.y & 0xFFFFu) << symShift]; yq[l][3] = tg[(rec.y >> 16) << symShift];
             }
         }
         // (3) install the input chunks and publish them
 #pragma unroll
-        for (int g = 0; g < FSE_MAXG; ++g) {
-            if (!((rm >> g) & 1ull)) continue;               // uniform
-            const int nlo = __shfl(validLo, g, WAVE) - FSE_IN_CHUNK;
-            const u32 j = (u32)(nlo + 4 * lane) & (FSE_IN_RING - 1);
-            u32* const rg = (u32*)(ldsb + (size_t)g * slotBytes + inOff);
-            rg[j >> 2] = pend[g];
-            if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = pend[g];
+        for (int l = 0; l < FSE_SRV_G; ++l) {
+            if (!((rm >> l) & 1ull)) continue;               // uniform
+            const int nlo = __shfl(validLo, l, WAVE) - FSE_IN_CHUNK;
+            fse_ring_put((u32*)(ldsb + (size_t)(g0 + l) * slotBytes + inOff), nlo + 4 * lane, pend[l]);
         }
         if (wantFill) { validLo -= FSE_IN_CHUNK; ctl_store(&ctl->srvValidLo, validLo); }
         // (4) the ring records are in registers now: hand the slots back, then pack and store the symbols
         if (wantFlush) { ctl_store(&ctl->srvFlushed, it); }
 #pragma unroll
-        for (int g = 0; g < FSE_MAXG; ++g) {
-            if (!((fm >> g) & 1ull)) continue;               // uniform
-            const u32 cnt = (u32)__shfl((int)avail, g, WAVE), fl_g = (u32)__shfl((int)flushed, g, WAVE);
-            u8* const og = (u8*)(uintptr_t)__shfl(outBits, g, WAVE) + 4ull * fl_g;
+        for (int l = 0; l < FSE_SRV_G; ++l) {
+            if (!((fm >> l) & 1ull)) continue;               // uniform
+            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
+            u8* const og = (u8*)(uintptr_t)__shfl(outBits, l, WAVE) + 4ull * fl_g;
             if ((u32)lane < cnt) {
-                const u32 w = yq[g][0] | (yq[g][1] << 8) | (yq[g][2] << 16) | (yq[g][3] << 24);
+                const u32 w = yq[l][0] | (yq[l][1] << 8) | (yq[l][2] << 16) | (yq[l][3] << 24);
                 __builtin_memcpy(og + 4u * lane, &w, 4);
             }
         }
         if (wantFlush) flushed = it;
+        TIMING({ const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy; })
+    }
+    TIMING(if (lane == 0 && g0 == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[4] = sBusy; t[5] = sIdle; t[6] = nBusy; })
+}
+
+// cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
+struct FseCellsRef { const u32* cells;
+    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = cells[st]; ns = c & 0xFFFFu; sym = (c >> 16) & 0xFFu; nb = c >> 24; } };
+struct FseCellsCompact { const u16* A; const u8* syms;
+    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = A[st]; ns = c & 0xFFFu; nb = c >> 12; sym = syms[st]; } };
+template <class Cells>
+DEV u32 fse_tail_step(const Cells& t, u32& state, BitReader& r, bool fast)          // FSE_decodeSymbol(Fast), fse.h:600-622
+{
+    u32 ns, nb, sym;
+    t.get(state, ns, nb, sym);
+    const u32 low = fast ? r.read_fast(nb) : r.read(nb);
+    state = ns + low;
+    return sym;
+}
+template <class Cells>
+DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long op, long omax, bool fast)
+{
+    for (;;) {                                                   // remaining iterations of fse_decompress.c:201-218
+        const int st = r.reload();
+        if (!((st == BR_UNFINISHED) & (op < omax - 3))) break;
+        out[op + 0] = (u8)fse_tail_step(t, s1, r, fast);
+        out[op + 1] = (u8)fse_tail_step(t, s2, r, fast);
+        out[op + 2] = (u8)fse_tail_step(t, s1, r, fast);
+        out[op + 3] = (u8)fse_tail_step(t, s2, r, fast);
+        op += 4;
+    }
+    for (;;) {                                                   // :222-235
+        if (op > omax - 2) return FERR(dstSize_tooSmall);
+        out[op++] = (u8)fse_tail_step(t, s1, r, fast);
+        if (r.reload() == BR_OVERFLOW) { out[op++] = (u8)fse_tail_step(t, s2, r, fast); return (size_t)op; }
+        if (op > omax - 2) return FERR(dstSize_tooSmall);
+        out[op++] = (u8)fse_tail_step(t, s2, r, fast);
+        if (r.reload() == BR_OVERFLOW) { out[op++] = (u8)fse_tail_step(t, s1, r, fast); return (size_t)op; }
     }
 }
 
@@ -252,6 +293,14 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             const size_t b = first + g;
             if (b >= a.nBlocks) break;
             if (a.meta && a.meta[b].state == 0) continue;
+            if (a.atab) {                                        // k_fse_dbuild output: already in the LDS format
+                const u32 ts = 1u << a.meta[b].tableLog;
+                const u32* const t32 = (const u32*)(a.atab + (b << a.maxTableLog));
+                u32* const A32 = (u32*)(ldsb + (size_t)g * slotBytes);
+                for (u32 i = tid; i < ts / 2; i += FSE_DEC_THREADS) A32[i] = t32[i];
+                anyNb0 |= !(a.meta[b].state & 2u);               // a cell with nbBits == 0 needs a counter > tableSize/2
+                continue;
+            }
             const u32* t = a.dtables + b * a.dtStrideU32;
             const u32 tl = t[0] & 0xFFFFu;
             if (tl > a.maxTableLog) continue;
@@ -280,13 +329,15 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     u32 hdr = 0;
     if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
     u32 tl = 0; bool fast = false;
-    const u32* const gtab = a.dtables + (owner ? b : 0) * a.dtStrideU32;   // reference-layout table in global memory
+    const bool compact = a.atab != nullptr;
+    const u32* const gtab = compact ? nullptr : a.dtables + (owner ? b : 0) * a.dtStrideU32;   // reference-layout table in global memory
     if (owner) {
-        const u32 h0 = gtab[0];
-        tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0;
+        if (compact) { tl = a.meta[b].tableLog; fast = (a.meta[b].state & 2u) != 0; }
+        else { const u32 h0 = gtab[0]; tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0; }
         if (tl > a.maxTableLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; }
     }
-    const u32* const cells = gtab + 1;                          // literal path reads the reference cells
+    const u32* const cells = compact ? nullptr : gtab + 1;      // literal path: reference cells, or the LDS cells + symbol table
+    const u8* const syms = compact ? a.symtab + ((owner ? b : 0) << a.maxTableLog) : (const u8*)cells + 2;
     const u16* const A = (const u16*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes);
     const u8* in = nullptr; size_t S = 0; u8* out = nullptr;
     const long omax = (long)a.dstCapacity;
@@ -314,72 +365,66 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // (>= 16 output groups left and the window stays >= 24 bytes above the stream start: at >= 24 + 16*6), so the
     // 16 iterations of a phase run without any per-iteration bookkeeping; whatever is left goes to the literal tail.
     // Bulk state uses p = at+1, u = used+8 (u in [8,16) after a reload), so no shift amount is ever 0 or 32.
-    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> lane) & 1u);
-    BulkState bs; bs.s1 = s1; bs.s2 = s2; bs.pofs = (u32)r.at + 1u; bs.u = r.used + 8u;
-    bs.whi = bs.wlo = bs.l1hi = bs.l1lo = bs.l2hi = bs.l2lo = 0;
+    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> lane) & 1u);
+    BulkState bs; bs.s1 = s1; bs.s2 = s2; bs.q = 0; bs.bq = 0;
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + 512)
     if (can) {
-        const u64 w = ldg64u(in + bs.pofs), a1 = ldg64u(in + bs.pofs - 8), a2 = ldg64u(in + bs.pofs - 16);
-        bs.whi = (u32)(w >> 32); bs.wlo = (u32)w; bs.l1hi = (u32)(a1 >> 32); bs.l1lo = (u32)a1; bs.l2hi = (u32)(a2 >> 32); bs.l2lo = (u32)a2;
+        const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the payload
+        bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
         groups = (omax - 3 - op + 3) >> 2;
-        validLo = ((int)bs.pofs - 16 - 208) & ~255;  // slack below the lowest byte read next
+        // P = q + 8 = byte offset of dword dp.  The ring must reach up to P + 4 and down to the lowest byte a phase can
+        // read, P - 8 - 6*16 = P - 104
+        validLo = ((int)bs.q + 8 - 232) & ~255;
     }
     DecCtl* const ctl = ctlAll + (lane < FSE_MAXG ? lane : 0);
     if (wave == 0 && lane < FSE_MAXG) {
-        ctl->pubIters = 0; ctl->pubPofs = can ? bs.pofs : 0x80000000u;
+        ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S : 0);
-        const unsigned long long ib = (unsigned long long)(uintptr_t)in, ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)cells;
+        const unsigned long long ib = (unsigned long long)(uintptr_t)in, ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)syms;
         ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
     }
     __syncthreads();
-    if (wave == 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane); return; }
+    if (wave >= 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G); return; }
 
     uint2* const myRing = (uint2*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + ringOff);
     const u8* const myIn = ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + inOff;
+    TIMING(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
     while (__any(can)) {
         bool ready = false;
         if (can) {
             const u32 fl = ctl_load(&ctl->srvFlushed);
             const int vlo = ctl_load(&ctl->srvValidLo);
             // room for 16 more records, and the lowest byte this phase can read (p - 6*16 - 16) is in the ring
-            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.pofs - 6 * FSE_CHECK_EVERY - 16 >= vlo);
+            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - 6 * FSE_CHECK_EVERY >= vlo);
         }
         if (ready) {
-            if (nb0) fse_bulk_phase<true>(bs, A, myIn, myRing, iters);
-            else     fse_bulk_phase<false>(bs, A, myIn, myRing, iters);
+            uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
+            if (nb0) fse_bulk_phase<true>(bs, A, myIn, ring);
+            else     fse_bulk_phase<false>(bs, A, myIn, ring);
             iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
-            can = bs.pofs - 1u >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
+            // the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
+            can = bs.q >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
             ctl_store(&ctl->pubIters, iters);
-            ctl_store(&ctl->pubPofs, can ? bs.pofs : (bs.pofs | 0x80000000u));
+            ctl_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
         }
+        TIMING({ const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB; })
         if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
     }
+    TIMING(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[0] = tRun; t[1] = tWait; t[2] = nRun; t[3] = nWait; })
     if (!owner) return;
     op = 4 * (long)iters;
-    if (iters) { r.at = (size_t)bs.pofs - 1; r.used = bs.u - 8u; r.win = ldg64u(in + r.at); s1 = bs.s1; s2 = bs.s2; }   // back to the reference's (at, used, window)
+    if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container) after a reload
+        const u32 B = 8u * (bs.q + 8u) + bs.bq;
+        r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = bs.s1; s2 = bs.s2;
+    }
 
-    // ---- literal tail: remaining iterations of :201-218, then :222-235 (cells read from the reference table)
-    for (;;) {
-        const int st = r.reload();
-        if (!((st == BR_UNFINISHED) & (op < omax - 3))) break;
-        out[op + 0] = (u8)fse_step(s1, r, cells, fast);
-        out[op + 1] = (u8)fse_step(s2, r, cells, fast);
-        out[op + 2] = (u8)fse_step(s1, r, cells, fast);
-        out[op + 3] = (u8)fse_step(s2, r, cells, fast);
-        op += 4;
-    }
+    // ---- literal tail: remaining iterations of :201-218, then :222-235
     size_t result;
-    for (;;) {
-        if (op > omax - 2) { result = FERR(dstSize_tooSmall); break; }
-        out[op++] = (u8)fse_step(s1, r, cells, fast);
-        if (r.reload() == BR_OVERFLOW) { out[op++] = (u8)fse_step(s2, r, cells, fast); result = (size_t)op; break; }
-        if (op > omax - 2) { result = FERR(dstSize_tooSmall); break; }
-        out[op++] = (u8)fse_step(s2, r, cells, fast);
-        if (r.reload() == BR_OVERFLOW) { out[op++] = (u8)fse_step(s1, r, cells, fast); result = (size_t)op; break; }
-    }
+    if (compact) result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
+    else         result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
 }
 

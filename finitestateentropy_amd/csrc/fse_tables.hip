@@ -8,6 +8,7 @@
 #include "internal.h"
 
 #include "fse_glue.h"
+#include "fse_wave_build.h"
 
 // ---------------------------------------------------------------------------------------------------
 //  prepare kernels (one lane per block)
@@ -48,7 +49,13 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a)
     if (m.state == 0) a.results[b] = result;
 }
 
-__global__ __launch_bounds__(64) void k_fse_dprep(FseDPrepArgs a)
+// Decompress side, two kernels:
+//   k_fse_dparse : one lane per block -- FSE_readNCount (a serial bit parser, lib/entropy_common.c:41-144) and the
+//                  checks of FSE_decompress_wksp (lib/fse_decompress.c:264-269); leaves the counters in scratch;
+//   k_fse_dbuild : one wave per block -- FSE_buildDTable (lib/fse_decompress.c:71-126) with the wave-cooperative
+//                  spread / rank of fse_wave_build.h, emitting the decoder's compact cell format
+//                  (cell = newState | nbBits << 12, symbol in a separate byte table) with coalesced stores.
+__global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
 {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= a.nBlocks) return;
@@ -57,17 +64,40 @@ __global__ __launch_bounds__(64) void k_fse_dprep(FseDPrepArgs a)
     const size_t cSize = view_size(a.csrc, b);
     size_t result = 0;
     do {
-        s16 norm[256];
         u32 tl = 0, maxSV = 255;
-        const size_t h = fse_read_ncount(norm, &maxSV, &tl, in, cSize);    // fse_decompress.c:264
+        const size_t h = fse_read_ncount(a.norms + b * 256, &maxSV, &tl, in, cSize);    // fse_decompress.c:264
         if (is_err(h)) { result = h; break; }
         if (tl > a.maxLog) { result = FERR(tableLog_tooLarge); break; }    // :266
-        const size_t e = fse_build_dtable(a.dtables + b * a.dtStrideU32, norm, maxSV, tl);   // :271
-        if (is_err(e)) { result = e; break; }
         m.state = 1; m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
     } while (0);
     a.meta[b] = m;
     if (m.state == 0) a.results[b] = result;
+}
+
+__global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 wbLds[];
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const FseMeta m = a.meta[b];
+    if (m.state == 0) return;                                              // uniform
+    const WaveBuildLds w = wave_build_carve(wbLds, capTs);
+    *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
+    __syncthreads();
+    const u32 tl = m.tableLog, ts = 1u << tl;
+    const bool fast = wave_spread_rank(w, m.maxSV, tl, lane, [&](u32 u, u32 s, u32 r) {
+        const int n = w.nrm[s];
+        const u32 next = (n > 0 ? (u32)n : 1u) + r;                        // symbolNext[s]++, fse_decompress.c:117-122
+        const u32 nb = tl - hibit32(next);
+        w.cell[u] = (u16)((((next << nb) - ts) & 0xFFFu) | (nb << 12));
+    });
+    u32* const A32 = (u32*)(a.atab + b * capTs);
+    const u32* const c32 = (const u32*)w.cell;
+    for (u32 i = lane; i < ts / 2; i += 64) A32[i] = c32[i];
+    u32* const S32 = (u32*)(a.symtab + b * capTs);
+    const u32* const y32 = (const u32*)w.symTab;
+    for (u32 i = lane; i < ts / 4; i += 64) S32[i] = y32[i];
+    if (lane == 0) a.meta[b].state = 1u | (fast ? 2u : 0u);
 }
 
 hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
@@ -81,8 +111,11 @@ hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    const u32 capTs = 1u << a.maxLog;
+    const size_t ldsBytes = 512 + 520 + 256 + 3 * (size_t)capTs + 16384 + 8192;
     probe_before(PK_FSE_DPREP, s);
-    hipLaunchKernelGGL(k_fse_dprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_fse_dparse, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
     probe_after(PK_FSE_DPREP, s);
     return hipGetLastError();
 }

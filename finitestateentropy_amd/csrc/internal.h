@@ -74,8 +74,11 @@ inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
 struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
     BlockView csrc;
     unsigned maxLog;
-    u32* dtables; size_t dtStrideU32;
-    FseMeta* meta;
+    // outputs, `capTs` = 1 << maxLog cells per block: the decoder's own table format (fse_decode.hip)
+    u16* atab;                   // cell x: newState (12 bits) | nbBits << 12
+    u8* symtab;                  // cell x: symbol
+    s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
+    FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1
     size_t* results;
     size_t nBlocks;
 };
@@ -85,7 +88,8 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     u8* dst; size_t dstStride; size_t dstCapacity;
     size_t* results;
     BlockView csrc;
-    const u32* dtables; size_t dtStrideU32;
+    const u32* dtables; size_t dtStrideU32;   // reference-layout tables (usingDTable batch), or nullptr:
+    const u16* atab; const u8* symtab;        // tables in the decoder's own format from k_fse_dbuild, 1 << maxTableLog cells per block
     const FseMeta* meta;         // nullptr for the plain usingDTable batch
     unsigned maxTableLog;
     int G;
