@@ -11,9 +11,15 @@
 #include "fse_wave_build.h"
 
 // ---------------------------------------------------------------------------------------------------
-//  prepare kernels (one lane per block)
+//  prepare kernels
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a)
+// Compress side, two kernels:
+//   k_fse_cnorm  : one lane per block -- the early outs of FSE_compress_wksp, FSE_optimalTableLog, FSE_normalizeCount
+//                  and FSE_writeNCount (serial by nature; lib/fse_compress.c:632-665); leaves the counters in scratch;
+//   k_fse_cbuild : one wave per block -- FSE_buildCTable_wksp (lib/fse_compress.c:66-169) with the wave-cooperative
+//                  spread / rank of fse_wave_build.h; the table is assembled in LDS in the reference layout and
+//                  written out with coalesced stores.
+__global__ __launch_bounds__(64) void k_fse_cnorm(FseCPrepArgs a)
 {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= a.nBlocks) return;
@@ -29,7 +35,7 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a)
         if (top < (n >> 7)) { result = 0; break; }
         const u32 maxSV = a.maxSVs[b];
         const u32 tl = fse_optimal_tablelog(a.tableLogReq ? a.tableLogReq : FSE_DEF_TL, n, maxSV, 2);   // :649,658
-        s16 norm[256];
+        s16* const norm = a.norms + b * 256;
         const unsigned* count = a.counts + b * 256;
         {   const size_t e = fse_normalize_count(norm, tl, count, n, maxSV);   // :659
             if (is_err(e)) { result = e; break; }
@@ -37,7 +43,6 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a)
         u8* const dst = a.dst + b * a.dstStride;
         const size_t h = fse_write_ncount(dst, a.dstCapacity, norm, maxSV, tl);   // :662
         if (is_err(h)) { result = h; break; }
-        fse_build_ctable(a.ctables + b * a.ctStrideU32, a.cellSym + b * a.cellSymStride, norm, maxSV, tl);   // :667
         // Encoder choice (fse_encode_par.hip): the block-parallel kernel relies on two encoder states fed the same symbols
         // merging quickly; per step that happens with probability ~ sum_s p_s / norm_s = present / tableSize.
         u32 present = 0;
@@ -47,6 +52,51 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a)
     } while (0);
     a.meta[b] = m;
     if (m.state == 0) a.results[b] = result;
+}
+
+__global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 wbLds[];
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const FseMeta m = a.meta[b];
+    if (m.state == 0) return;                                              // uniform
+    const WaveBuildLds w = wave_build_carve(wbLds, capTs);
+    u32* const img = (u32*)(wbLds + 512 + 520 + 256 + 3 * (size_t)capTs + 16384 + 8192);   // CTable image: 1 + capTs/2 + 512 words
+    u16* const cumAll = (u16*)(img + 1 + capTs / 2 + 512);                                  // [256] first stateTable slot of every symbol
+    *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
+    __syncthreads();
+    const u32 tl = m.tableLog, ts = 1u << tl, maxSV = m.maxSV;
+    u16* const stateTable = (u16*)(img + 1);
+    u32* const tt = img + 1 + (ts >> 1);                                   // tl >= FSE_MIN_TABLELOG here
+    {   // per symbol (lane l: symbols 4l..4l+3): cumulative slot, symbolTT (fse_compress.c:136-166)
+        int n[4]; u32 eff[4], laneSum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u32 s = 4 * lane + i; n[i] = s <= maxSV ? (int)w.nrm[s] : 0; eff[i] = n[i] == -1 ? 1u : (u32)n[i]; laneSum += eff[i]; }
+        u32 total;
+        u32 run = wb_scan_excl(laneSum, lane, &total);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 s = 4 * lane + i;
+            cumAll[s] = (u16)run;
+            if (s <= maxSV) {
+                if (n[i] == 0) { tt[2 * s] = 0; tt[2 * s + 1] = ((tl + 1) << 16) - ts; }
+                else if (n[i] == -1 || n[i] == 1) { tt[2 * s] = run - 1u; tt[2 * s + 1] = (tl << 16) - ts; }
+                else {
+                    const u32 maxBitsOut = tl - hibit32((u32)n[i] - 1);
+                    tt[2 * s] = run - (u32)n[i];
+                    tt[2 * s + 1] = (maxBitsOut << 16) - ((u32)n[i] << maxBitsOut);
+                }
+            }
+            run += eff[i];
+        }
+        if (lane == 0) img[0] = tl | (maxSV << 16);
+    }
+    __syncthreads();
+    wave_spread_rank(w, maxSV, tl, lane, [&](u32 u, u32 s, u32 r) { stateTable[(u32)cumAll[s] + r] = (u16)(ts + u); });   // :125-133
+    u32* const out = a.ctables + b * a.ctStrideU32;
+    const u32 words = 1 + (ts >> 1) + 2 * (maxSV + 1);
+    for (u32 i = lane; i < words; i += 64) out[i] = img[i];
 }
 
 // Decompress side, two kernels:
@@ -103,8 +153,11 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
 hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    const u32 capTs = 1u << a.maxTl;
+    const size_t ldsBytes = 512 + 520 + 256 + 3 * (size_t)capTs + 16384 + 8192 + 4 * (1 + (size_t)capTs / 2 + 512) + 512;
     probe_before(PK_FSE_CPREP, s);
-    hipLaunchKernelGGL(k_fse_cprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_fse_cnorm, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_fse_cbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
     probe_after(PK_FSE_CPREP, s);
     return hipGetLastError();
 }

@@ -31,7 +31,8 @@ struct FseCPrepArgs {            // glue g1-g4 (compress side): lib/fse_compress
     u8* dst; size_t dstStride; size_t dstCapacity;
     unsigned maxSVReq, tableLogReq;
     u32* ctables; size_t ctStrideU32;
-    u8* cellSym; size_t cellSymStride;   // scratch: tableSize bytes per block
+    unsigned maxTl;              // largest tableLog FSE_optimalTableLog can pick for this request (sizes the tables)
+    s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
     FseMeta* meta;
     size_t* results;
     size_t nBlocks;
