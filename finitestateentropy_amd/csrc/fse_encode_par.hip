@@ -280,8 +280,8 @@ hipError_t launch_fse_encode_par(FseEncArgs a, hipStream_t s)
     size_t img = a.dstCapacity + 32;
     if (fixed + img > maxLds) img = maxLds - fixed;
     img &= ~(size_t)15;
-    probe_before(PK_FSE_ENCODE, s);
+    probe_before(PK_FSE_ENCODE_PAR, s);
     hipLaunchKernelGGL(k_fse_encode_par, dim3((unsigned)a.nBlocks), dim3(FSE_PAR_THREADS), fixed + img, s, a, tableWords, (u32)srcBytes, (u32)img);
-    probe_after(PK_FSE_ENCODE, s);
+    probe_after(PK_FSE_ENCODE_PAR, s);
     return hipGetLastError();
 }

@@ -1,0 +1,269 @@
+// fse_encode_wave.hip -- a2: FSE_compress_usingCTable, one wave per block
+// (reference: lib/fse_compress.c:554-623, lib/fse.h:503-527, lib/bitstream.h:183-260; format SURVEY A.1/A.3).
+//
+// tANS encoding is a loop-carried chain (two interleaved chains per block), but the encoder state is only
+// tableLog bits wide and every step replaces part of it by a function of the symbol alone, so a chain "forgets"
+// where it came from.  That makes the block splittable without changing a single output bit:
+//
+//   One 64-lane wave per block; only the CTable lives in LDS, so many blocks are resident per CU.  In emission
+//   order (last source byte first) lane t owns a contiguous range of symbols.
+//   Pass 1: the lane warms both chains up over the FSE_WV_WARM symbols in front of its range starting from an
+//   arbitrary state, remembers the states it arrives with (its speculated start), then runs its range counting
+//   bits and remembers the states it ends with.  Verification: lane t's speculated start must equal lane t-1's
+//   end; lane 0 starts from the exact FSE_initCState2 states, so if every link matches, every start is exact by
+//   induction.  A lane whose link does not match re-runs its range from its predecessor's end, and the check is
+//   repeated until no link changes (worst case this degenerates into the serial algorithm).  Nothing is assumed:
+//   the output is bit-exact by construction.
+//   Pass 2: a wave prefix sum of the bit counts gives every lane its bit offset (and the exact compressed size /
+//   the BIT_closeCStream verdict before a single bit is written); each lane re-runs its range from its verified
+//   start and writes its bits straight to global memory: whole 32-bit words as they fill up, the last whole
+//   bytes at the end.  The byte shared by two neighbouring ranges is stored by the upper lane with the lower
+//   lane's bits OR-ed in afterwards (one global atomic per lane).  CState2, CState1 and the end mark are appended
+//   by the lane that owns the final states (lib/fse_compress.c:608-610).
+//   Source bytes are streamed per lane, 16 per (unaligned) load, one load ahead.
+#include "internal.h"
+
+#define FSE_WV_WARM 1024            // warm-up symbols (half per chain) in front of every range
+
+#define WV_STEP(ST, sym, nb)                                                                         \
+    {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
+        const u32 f2_ = e_.x, dn_ = e_.y;                                                             \
+        nb = ((ST) + dn_) >> 16;                                                                      \
+        (ST) = *(const u16*)(ldsb + ((((ST) >> nb) << 1) + f2_));                                     \
+    }
+#define WV_STEP_BITS(ST, sym, nb, bits)                                                              \
+    {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
+        const u32 f2_ = e_.x, dn_ = e_.y;                                                             \
+        nb = ((ST) + dn_) >> 16;                                                                      \
+        bits = __builtin_amdgcn_ubfe((ST), 0u, nb);                                                   \
+        (ST) = *(const u16*)(ldsb + ((((ST) >> nb) << 1) + f2_));                                     \
+    }
+
+DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+
+// run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even);
+// returns the number of bits they emit.
+DEV u32 wv_count(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
+{
+    u32 bits = 0, j = ja;
+    if (j + 16 <= jb) {
+        uint4 cur = wv_load16(src + (n - 16 - j));
+        while (j + 16 <= jb) {
+            const u32 nj = j + 16;
+            const uint4 nxt = wv_load16(src + (n - 16 - (nj + 16 <= jb ? nj : j)));
+            u32 na, nbb;
+#define WV_PAIR(w, hiA, hiB)                                                                         \
+            {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u); \
+                WV_STEP(xa, sa, na) WV_STEP(xb, sb, nbb) bits += na + nbb; }
+            WV_PAIR(cur.w, 24u, 16u) WV_PAIR(cur.w, 8u, 0u) WV_PAIR(cur.z, 24u, 16u) WV_PAIR(cur.z, 8u, 0u)
+            WV_PAIR(cur.y, 24u, 16u) WV_PAIR(cur.y, 8u, 0u) WV_PAIR(cur.x, 24u, 16u) WV_PAIR(cur.x, 8u, 0u)
+#undef WV_PAIR
+            cur = nxt; j = nj;
+        }
+    }
+    for (; j < jb; ++j) {
+        const u32 sym = src[n - 1 - j];
+        u32 nb;
+        if (j & 1u) { WV_STEP(xb, sym, nb) } else { WV_STEP(xa, sym, nb) }
+        bits += nb;
+    }
+    return bits;
+}
+
+// bit sink of one lane: bits are appended LSB-first; whole 32-bit words are stored as they complete
+struct WvSink {
+    u8* dst; u32 pos; u64 acc; u32 nacc;
+    DEV void put(u32 v, u32 nb) { acc |= (u64)v << nacc; nacc += nb; }
+    DEV void spill() { if (nacc >= 32u) { const u32 w = (u32)acc; __builtin_memcpy(dst + pos, &w, 4); pos += 4; acc >>= 32; nacc -= 32u; } }
+};
+
+DEV void wv_emit(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
+{
+    u32 j = ja;
+    if (j + 16 <= jb) {
+        uint4 cur = wv_load16(src + (n - 16 - j));
+        while (j + 16 <= jb) {
+            const u32 nj = j + 16;
+            const uint4 nxt = wv_load16(src + (n - 16 - (nj + 16 <= jb ? nj : j)));
+            u32 na, nbb, ba, bb;
+#define WV_PAIR(w, hiA, hiB)                                                                         \
+            {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u); \
+                WV_STEP_BITS(xa, sa, na, ba) WV_STEP_BITS(xb, sb, nbb, bb)                             \
+                k.put(ba | (bb << na), na + nbb); k.spill(); }
+            WV_PAIR(cur.w, 24u, 16u) WV_PAIR(cur.w, 8u, 0u) WV_PAIR(cur.z, 24u, 16u) WV_PAIR(cur.z, 8u, 0u)
+            WV_PAIR(cur.y, 24u, 16u) WV_PAIR(cur.y, 8u, 0u) WV_PAIR(cur.x, 24u, 16u) WV_PAIR(cur.x, 8u, 0u)
+#undef WV_PAIR
+            cur = nxt; j = nj;
+        }
+    }
+    for (; j < jb; ++j) {
+        const u32 sym = src[n - 1 - j];
+        u32 nb, bits;
+        if (j & 1u) { WV_STEP_BITS(xb, sym, nb, bits) } else { WV_STEP_BITS(xa, sym, nb, bits) }
+        k.put(bits, nb); k.spill();
+    }
+}
+
+DEV u32 wv_init_state(const u8* ldsb, const u8* ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
+{
+    const uint2 e = *(const uint2*)(ttb + 8u * sym);
+    const u32 nb = (e.y + (1u << 15)) >> 16;
+    return *(const u16*)(ldsb + (((((nb << 16) - e.y) >> nb) << 1) + e.x));
+}
+
+// the whole block by one lane, byte by byte (lib/fse_compress.c:554-623 as written): used when a lane's share of the
+// output is shorter than one byte, which the word-wise writer above does not handle
+DEV size_t wv_serial(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u8* dst, size_t cap, u32 tl)
+{
+    const u32 lim = (u32)(cap - 8);
+    u64 acc = 0; u32 nacc = 0, pos = 0;
+    u32 xa = wv_init_state(ldsb, ttb, src[n - 1]), xb = wv_init_state(ldsb, ttb, src[n - 2]);
+    for (u32 j = 2; j < n; ++j) {
+        const u32 sym = src[n - 1 - j];
+        u32 nb, bits;
+        if (j & 1u) { WV_STEP_BITS(xb, sym, nb, bits) } else { WV_STEP_BITS(xa, sym, nb, bits) }
+        acc |= (u64)bits << nacc; nacc += nb;
+        if (nacc >= 32u || j + 1 == n) {                                   // BIT_flushBits, bitstream.h:239-249
+            __builtin_memcpy(dst + pos, &acc, 8);
+            const u32 nby = nacc >> 3; pos += nby; pos = pos > lim ? lim : pos; acc >>= (nby << 3); nacc &= 7u;
+        }
+    }
+    const u32 c2 = (n & 1u) ? xb : xa, c1 = (n & 1u) ? xa : xb, mask = (1u << tl) - 1u;
+#define WV_FLUSH() { __builtin_memcpy(dst + pos, &acc, 8); const u32 nby = nacc >> 3; pos += nby; pos = pos > lim ? lim : pos; acc >>= (nby << 3); nacc &= 7u; }
+    acc |= (u64)(c2 & mask) << nacc; nacc += tl; WV_FLUSH()
+    acc |= (u64)(c1 & mask) << nacc; nacc += tl; WV_FLUSH()
+    acc |= (u64)1 << nacc; nacc += 1; WV_FLUSH()
+#undef WV_FLUSH
+    return (pos >= lim) ? 0 : (size_t)pos + (nacc > 0);
+}
+
+__global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const u8* const ldsb = (const u8*)lds;
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+
+    u32 hdr = 0;
+    if (a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) return; hdr = a.meta[b].hdrSize; }
+    const u32* const gct = a.ctables + b * a.ctStrideU32;
+    const u32 h0 = gct[0];
+    const u32 tl = h0 & 0xFFFFu, msv = h0 >> 16;
+    if (tl > a.maxTableLog || msv > 255u) { if (lane == 0) a.results[b] = FERR(tableLog_tooLarge); return; }
+    const u8* const src = view_ptr(a.src, b);
+    const size_t n64 = view_size(a.src, b);
+    u8* const dst = a.dst + b * a.dstStride + hdr;
+    const size_t cap = a.dstCapacity - hdr;
+    if (n64 >= ((size_t)1 << 31)) { if (lane == 0) a.results[b] = FERR(srcSize_wrong); return; }
+    const u32 n = (u32)n64;
+    if (n <= 2 || cap <= 8) { if (lane == 0) a.results[b] = 0; return; }    // fse_compress.c:566-568
+
+    // ---- stage the CTable (coalesced): word 0 header, stateTable at byte 4, symbolTT rebased to LDS byte addresses
+    const u32 ttStart = 1 + (tl ? (1u << (tl - 1)) : 1u);
+    const u32 ttAl = (ttStart + 1u) & ~1u;                                  // 8-byte aligned symbolTT copy
+    const u32 words = ttStart + 2 * (msv + 1);
+    for (u32 i = lane; i < words; i += 64) {
+        u32 v = gct[i];
+        if (i >= ttStart) { if (((i - ttStart) & 1u) == 0) v = 2u * v + 4u; lds[i - ttStart + ttAl] = v; }
+        else lds[i] = v;
+    }
+    __syncthreads();
+    const u8* const ttb = ldsb + 4u * ttAl;
+
+    // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains)
+    const u32 m = n - 2;
+    u32 C = (m + 63u) / 64u;
+    C = (C + 1u) & ~1u;                                                     // even: every range starts on chain A
+    const u32 j0 = 2 + lane * C;
+    const u32 j1 = j0 + C < n ? j0 + C : n;
+    const bool mine = j0 < n;                                               // non-empty range
+    const u32 lastLane = (m + C - 1) / C - 1;                               // owner of the final states
+
+    // ---- pass 1: speculated start, bit count, end states
+    u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
+    if (mine) {
+        if (j0 <= 2 + FSE_WV_WARM) {                                        // the warm-up would reach the block end: be exact
+            xa = wv_init_state(ldsb, ttb, src[n - 1]);
+            xb = wv_init_state(ldsb, ttb, src[n - 2]);
+            wv_count(ldsb, ttb, src, n, 2, j0, xa, xb);
+        } else {
+            xa = xb = 1u << tl;                                             // any state will do: it is verified below
+            wv_count(ldsb, ttb, src, n, j0 - FSE_WV_WARM, j0, xa, xb);
+        }
+        start = xa | (xb << 16);
+        bits = wv_count(ldsb, ttb, src, n, j0, j1, xa, xb);
+        end = xa | (xb << 16);
+    }
+    // ---- verification / repair: start[t] must equal end[t-1]; lane 0 (and every lane that ran from the block end) is exact
+    for (;;) {
+        const u32 prevEnd = (u32)__shfl_up((int)end, 1, WAVE);
+        const bool bad = mine && lane > 0 && start != prevEnd;
+        if (!__any(bad)) break;
+        if (bad) {
+            start = prevEnd;
+            xa = start & 0xFFFFu; xb = start >> 16;
+            bits = wv_count(ldsb, ttb, src, n, j0, j1, xa, xb);
+            end = xa | (xb << 16);
+        }
+    }
+
+    // ---- prefix sum of the bit counts
+    u32 incl = bits;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    const u32 excl = incl - bits;
+    const u64 bodyBits = (u32)__shfl((int)incl, 63, WAVE);
+    const u32 fin = (u32)__shfl((int)end, (int)lastLane, WAVE);
+
+    // ---- verdict (BIT_closeCStream, bitstream.h:254-260): total bits incl. the two states and the end mark
+    const u64 totalBits = bodyBits + 2u * tl + 1u;
+    const size_t whole = (size_t)(totalBits >> 3);
+    size_t csize = (whole >= cap - 8) ? 0 : (size_t)((totalBits + 7) >> 3);
+    size_t result = csize;
+    if (a.meta) result = (csize != 0 && (size_t)hdr + csize < n64 - 1) ? (size_t)hdr + csize : 0;   // fse_compress.c:668-676
+    if (result == 0) { if (lane == 0) a.results[b] = 0; return; }
+
+    // ---- pass 2.  The word-wise writer needs every range (but the last) to span at least one byte of output
+    if (__any(mine && lane < lastLane && bits < 8u)) {
+        if (lane == 0) {
+            const size_t cs = wv_serial(ldsb, ttb, src, n, dst, cap, tl);
+            a.results[b] = a.meta ? ((cs != 0 && (size_t)hdr + cs < n64 - 1) ? (size_t)hdr + cs : 0) : cs;
+        }
+        return;
+    }
+    u32 tail = 0;
+    if (mine) {
+        WvSink k; k.dst = dst; k.pos = excl >> 3; k.acc = 0; k.nacc = excl & 7u;
+        xa = start & 0xFFFFu; xb = start >> 16;
+        wv_emit(ldsb, ttb, src, n, j0, j1, xa, xb, k);
+        if (lane == lastLane) {
+            // fse_compress.c:608-609 : CState2 then CState1.  n even -> CState2 is the even-distance chain (:577-580), n odd -> CState1 (:572-576)
+            const u32 fa = fin & 0xFFFFu, fb = fin >> 16;
+            const u32 c2 = (n & 1u) ? fb : fa, c1 = (n & 1u) ? fa : fb;
+            const u32 mask = (1u << tl) - 1u;
+            k.put(c2 & mask, tl); k.spill();
+            k.put(c1 & mask, tl); k.spill();
+            k.put(1u, 1u); k.spill();
+            k.nacc = (k.nacc + 7u) & ~7u;                                   // the last partial byte is this lane's
+        }
+        while (k.nacc >= 8u) { dst[k.pos++] = (u8)k.acc; k.acc >>= 8; k.nacc -= 8u; }
+        tail = (u32)k.acc;                                                  // < 8 bits, belong to the next lane's first byte
+    }
+    const u32 prevTail = (u32)__shfl_up((int)tail, 1, WAVE);
+    if (mine && lane > 0 && (excl & 7u)) {
+        u8* const p = dst + (excl >> 3);
+        const uintptr_t ad = (uintptr_t)p;
+        atomicOr((u32*)(ad & ~(uintptr_t)3), prevTail << (8u * (u32)(ad & 3u)));
+    }
+    if (lane == 0) a.results[b] = result;
+}
+
+hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    const size_t ldsBytes = 4 * (size_t)(2 + (1u << (a.maxTableLog - 1)) + 512 + 2);
+    probe_before(PK_FSE_ENCODE_PAR, s);
+    hipLaunchKernelGGL(k_fse_encode_wave, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a);
+    probe_after(PK_FSE_ENCODE_PAR, s);
+    return hipGetLastError();
+}
