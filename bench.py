@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 BLOCK = 32768
 KERNEL_NAMES = ["k_hist", "k_fse_cprep", "k_fse_encode", "k_fse_dprep", "k_fse_decode",
-                "k_huf_cprep", "k_huf_encode", "k_huf_dprep", "k_huf_decode", "k_fse_encode_par"]
+                "k_huf_cprep", "k_huf_encode", "k_huf_dprep", "k_huf_decode", "k_fse_encode_wave"]
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -106,7 +106,7 @@ def main():
 
         def decode():
             hip.fse_decompress_batch(dst, res, BLOCK, max_log=max(args.table_log, 9), dst=out, results=dres, workspace=ws_d)
-        hot = ("k_fse_encode", "k_fse_encode_par", "k_fse_decode")
+        hot = ("k_fse_encode", "k_fse_encode_wave", "k_fse_decode")
     else:
         ws_c = hip.huf_workspace(nb, False, dev)
         ws_d = hip.huf_workspace(nb, True, dev)

@@ -29,21 +29,21 @@
     {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
         const u32 f2_ = e_.x, dn_ = e_.y;                                                             \
         nb = ((ST) + dn_) >> 16;                                                                      \
-        (ST) = *(const u16*)(ldsb + ((((ST) >> nb) << 1) + f2_));                                     \
+        (ST) = *(const u16*)(lds0 + ((((ST) >> nb) << 1) + f2_));                                     \
     }
 #define WV_STEP_BITS(ST, sym, nb, bits)                                                              \
     {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
         const u32 f2_ = e_.x, dn_ = e_.y;                                                             \
         nb = ((ST) + dn_) >> 16;                                                                      \
         bits = __builtin_amdgcn_ubfe((ST), 0u, nb);                                                   \
-        (ST) = *(const u16*)(ldsb + ((((ST) >> nb) << 1) + f2_));                                     \
+        (ST) = *(const u16*)(lds0 + ((((ST) >> nb) << 1) + f2_));                                     \
     }
 
 DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
 // run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even);
 // returns the number of bits they emit.
-DEV u32 wv_count(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
+DEV u32 wv_count(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
 {
     u32 bits = 0, j = ja;
     if (j + 16 <= jb) {
@@ -51,6 +51,7 @@ DEV u32 wv_count(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u3
         while (j + 16 <= jb) {
             const u32 nj = j + 16;
             const uint4 nxt = wv_load16(src + (n - 16 - (nj + 16 <= jb ? nj : j)));
+            __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one load ahead of its use
             u32 na, nbb;
 #define WV_PAIR(w, hiA, hiB)                                                                         \
             {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u); \
@@ -77,7 +78,7 @@ struct WvSink {
     DEV void spill() { if (nacc >= 32u) { const u32 w = (u32)acc; __builtin_memcpy(dst + pos, &w, 4); pos += 4; acc >>= 32; nacc -= 32u; } }
 };
 
-DEV void wv_emit(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
+DEV void wv_emit(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
 {
     u32 j = ja;
     if (j + 16 <= jb) {
@@ -85,6 +86,7 @@ DEV void wv_emit(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u3
         while (j + 16 <= jb) {
             const u32 nj = j + 16;
             const uint4 nxt = wv_load16(src + (n - 16 - (nj + 16 <= jb ? nj : j)));
+            __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one load ahead of its use
             u32 na, nbb, ba, bb;
 #define WV_PAIR(w, hiA, hiB)                                                                         \
             {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u); \
@@ -104,20 +106,20 @@ DEV void wv_emit(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u32 ja, u3
     }
 }
 
-DEV u32 wv_init_state(const u8* ldsb, const u8* ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
+DEV u32 wv_init_state(const u8* lds0, const u8* ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
 {
     const uint2 e = *(const uint2*)(ttb + 8u * sym);
     const u32 nb = (e.y + (1u << 15)) >> 16;
-    return *(const u16*)(ldsb + (((((nb << 16) - e.y) >> nb) << 1) + e.x));
+    return *(const u16*)(lds0 + (((((nb << 16) - e.y) >> nb) << 1) + e.x));
 }
 
 // the whole block by one lane, byte by byte (lib/fse_compress.c:554-623 as written): used when a lane's share of the
 // output is shorter than one byte, which the word-wise writer above does not handle
-DEV size_t wv_serial(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u8* dst, size_t cap, u32 tl)
+DEV size_t wv_serial(const u8* lds0, const u8* ttb, const u8* src, u32 n, u8* dst, size_t cap, u32 tl)
 {
     const u32 lim = (u32)(cap - 8);
     u64 acc = 0; u32 nacc = 0, pos = 0;
-    u32 xa = wv_init_state(ldsb, ttb, src[n - 1]), xb = wv_init_state(ldsb, ttb, src[n - 2]);
+    u32 xa = wv_init_state(lds0, ttb, src[n - 1]), xb = wv_init_state(lds0, ttb, src[n - 2]);
     for (u32 j = 2; j < n; ++j) {
         const u32 sym = src[n - 1 - j];
         u32 nb, bits;
@@ -137,12 +139,25 @@ DEV size_t wv_serial(const u8* ldsb, const u8* ttb, const u8* src, u32 n, u8* ds
     return (pos >= lim) ? 0 : (size_t)pos + (nacc > 0);
 }
 
-__global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
+#ifdef FSE_ENC_TIMING       // development aid: per-block cycle accounting
+__device__ unsigned long long g_encTiming[4096 * 8];
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_encTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_encTiming), sizeof(g_encTiming)); }
+#define ETIMING(x) x
+#else
+#define ETIMING(x)
+#endif
+
+#define FSE_WV_WAVES 4               // blocks (waves) per workgroup; the waves never synchronise with each other
+__global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArgs a, u32 slotWords)
 {
-    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    ETIMING(unsigned long long T0 = __builtin_readcyclecounter(); unsigned long long T1 = 0; unsigned long long T2 = 0; unsigned long long T3 = 0; unsigned long long T4 = 0; u32 rounds = 0;)
+    extern __shared__ __attribute__((aligned(16))) u32 ldsAll[];
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    u32* const lds = ldsAll + wv * slotWords;
     const u8* const ldsb = (const u8*)lds;
-    const size_t b = blockIdx.x;
-    const u32 lane = threadIdx.x;
+    const u32 ldsOff = wv * slotWords * 4u;                                 // LDS byte address of this wave's slot
+    const size_t b = (size_t)blockIdx.x * FSE_WV_WAVES + wv;
+    if (b >= a.nBlocks) return;
 
     u32 hdr = 0;
     if (a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) return; hdr = a.meta[b].hdrSize; }
@@ -164,11 +179,13 @@ __global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
     const u32 words = ttStart + 2 * (msv + 1);
     for (u32 i = lane; i < words; i += 64) {
         u32 v = gct[i];
-        if (i >= ttStart) { if (((i - ttStart) & 1u) == 0) v = 2u * v + 4u; lds[i - ttStart + ttAl] = v; }
+        if (i >= ttStart) { if (((i - ttStart) & 1u) == 0) v = 2u * v + 4u + ldsOff; lds[i - ttStart + ttAl] = v; }
         else lds[i] = v;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // the slot is private to this wave: LDS is in order per wave
     const u8* const ttb = ldsb + 4u * ttAl;
+    const u8* const lds0 = (const u8*)ldsAll;                              // symbolTT holds absolute LDS byte addresses
+    ETIMING(T1 = __builtin_readcyclecounter();)
 
     // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains)
     const u32 m = n - 2;
@@ -183,17 +200,18 @@ __global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
     u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
     if (mine) {
         if (j0 <= 2 + FSE_WV_WARM) {                                        // the warm-up would reach the block end: be exact
-            xa = wv_init_state(ldsb, ttb, src[n - 1]);
-            xb = wv_init_state(ldsb, ttb, src[n - 2]);
-            wv_count(ldsb, ttb, src, n, 2, j0, xa, xb);
+            xa = wv_init_state(lds0, ttb, src[n - 1]);
+            xb = wv_init_state(lds0, ttb, src[n - 2]);
+            wv_count(lds0, ttb, src, n, 2, j0, xa, xb);
         } else {
             xa = xb = 1u << tl;                                             // any state will do: it is verified below
-            wv_count(ldsb, ttb, src, n, j0 - FSE_WV_WARM, j0, xa, xb);
+            wv_count(lds0, ttb, src, n, j0 - FSE_WV_WARM, j0, xa, xb);
         }
         start = xa | (xb << 16);
-        bits = wv_count(ldsb, ttb, src, n, j0, j1, xa, xb);
+        bits = wv_count(lds0, ttb, src, n, j0, j1, xa, xb);
         end = xa | (xb << 16);
     }
+    ETIMING(T2 = __builtin_readcyclecounter();)
     // ---- verification / repair: start[t] must equal end[t-1]; lane 0 (and every lane that ran from the block end) is exact
     for (;;) {
         const u32 prevEnd = (u32)__shfl_up((int)end, 1, WAVE);
@@ -202,10 +220,12 @@ __global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
         if (bad) {
             start = prevEnd;
             xa = start & 0xFFFFu; xb = start >> 16;
-            bits = wv_count(ldsb, ttb, src, n, j0, j1, xa, xb);
+            bits = wv_count(lds0, ttb, src, n, j0, j1, xa, xb);
             end = xa | (xb << 16);
         }
+        ETIMING(++rounds;)
     }
+    ETIMING(T3 = __builtin_readcyclecounter();)
 
     // ---- prefix sum of the bit counts
     u32 incl = bits;
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
     // ---- pass 2.  The word-wise writer needs every range (but the last) to span at least one byte of output
     if (__any(mine && lane < lastLane && bits < 8u)) {
         if (lane == 0) {
-            const size_t cs = wv_serial(ldsb, ttb, src, n, dst, cap, tl);
+            const size_t cs = wv_serial(lds0, ttb, src, n, dst, cap, tl);
             a.results[b] = a.meta ? ((cs != 0 && (size_t)hdr + cs < n64 - 1) ? (size_t)hdr + cs : 0) : cs;
         }
         return;
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
     if (mine) {
         WvSink k; k.dst = dst; k.pos = excl >> 3; k.acc = 0; k.nacc = excl & 7u;
         xa = start & 0xFFFFu; xb = start >> 16;
-        wv_emit(ldsb, ttb, src, n, j0, j1, xa, xb, k);
+        wv_emit(lds0, ttb, src, n, j0, j1, xa, xb, k);
         if (lane == lastLane) {
             // fse_compress.c:608-609 : CState2 then CState1.  n even -> CState2 is the even-distance chain (:577-580), n odd -> CState1 (:572-576)
             const u32 fa = fin & 0xFFFFu, fb = fin >> 16;
@@ -255,15 +275,17 @@ __global__ __launch_bounds__(64) void k_fse_encode_wave(FseEncArgs a)
         const uintptr_t ad = (uintptr_t)p;
         atomicOr((u32*)(ad & ~(uintptr_t)3), prevTail << (8u * (u32)(ad & 3u)));
     }
+    ETIMING(T4 = __builtin_readcyclecounter(); if (lane == 0 && b < 4096) { unsigned long long* t = g_encTiming + 8 * b; t[0] = T1 - T0; t[1] = T2 - T1; t[2] = T3 - T2; t[3] = T4 - T3; t[4] = rounds; })
     if (lane == 0) a.results[b] = result;
 }
 
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const size_t ldsBytes = 4 * (size_t)(2 + (1u << (a.maxTableLog - 1)) + 512 + 2);
-    probe_before(PK_FSE_ENCODE_PAR, s);
-    hipLaunchKernelGGL(k_fse_encode_wave, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a);
-    probe_after(PK_FSE_ENCODE_PAR, s);
+    const u32 slotWords = (2 + (1u << (a.maxTableLog - 1)) + 512 + 2 + 3) & ~3u;
+    const size_t ldsBytes = 4 * (size_t)slotWords * FSE_WV_WAVES;
+    probe_before(PK_FSE_ENCODE_WAVE, s);
+    hipLaunchKernelGGL(k_fse_encode_wave, dim3((unsigned)((a.nBlocks + FSE_WV_WAVES - 1) / FSE_WV_WAVES)), dim3(64 * FSE_WV_WAVES), ldsBytes, s, a, slotWords);
+    probe_after(PK_FSE_ENCODE_WAVE, s);
     return hipGetLastError();
 }

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_fse_cnorm(FseCPrepArgs a)
         u8* const dst = a.dst + b * a.dstStride;
         const size_t h = fse_write_ncount(dst, a.dstCapacity, norm, maxSV, tl);   // :662
         if (is_err(h)) { result = h; break; }
-        // Encoder choice (fse_encode_par.hip): the block-parallel kernel relies on two encoder states fed the same symbols
+        // Encoder choice (fse_encode_wave.hip): the wave-per-block kernel relies on two encoder states fed the same symbols
         // merging quickly; per step that happens with probability ~ sum_s p_s / norm_s = present / tableSize.
         u32 present = 0;
         for (u32 s = 0; s <= maxSV; ++s) present += norm[s] != 0;

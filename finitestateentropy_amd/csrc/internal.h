@@ -56,9 +56,8 @@ enum { FSE_ENC_PAR = 1, FSE_ENC_LANE = 2 };
 __host__ __device__ inline bool fse_enc_skip(unsigned state, unsigned onlyState) { return state == 0 || (onlyState != 0 && state != onlyState); }
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
 size_t fse_encode_blocks_per_round(unsigned maxTableLog);
-hipError_t launch_fse_encode_par(FseEncArgs a, hipStream_t s);   // block-parallel variant (one workgroup per block)
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s);  // block-parallel variant (one wave per block, streaming I/O)
-// picks the block-parallel kernel for uniformly sized blocks of >= 2 KiB, the lane-per-block kernel otherwise (both exact)
+// picks the wave-per-block kernel for uniformly sized blocks of >= 2 KiB, the lane-per-block kernel otherwise (both exact)
 // With prepare-kernel metadata the choice is per block (k_fse_cprep marks slowly-mixing tables FSE_ENC_LANE): both kernels
 // are launched and each one skips the other's blocks.
 inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
@@ -161,7 +160,7 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
 hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, hipStream_t s);
 
 // ---- kernel timing probe (HIP events on the launch stream; used by bench.py for the live roofline figure) ----
-enum { PK_HIST = 0, PK_FSE_CPREP, PK_FSE_ENCODE, PK_FSE_DPREP, PK_FSE_DECODE, PK_HUF_CPREP, PK_HUF_ENCODE, PK_HUF_DPREP, PK_HUF_DECODE, PK_FSE_ENCODE_PAR, PK_COUNT };
+enum { PK_HIST = 0, PK_FSE_CPREP, PK_FSE_ENCODE, PK_FSE_DPREP, PK_FSE_DECODE, PK_HUF_CPREP, PK_HUF_ENCODE, PK_HUF_DPREP, PK_HUF_DECODE, PK_FSE_ENCODE_WAVE, PK_COUNT };
 void probe_before(int kernelId, hipStream_t s);
 void probe_after(int kernelId, hipStream_t s);
 

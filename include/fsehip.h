@@ -176,7 +176,7 @@ FSEHIP_API int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t block
 /* Kernel timing probe for benchmarks: between probe_begin and probe_collect every kernel launch of the library is
  * bracketed by HIP events on its own stream.  probe_collect synchronises and returns, per kernel id
  * (0 hist, 1 fse_cprep, 2 fse_encode [lane per block], 3 fse_dprep, 4 fse_decode, 5 huf_cprep, 6 huf_encode, 7 huf_dprep,
- * 8 huf_decode, 9 fse_encode_par [workgroup per block]), the summed duration in milliseconds and the number of launches.  Arrays hold 16 entries. */
+ * 8 huf_decode, 9 fse_encode_wave [wave per block]), the summed duration in milliseconds and the number of launches.  Arrays hold 16 entries. */
 FSEHIP_API int FSEHIP_probe_begin(void);
 FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
 
