@@ -41,36 +41,6 @@
 
 DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
-// run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even);
-// returns the number of bits they emit.
-DEV u32 wv_count(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
-{
-    u32 bits = 0, j = ja;
-    if (j + 16 <= jb) {
-        uint4 cur = wv_load16(src + (n - 16 - j));
-        while (j + 16 <= jb) {
-            const u32 nj = j + 16;
-            const uint4 nxt = wv_load16(src + (n - 16 - (nj + 16 <= jb ? nj : j)));
-            __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one load ahead of its use
-            u32 na, nbb;
-#define WV_PAIR(w, hiA, hiB)                                                                         \
-            {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u); \
-                WV_STEP(xa, sa, na) WV_STEP(xb, sb, nbb) bits += na + nbb; }
-            WV_PAIR(cur.w, 24u, 16u) WV_PAIR(cur.w, 8u, 0u) WV_PAIR(cur.z, 24u, 16u) WV_PAIR(cur.z, 8u, 0u)
-            WV_PAIR(cur.y, 24u, 16u) WV_PAIR(cur.y, 8u, 0u) WV_PAIR(cur.x, 24u, 16u) WV_PAIR(cur.x, 8u, 0u)
-#undef WV_PAIR
-            cur = nxt; j = nj;
-        }
-    }
-    for (; j < jb; ++j) {
-        const u32 sym = src[n - 1 - j];
-        u32 nb;
-        if (j & 1u) { WV_STEP(xb, sym, nb) } else { WV_STEP(xa, sym, nb) }
-        bits += nb;
-    }
-    return bits;
-}
-
 // bit sink of one lane: bits are appended LSB-first; whole 32-bit words are stored as they complete
 struct WvSink {
     u8* dst; u32 pos; u64 acc; u32 nacc;
@@ -78,33 +48,52 @@ struct WvSink {
     DEV void spill() { if (nacc >= 32u) { const u32 w = (u32)acc; __builtin_memcpy(dst + pos, &w, 4); pos += 4; acc >>= 32; nacc -= 32u; } }
 };
 
-DEV void wv_emit(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
+// Run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even).  Returns the
+// number of bits they emit; with EMIT the bits also go to the sink.  The source is streamed downwards: 64 bytes (four
+// 16-byte loads of one 64-byte segment, so the segment is fetched from memory once) one segment ahead of its use.
+template <bool EMIT>
+DEV u32 wv_run(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink* k)
 {
-    u32 j = ja;
-    if (j + 16 <= jb) {
-        uint4 cur = wv_load16(src + (n - 16 - j));
-        while (j + 16 <= jb) {
-            const u32 nj = j + 16;
-            const uint4 nxt = wv_load16(src + (n - 16 - (nj + 16 <= jb ? nj : j)));
-            __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one load ahead of its use
-            u32 na, nbb, ba, bb;
+    u32 bits = 0, j = ja;
+    u32 na, nbb, ba, bb;
 #define WV_PAIR(w, hiA, hiB)                                                                         \
-            {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u); \
-                WV_STEP_BITS(xa, sa, na, ba) WV_STEP_BITS(xb, sb, nbb, bb)                             \
-                k.put(ba | (bb << na), na + nbb); k.spill(); }
-            WV_PAIR(cur.w, 24u, 16u) WV_PAIR(cur.w, 8u, 0u) WV_PAIR(cur.z, 24u, 16u) WV_PAIR(cur.z, 8u, 0u)
-            WV_PAIR(cur.y, 24u, 16u) WV_PAIR(cur.y, 8u, 0u) WV_PAIR(cur.x, 24u, 16u) WV_PAIR(cur.x, 8u, 0u)
-#undef WV_PAIR
-            cur = nxt; j = nj;
+    {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u);     \
+        if (EMIT) { WV_STEP_BITS(xa, sa, na, ba) WV_STEP_BITS(xb, sb, nbb, bb) k->put(ba | (bb << na), na + nbb); k->spill(); } \
+        else { WV_STEP(xa, sa, na) WV_STEP(xb, sb, nbb) bits += na + nbb; } }
+#define WV_QUAD(v)                                                                                   \
+    WV_PAIR(v.w, 24u, 16u) WV_PAIR(v.w, 8u, 0u) WV_PAIR(v.z, 24u, 16u) WV_PAIR(v.z, 8u, 0u)           \
+    WV_PAIR(v.y, 24u, 16u) WV_PAIR(v.y, 8u, 0u) WV_PAIR(v.x, 24u, 16u) WV_PAIR(v.x, 8u, 0u)
+    if (j + 64 <= jb) {
+        const u8* p = src + (n - 64 - j);
+        uint4 c0 = wv_load16(p), c1 = wv_load16(p + 16), c2 = wv_load16(p + 32), c3 = wv_load16(p + 48);
+        while (j + 64 <= jb) {
+            const u32 nj = j + 64;
+            const u8* const q = src + (n - 64 - (nj + 64 <= jb ? nj : j));
+            const uint4 n0 = wv_load16(q), n1 = wv_load16(q + 16), n2 = wv_load16(q + 32), n3 = wv_load16(q + 48);
+            __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one segment ahead of its use
+            WV_QUAD(c3) WV_QUAD(c2) WV_QUAD(c1) WV_QUAD(c0)
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; j = nj;
         }
     }
+    while (j + 16 <= jb) {
+        const uint4 c = wv_load16(src + (n - 16 - j));
+        WV_QUAD(c)
+        j += 16;
+    }
+#undef WV_QUAD
+#undef WV_PAIR
     for (; j < jb; ++j) {
         const u32 sym = src[n - 1 - j];
-        u32 nb, bits;
-        if (j & 1u) { WV_STEP_BITS(xb, sym, nb, bits) } else { WV_STEP_BITS(xa, sym, nb, bits) }
-        k.put(bits, nb); k.spill();
+        u32 nb, b1;
+        if (j & 1u) { WV_STEP_BITS(xb, sym, nb, b1) } else { WV_STEP_BITS(xa, sym, nb, b1) }
+        if (EMIT) { k->put(b1, nb); k->spill(); } else bits += nb;
     }
+    return bits;
 }
+DEV u32 wv_count(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
+{ return wv_run<false>(lds0, ttb, src, n, ja, jb, xa, xb, nullptr); }
+DEV void wv_emit(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
+{ wv_run<true>(lds0, ttb, src, n, ja, jb, xa, xb, &k); }
 
 DEV u32 wv_init_state(const u8* lds0, const u8* ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
 {
@@ -187,14 +176,18 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     const u8* const lds0 = (const u8*)ldsAll;                              // symbolTT holds absolute LDS byte addresses
     ETIMING(T1 = __builtin_readcyclecounter();)
 
-    // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains)
+    // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains).  Lane t owns
+    //      [bound(t), bound(t+1)); the boundaries are even (every range starts on chain A) and, for blocks of >= 4 KiB,
+    //      shifted so that the ranges above lane 0's end on 64-byte aligned source addresses (whole segments per load group)
     const u32 m = n - 2;
     u32 C = (m + 63u) / 64u;
-    C = (C + 1u) & ~1u;                                                     // even: every range starts on chain A
-    const u32 j0 = 2 + lane * C;
-    const u32 j1 = j0 + C < n ? j0 + C : n;
+    C = m >= 4096u ? (C + 63u) & ~63u : (C + 1u) & ~1u;
+    const u32 delta = m >= 4096u ? (u32)((0 - ((uintptr_t)src + n - 2u)) & 62u) : 0u;   // < 64 <= C, even
+    const u32 lo0 = lane ? 2 + lane * C - delta : 2u, hi0 = 2 + (lane + 1) * C - delta;
+    const u32 j0 = lo0 < n ? lo0 : n;
+    const u32 j1 = (lane == 63u || hi0 > n) ? n : hi0;
     const bool mine = j0 < n;                                               // non-empty range
-    const u32 lastLane = (m + C - 1) / C - 1;                               // owner of the final states
+    const u32 lastLane = (m + delta - 1) / C < 63u ? (m + delta - 1) / C : 63u;   // owner of the final states
 
     // ---- pass 1: speculated start, bit count, end states
     u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
