@@ -7,7 +7,7 @@
 //
 //   One 64-lane wave per block; only the CTable lives in LDS, so many blocks are resident per CU.  In emission
 //   order (last source byte first) lane t owns a contiguous range of symbols.
-//   Pass 1: the lane warms both chains up over the FSE_WV_WARM symbols in front of its range starting from an
+//   Pass 1: the lane warms both chains up over `warm` symbols in front of its range starting from an
 //   arbitrary state, remembers the states it arrives with (its speculated start), then runs its range counting
 //   bits and remembers the states it ends with.  Verification: lane t's speculated start must equal lane t-1's
 //   end; lane 0 starts from the exact FSE_initCState2 states, so if every link matches, every start is exact by
@@ -23,7 +23,11 @@
 //   Source bytes are streamed per lane, 16 per (unaligned) load, one load ahead.
 #include "internal.h"
 
-#define FSE_WV_WARM 1024            // warm-up symbols (half per chain) in front of every range
+// Warm-up symbols (half per chain) in front of every range.  Two states fed the same symbols merge with probability
+// ~ present/tableSize per step (sum_s p_s / norm_s), so the warm-up is sized as a multiple of tableSize/present.
+#define FSE_WV_WARM_FACTOR 26u
+#define FSE_WV_WARM_MIN 128u
+#define FSE_WV_WARM_MAX 4096u
 
 #define WV_STEP(ST, sym, nb)                                                                         \
     {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
@@ -41,11 +45,42 @@
 
 DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
-// bit sink of one lane: bits are appended LSB-first; whole 32-bit words are stored as they complete
+// Bit sink of one lane.  Bits are appended LSB-first; completed 32-bit words go to a small per-lane LDS ring that is
+// indexed by the low bits of the word's global address, and every time a WV_LINE-byte aligned piece of the output is
+// complete it is written to global memory with 16-byte stores (whole sectors: the compressed stream leaves the chip
+// once).  The first bytes of a lane (up to the first line boundary) and its last ones go out bytewise / wordwise.
+#define WV_LINE 32u
+#define WV_RING (2u * WV_LINE)
 struct WvSink {
-    u8* dst; u32 pos; u64 acc; u32 nacc;
+    u8* dstAl;            // destination rounded down to WV_RING bytes
+    u32* ring;            // this lane's LDS ring
+    u32 woff;             // offset from dstAl of the next 32-bit word (multiple of 4)
+    u32 done;             // offset from dstAl up to which this lane's bytes are in global memory
+    u64 acc; u32 nacc;
     DEV void put(u32 v, u32 nb) { acc |= (u64)v << nacc; nacc += nb; }
-    DEV void spill() { if (nacc >= 32u) { const u32 w = (u32)acc; __builtin_memcpy(dst + pos, &w, 4); pos += 4; acc >>= 32; nacc -= 32u; } }
+    DEV void spill() { if (nacc >= 32u) { ring[(woff & (WV_RING - 1)) >> 2] = (u32)acc; woff += 4; acc >>= 32; nacc -= 32u; } }
+    DEV void copy_out(u32 upTo)                                         // bytes [done, upTo), any alignment
+    {
+        const u8* const rb = (const u8*)ring;
+        u32 o = done;
+        while (o < upTo) {
+            if (((o & 3u) == 0) && o + 4 <= upTo) { const u32 w = ring[(o & (WV_RING - 1)) >> 2]; __builtin_memcpy(dstAl + o, &w, 4); o += 4; }
+            else { dstAl[o] = rb[o & (WV_RING - 1)]; ++o; }
+        }
+        done = upTo;
+    }
+    DEV void line()                                                     // once per 16 symbols (<= 24 bytes): at most one line completes
+    {
+        const u32 L = done & ~(WV_LINE - 1);
+        if (woff >= L + WV_LINE) {
+            if (done == L) {
+                const uint4* const r4 = (const uint4*)(ring + ((L & (WV_RING - 1)) >> 2));
+#pragma unroll
+                for (u32 q = 0; q < WV_LINE / 16; ++q) { const uint4 v = r4[q]; __builtin_memcpy(dstAl + L + 16 * q, &v, 16); }
+                done = L + WV_LINE;
+            } else copy_out(L + WV_LINE);
+        }
+    }
 };
 
 // Run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even).  Returns the
@@ -62,7 +97,8 @@ DEV u32 wv_run(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 
         else { WV_STEP(xa, sa, na) WV_STEP(xb, sb, nbb) bits += na + nbb; } }
 #define WV_QUAD(v)                                                                                   \
     WV_PAIR(v.w, 24u, 16u) WV_PAIR(v.w, 8u, 0u) WV_PAIR(v.z, 24u, 16u) WV_PAIR(v.z, 8u, 0u)           \
-    WV_PAIR(v.y, 24u, 16u) WV_PAIR(v.y, 8u, 0u) WV_PAIR(v.x, 24u, 16u) WV_PAIR(v.x, 8u, 0u)
+    WV_PAIR(v.y, 24u, 16u) WV_PAIR(v.y, 8u, 0u) WV_PAIR(v.x, 24u, 16u) WV_PAIR(v.x, 8u, 0u)          \
+    if (EMIT) k->line();
     if (j + 64 <= jb) {
         const u8* p = src + (n - 64 - j);
         uint4 c0 = wv_load16(p), c1 = wv_load16(p + 16), c2 = wv_load16(p + 32), c3 = wv_load16(p + 48);
@@ -136,8 +172,8 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_encTiming(uns
 #define ETIMING(x)
 #endif
 
-#define FSE_WV_WAVES 4               // blocks (waves) per workgroup; the waves never synchronise with each other
-__global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArgs a, u32 slotWords)
+#define FSE_WV_WAVES 1               // blocks (waves) per workgroup; the waves never synchronise with each other
+__global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArgs a, u32 slotWords, u32 tableWords)
 {
     ETIMING(unsigned long long T0 = __builtin_readcyclecounter(); unsigned long long T1 = 0; unsigned long long T2 = 0; unsigned long long T3 = 0; unsigned long long T4 = 0; u32 rounds = 0;)
     extern __shared__ __attribute__((aligned(16))) u32 ldsAll[];
@@ -166,14 +202,25 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     const u32 ttStart = 1 + (tl ? (1u << (tl - 1)) : 1u);
     const u32 ttAl = (ttStart + 1u) & ~1u;                                  // 8-byte aligned symbolTT copy
     const u32 words = ttStart + 2 * (msv + 1);
+    u32 presentLane = 0;
     for (u32 i = lane; i < words; i += 64) {
         u32 v = gct[i];
-        if (i >= ttStart) { if (((i - ttStart) & 1u) == 0) v = 2u * v + 4u + ldsOff; lds[i - ttStart + ttAl] = v; }
-        else lds[i] = v;
+        if (i >= ttStart) {
+            if (((i - ttStart) & 1u) == 0) v = 2u * v + 4u + ldsOff;
+            else presentLane += v != ((tl + 1) << 16) - (1u << tl);           // deltaNbBits of a symbol that does not occur (fse_compress.c:143)
+            lds[i - ttStart + ttAl] = v;
+        } else lds[i] = v;
     }
+    u32 present = presentLane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) present += (u32)__shfl_xor((int)present, off, WAVE);
+    u32 warm = (FSE_WV_WARM_FACTOR << tl) / (present ? present : 1u);
+    warm = (warm + 63u) & ~63u;
+    warm = warm < FSE_WV_WARM_MIN ? FSE_WV_WARM_MIN : (warm > FSE_WV_WARM_MAX ? FSE_WV_WARM_MAX : warm);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // the slot is private to this wave: LDS is in order per wave
     const u8* const ttb = ldsb + 4u * ttAl;
     const u8* const lds0 = (const u8*)ldsAll;                              // symbolTT holds absolute LDS byte addresses
+    u32* const ringBase = lds + tableWords;                                // 64 output rings behind the table
     ETIMING(T1 = __builtin_readcyclecounter();)
 
     // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains).  Lane t owns
@@ -192,13 +239,13 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     // ---- pass 1: speculated start, bit count, end states
     u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
     if (mine) {
-        if (j0 <= 2 + FSE_WV_WARM) {                                        // the warm-up would reach the block end: be exact
+        if (j0 <= 2 + warm) {                                        // the warm-up would reach the block end: be exact
             xa = wv_init_state(lds0, ttb, src[n - 1]);
             xb = wv_init_state(lds0, ttb, src[n - 2]);
             wv_count(lds0, ttb, src, n, 2, j0, xa, xb);
         } else {
             xa = xb = 1u << tl;                                             // any state will do: it is verified below
-            wv_count(lds0, ttb, src, n, j0 - FSE_WV_WARM, j0, xa, xb);
+            wv_count(lds0, ttb, src, n, j0 - warm, j0, xa, xb);
         }
         start = xa | (xb << 16);
         bits = wv_count(lds0, ttb, src, n, j0, j1, xa, xb);
@@ -246,7 +293,11 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     }
     u32 tail = 0;
     if (mine) {
-        WvSink k; k.dst = dst; k.pos = excl >> 3; k.acc = 0; k.nacc = excl & 7u;
+        WvSink k;
+        const u32 lead = (u32)((uintptr_t)dst & (WV_RING - 1));
+        const u32 off0 = lead + (excl >> 3);                                // my first byte, as an offset from dstAl
+        k.dstAl = dst - lead; k.ring = ringBase + lane * (WV_RING / 4);
+        k.woff = off0 & ~3u; k.done = off0; k.acc = 0; k.nacc = 8u * (off0 & 3u) + (excl & 7u);
         xa = start & 0xFFFFu; xb = start >> 16;
         wv_emit(lds0, ttb, src, n, j0, j1, xa, xb, k);
         if (lane == lastLane) {
@@ -259,8 +310,9 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
             k.put(1u, 1u); k.spill();
             k.nacc = (k.nacc + 7u) & ~7u;                                   // the last partial byte is this lane's
         }
-        while (k.nacc >= 8u) { dst[k.pos++] = (u8)k.acc; k.acc >>= 8; k.nacc -= 8u; }
-        tail = (u32)k.acc;                                                  // < 8 bits, belong to the next lane's first byte
+        k.ring[(k.woff & (WV_RING - 1)) >> 2] = (u32)k.acc;                 // < 32 bits left
+        k.copy_out(k.woff + (k.nacc >> 3));                                 // every complete byte
+        tail = (u32)(k.acc >> (k.nacc & ~7u));                              // < 8 bits, belong to the next lane's first byte
     }
     const u32 prevTail = (u32)__shfl_up((int)tail, 1, WAVE);
     if (mine && lane > 0 && (excl & 7u)) {
@@ -275,10 +327,11 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const u32 slotWords = (2 + (1u << (a.maxTableLog - 1)) + 512 + 2 + 3) & ~3u;
+    const u32 tableWords = (2 + (1u << (a.maxTableLog - 1)) + 512 + 2 + 31) & ~31u;    // rings start 128-byte aligned
+    const u32 slotWords = tableWords + 64 * (WV_RING / 4);
     const size_t ldsBytes = 4 * (size_t)slotWords * FSE_WV_WAVES;
     probe_before(PK_FSE_ENCODE_WAVE, s);
-    hipLaunchKernelGGL(k_fse_encode_wave, dim3((unsigned)((a.nBlocks + FSE_WV_WAVES - 1) / FSE_WV_WAVES)), dim3(64 * FSE_WV_WAVES), ldsBytes, s, a, slotWords);
+    hipLaunchKernelGGL(k_fse_encode_wave, dim3((unsigned)((a.nBlocks + FSE_WV_WAVES - 1) / FSE_WV_WAVES)), dim3(64 * FSE_WV_WAVES), ldsBytes, s, a, slotWords, tableWords);
     probe_after(PK_FSE_ENCODE_WAVE, s);
     return hipGetLastError();
 }
