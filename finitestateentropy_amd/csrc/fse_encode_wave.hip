@@ -285,6 +285,10 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
 
     // ---- pass 2.  The word-wise writer needs every range (but the last) to span at least one byte of output
     if (__any(mine && lane < lastLane && bits < 8u)) {
+        if (a.meta && a.onlyState == FSE_ENC_PAR) {                         // the lane-per-block kernel runs right after this one
+            if (lane == 0) const_cast<FseMeta*>(a.meta)[b].state = FSE_ENC_LANE;
+            return;
+        }
         if (lane == 0) {
             const size_t cs = wv_serial(lds0, ttb, src, n, dst, cap, tl);
             a.results[b] = a.meta ? ((cs != 0 && (size_t)hdr + cs < n64 - 1) ? (size_t)hdr + cs : 0) : cs;

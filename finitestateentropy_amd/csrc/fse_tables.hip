@@ -43,11 +43,12 @@ __global__ __launch_bounds__(64) void k_fse_cnorm(FseCPrepArgs a)
         u8* const dst = a.dst + b * a.dstStride;
         const size_t h = fse_write_ncount(dst, a.dstCapacity, norm, maxSV, tl);   // :662
         if (is_err(h)) { result = h; break; }
-        // Encoder choice (fse_encode_wave.hip): the wave-per-block kernel relies on two encoder states fed the same symbols
-        // merging quickly; per step that happens with probability ~ sum_s p_s / norm_s = present / tableSize.
-        u32 present = 0;
-        for (u32 s = 0; s <= maxSV; ++s) present += norm[s] != 0;
-        m.state = (present * 40u >= (1u << tl)) ? FSE_ENC_PAR : FSE_ENC_LANE;
+        // Encoder choice.  The wave-per-block kernel (fse_encode_wave.hip) is the default; it needs every lane's share of
+        // the output to span at least one byte, which fails when one symbol takes (almost) the whole table: those blocks
+        // go to the lane-per-block kernel.  (The wave kernel re-checks exactly and hands further blocks over at run time.)
+        int top1 = 0;
+        for (u32 s = 0; s <= maxSV; ++s) top1 = norm[s] > top1 ? norm[s] : top1;
+        m.state = ((u32)top1 * 64u > (63u << tl)) ? FSE_ENC_LANE : FSE_ENC_PAR;
         m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
     } while (0);
     a.meta[b] = m;
