@@ -203,7 +203,7 @@ static FseCWs fse_cws(unsigned tableLog)
     return w;
 }
 #define WS_SLACK 2048
-#define WS_MAX_CHUNK 24576
+#define WS_MAX_CHUNK 131072          // blocks per pass over the workspace (tables of 131072 blocks: 0.8 GiB)
 // largest chunk <= limit that is a whole number of device-filling rounds of the hot-loop kernel (no ragged last wave of workgroups)
 static size_t round_chunk(size_t limit, size_t perRound)
 {
