@@ -389,6 +389,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     __syncthreads();
     if (wave >= 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G); return; }
 
+    __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + ringOff);
     const u8* const myIn = ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + inOff;
     TIMING(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
