@@ -55,35 +55,47 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decTiming(uns
 #endif
 struct BulkState { u32 s1, s2, q, bq; };
 
-#define FSE_BULK_SYM(c, state, t, nb)                                                     \
-    {   nb = (c) >> 12;                                                                   \
-        const u32 bits_ = __builtin_amdgcn_ubfe((t), 32u - nb, nb);                       \
-        state = ((c) & 0xFFFu) | bits_; }
+// One symbol of the bulk loop.  The decoder lane keeps its two states as LDS byte addresses of their table cells.
+//   FAST (maxTableLog <= 11): cell = 2*newState (12 bits) | nbBits << 12 and the tables sit on table-size aligned LDS
+//   addresses, so the next address is (cell & 0xFFF | tableBase) + 2*bits: one and_or off the dependent chain, one
+//   shift-add on it.   Otherwise: cell = newState | nbBits << 12, next address = ((cell & 0xFFF | bits) << 1) + tableBase.
+typedef const __attribute__((address_space(3))) u16* lds_u16_ptr;
+typedef const __attribute__((address_space(3))) u32* lds_u32_ptr;
+DEV u32 lds_cell(u32 addr) { return *(lds_u16_ptr)(uintptr_t)addr; }   // absolute LDS byte address -> table cell
+
+template <bool FAST>
+DEV void fse_bulk_sym(u32 c, u32& sA, u32 t, u32& nb, u32 tabOff)
+{
+    nb = c >> 12;
+    const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nb, nb);
+    if (FAST) sA = (bits << 1) + ((c & 0xFFFu) | tabOff);
+    else      sA = ((((c & 0xFFFu) | bits)) << 1) + tabOff;
+}
 
 // One phase = FSE_CHECK_EVERY iterations for one lane, registers + LDS only.
-template <bool NB0>
-DEV void fse_bulk_phase(BulkState& b, const u16* A, const u8* myIn, uint2* ring)
+template <bool NB0, bool FAST>
+DEV void fse_bulk_phase(BulkState& b, u32 tabOff, u32 myIn, uint2* ring)
 {
     u32 s1 = b.s1, s2 = b.s2, q = b.q, bq = b.bq;
 #pragma unroll 2
     for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
-        const u32 c1 = A[s1], c2 = A[s2];
-        const u32* const wp = (const u32*)(myIn + (q & (FSE_IN_RING - 4)));
+        const u32 c1 = lds_cell(s1), c2 = lds_cell(s2);
+        const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (q & (FSE_IN_RING - 4)));
         const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
         const u32 thi = __builtin_amdgcn_alignbit(d2, d1, bq), tlo = __builtin_amdgcn_alignbit(d1, d0, bq);
         uint2 rec;
-        rec.x = __builtin_amdgcn_perm(s2, s1, 0x05040100u);      // s1 | s2 << 16
+        rec.x = __builtin_amdgcn_perm(s2, s1, 0x05040100u);      // low 16 bits of both cell addresses
         u32 nb1, nb2, nb3, nb4;
-        FSE_BULK_SYM(c1, s1, thi, nb1)
-        const u32 c3 = A[s1];
-        FSE_BULK_SYM(c2, s2, thi << nb1, nb2)
-        const u32 c4 = A[s2];
+        fse_bulk_sym<FAST>(c1, s1, thi, nb1, tabOff);
+        const u32 c3 = lds_cell(s1);
+        fse_bulk_sym<FAST>(c2, s2, thi << nb1, nb2, tabOff);
+        const u32 c4 = lds_cell(s2);
         const u32 s12 = nb1 + nb2;
         u32 t3 = __builtin_amdgcn_alignbit(thi, tlo, 32u - s12);
         if (NB0) t3 = s12 ? t3 : thi;
         rec.y = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
-        FSE_BULK_SYM(c3, s1, t3, nb3)
-        FSE_BULK_SYM(c4, s2, t3 << nb3, nb4)
+        fse_bulk_sym<FAST>(c3, s1, t3, nb3, tabOff);
+        fse_bulk_sym<FAST>(c4, s2, t3 << nb3, nb4, tabOff);
         const int left = (int)bq - (int)(s12 + nb3 + nb4);       // unread bits of dword dp after this iteration (>= -48)
         q += (u32)((left >> 5) << 2);                            // arithmetic shift: 0, -1 or -2 dwords
         bq = (u32)left & 31u;
@@ -115,7 +127,7 @@ DEV void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, _
 //      wave spends its cycles on the dependent chains only.  Each of the FSE_SRV_WAVES service waves looks after
 //      FSE_SRV_G of the workgroup's blocks; everything here is wave-cooperative and coalesced:
 //        * input : 256-byte chunks, one 4-byte load per lane, written below the bytes the decoder is reading;
-//        * output: record i of a block = the 4 states iteration i decoded FROM; symbol = symbolOf[state], gathered
+//        * output: record i of a block = the 4 states (as cell addresses) iteration i decoded FROM; symbol = symbolOf[state], gathered
 //                  from the L2-resident table in global memory (byte table from k_fse_dbuild, or the symbol bytes of the
 //                  reference-layout cells: stride 1 << symShift), packed, stored as one 256-byte row per 64 records.
 #define FSE_SRV_WAVES 4
@@ -204,8 +216,10 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, l, WAVE);
             if ((u32)lane < cnt) {
                 const uint2 rec = ((const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
-                yq[l][0] = tg[(rec.x & 0xFFFFu) << symShift]; yq[l][1] = tg[(rec.x >> 16) << symShift];
-                yq[l][2] = tg[(rec.y & 0xFFFFu) << symShift]; yq[l][3] = tg[(rec.y >> 16) << symShift];
+                // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+maxTableLog)
+                const u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.maxTableLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.maxTableLog);
+                const u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.maxTableLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.maxTableLog);
+                yq[l][0] = tg[x0 << symShift]; yq[l][1] = tg[x1 << symShift]; yq[l][2] = tg[x2 << symShift]; yq[l][3] = tg[x3 << symShift];
             }
         }
         // (3) install the input chunks and publish them
@@ -237,8 +251,8 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 // cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
 struct FseCellsRef { const u32* cells;
     DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = cells[st]; ns = c & 0xFFFFu; sym = (c >> 16) & 0xFFu; nb = c >> 24; } };
-struct FseCellsCompact { const u16* A; const u8* syms;
-    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = A[st]; ns = c & 0xFFFu; nb = c >> 12; sym = syms[st]; } };
+struct FseCellsCompact { const u16* A; const u8* syms; u32 nsShift;      // nsShift = 1 for the FAST cell format (2*newState)
+    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = A[st]; ns = (c & 0xFFFu) >> nsShift; nb = c >> 12; sym = syms[st]; } };
 template <class Cells>
 DEV u32 fse_tail_step(const Cells& t, u32& state, BitReader& r, bool fast)          // FSE_decodeSymbol(Fast), fse.h:600-622
 {
@@ -270,17 +284,21 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
     }
 }
 
-// LDS: DecCtl[FSE_MAXG] | per block: A[2^maxTableLog] (u16) | state ring (64 x 8 B) | input ring (512 + 16 B)
+// LDS: G tables A[2^maxTableLog] (u16) on table-size aligned addresses | DecCtl[FSE_MAXG] | per block: state ring
+// (64 x 8 B), input ring (512 + 16 B)
+template <bool FAST>
 __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t first = (size_t)blockIdx.x * a.G;
+    u8* const lds8 = (u8*)lds;
+    const u32 tabStride = 2u << a.maxTableLog;                   // bytes per table
+    DecCtl* const ctlAll = (DecCtl*)(lds8 + (size_t)a.G * tabStride);
+    u8* const ldsb = (u8*)ctlAll + FSE_CTL_BYTES;                // ring area: one slot of slotBytes per block
     const u32 slotBytes = a.slotU32 * 4u;                        // multiple of 8
-    const u32 ringOff = 2u << a.maxTableLog;                     // state ring offset inside a slot
-    const u32 inOff = ringOff + FSE_DEC_RING * 8;                // input ring offset inside a slot
-    DecCtl* const ctlAll = (DecCtl*)lds;
-    u8* const ldsb = (u8*)lds + FSE_CTL_BYTES;
+    const u32 ringOff = 0;                                       // state ring offset inside a slot
+    const u32 inOff = FSE_DEC_RING * 8;                          // input ring offset inside a slot
 
     // ---- stage: reference cells {u16 newState; u8 symbol; u8 nbBits} -> compact u16 (uniform control flow, both waves).
     //      A table whose fields do not fit 12+4 bits (cannot come from FSE_buildDTable) is flagged and decoded
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             if (a.atab) {                                        // k_fse_dbuild output: already in the LDS format
                 const u32 ts = 1u << a.meta[b].tableLog;
                 const u32* const t32 = (const u32*)(a.atab + (b << a.maxTableLog));
-                u32* const A32 = (u32*)(ldsb + (size_t)g * slotBytes);
+                u32* const A32 = (u32*)(lds8 + (size_t)g * tabStride);
                 for (u32 i = tid; i < ts / 2; i += FSE_DEC_THREADS) A32[i] = t32[i];
                 anyNb0 |= !(a.meta[b].state & 2u);               // a cell with nbBits == 0 needs a counter > tableSize/2
                 continue;
@@ -305,14 +323,14 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             const u32 tl = t[0] & 0xFFFFu;
             if (tl > a.maxTableLog) continue;
             const u32 ts = 1u << tl;
-            u16* A = (u16*)(ldsb + (size_t)g * slotBytes);
+            u16* A = (u16*)(lds8 + (size_t)g * tabStride);
             bool bad = false;
             for (u32 i = tid; i < ts; i += FSE_DEC_THREADS) {
                 const u32 c = t[1 + i];
                 const u32 ns = c & 0xFFFFu, nb = c >> 24;
-                bad |= (ns > 0xFFFu) | (nb > 15u) | ((ns & ((1u << (nb & 15u)) - 1u)) != 0);
+                bad |= (ns >= (FAST ? 0x800u : 0x1000u)) | (nb > 15u) | ((ns & ((1u << (nb & 15u)) - 1u)) != 0);
                 anyNb0 |= (nb == 0);
-                A[i] = (u16)((ns & 0xFFFu) | (nb << 12));
+                A[i] = (u16)((((FAST ? 2u * ns : ns)) & 0xFFFu) | (nb << 12));
             }
             if (bad) badBits |= 1u << g;
         }
@@ -338,7 +356,12 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     }
     const u32* const cells = compact ? nullptr : gtab + 1;      // literal path: reference cells, or the LDS cells + symbol table
     const u8* const syms = compact ? a.symtab + ((owner ? b : 0) << a.maxTableLog) : (const u8*)cells + 2;
-    const u16* const A = (const u16*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes);
+    // absolute LDS byte address of my table: the dynamic LDS segment starts at 0 (no static LDS in this kernel), which the
+    // table-size alignment of the FAST address arithmetic relies on
+    const u32 ldsBase = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds8;
+    if (ldsBase & (tabStride - 1)) __builtin_trap();
+    const u32 tabOff = ldsBase + (u32)(lane < a.G ? lane : 0) * tabStride;
+    const u16* const A = (const u16*)(lds8 + (tabOff - ldsBase));
     const u8* in = nullptr; size_t S = 0; u8* out = nullptr;
     const long omax = (long)a.dstCapacity;
     long op = 0;
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // 16 iterations of a phase run without any per-iteration bookkeeping; whatever is left goes to the literal tail.
     // Bulk state uses p = at+1, u = used+8 (u in [8,16) after a reload), so no shift amount is ever 0 or 32.
     bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> lane) & 1u);
-    BulkState bs; bs.s1 = s1; bs.s2 = s2; bs.q = 0; bs.bq = 0;
+    BulkState bs; bs.s1 = tabOff + 2u * s1; bs.s2 = tabOff + 2u * s2; bs.q = 0; bs.bq = 0;   // states as cell addresses
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + 512)
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + ringOff);
-    const u8* const myIn = ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + inOff;
+    const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
     TIMING(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
     while (__any(can)) {
         bool ready = false;
@@ -403,8 +426,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         }
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
-            if (nb0) fse_bulk_phase<true>(bs, A, myIn, ring);
-            else     fse_bulk_phase<false>(bs, A, myIn, ring);
+            if (nb0) fse_bulk_phase<true, FAST>(bs, tabOff, myIn, ring);
+            else     fse_bulk_phase<false, FAST>(bs, tabOff, myIn, ring);
             iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
             // the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
             can = bs.q >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
@@ -419,20 +442,20 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     op = 4 * (long)iters;
     if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container) after a reload
         const u32 B = 8u * (bs.q + 8u) + bs.bq;
-        r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = bs.s1; s2 = bs.s2;
+        r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s1 - tabOff) >> 1; s2 = (bs.s2 - tabOff) >> 1;
     }
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
     size_t result;
-    if (compact) result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
+    if (compact) result = fse_tail(FseCellsCompact{A, syms, FAST ? 1u : 0u}, s1, s2, r, out, op, omax, fast);
     else         result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
 }
 
 static void fse_decode_geometry(unsigned maxTableLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
-    *slotU32 = ((2u << maxTableLog) + FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 8) / 4;   // table + rings (+8: rotating banks)
-    int g = (int)((ldsBytes - FSE_CTL_BYTES) / (*slotU32 * 4));
+    *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 8) / 4;   // rings (+8: rotating banks)
+    int g = (int)((ldsBytes - FSE_CTL_BYTES) / ((2u << maxTableLog) + *slotU32 * 4));
     if (g > FSE_MAXG) g = FSE_MAXG;
     if (const char* dbg = getenv("FSEHIP_DEBUG_G")) { int v = atoi(dbg); if (v >= 1 && v < g) g = v; }   // tuning aid
     *G = g;
@@ -453,7 +476,8 @@ hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
     size_t ldsBytes = FSE_DEC_LDS;
     if (const char* dbg = getenv("FSEHIP_DEBUG_LDS")) ldsBytes = (size_t)atoi(dbg);   // tuning aid
     if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_fse_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_fse_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fse_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) return e;
         attrSet = true;
     }
@@ -461,7 +485,8 @@ hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
     probe_before(PK_FSE_DECODE, s);
-    hipLaunchKernelGGL(k_fse_decode, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    if (a.maxTableLog <= FSE_DEC_FAST_MAXLOG) hipLaunchKernelGGL(k_fse_decode<true>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    else hipLaunchKernelGGL(k_fse_decode<false>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     probe_after(PK_FSE_DECODE, s);
     return hipGetLastError();
 }

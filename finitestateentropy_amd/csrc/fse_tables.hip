@@ -140,7 +140,8 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
         const int n = w.nrm[s];
         const u32 next = (n > 0 ? (u32)n : 1u) + r;                        // symbolNext[s]++, fse_decompress.c:117-122
         const u32 nb = tl - hibit32(next);
-        w.cell[u] = (u16)((((next << nb) - ts) & 0xFFFu) | (nb << 12));
+        const u32 ns = (next << nb) - ts;
+        w.cell[u] = (u16)((((a.maxLog <= FSE_DEC_FAST_MAXLOG ? 2u * ns : ns)) & 0xFFFu) | (nb << 12));
     });
     u32* const A32 = (u32*)(a.atab + b * capTs);
     const u32* const c32 = (const u32*)w.cell;

@@ -76,7 +76,7 @@ struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCo
     BlockView csrc;
     unsigned maxLog;
     // outputs, `capTs` = 1 << maxLog cells per block: the decoder's own table format (fse_decode.hip)
-    u16* atab;                   // cell x: newState (12 bits) | nbBits << 12
+    u16* atab;                   // cell x: newState (12 bits; 2*newState when maxLog <= FSE_DEC_FAST_MAXLOG) | nbBits << 12
     u8* symtab;                  // cell x: symbol
     s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
     FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1
@@ -97,6 +97,7 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     unsigned slotU32;
     size_t nBlocks;
 };
+#define FSE_DEC_FAST_MAXLOG 11u   // up to this maxTableLog the decoder's cells hold 2*newState (see fse_decode.hip)
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s);
 size_t fse_decode_blocks_per_round(unsigned maxTableLog);   // blocks that fill the device once (for chunk sizing)
 
