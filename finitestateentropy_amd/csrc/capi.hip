@@ -230,7 +230,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     const FseCWs w = fse_cws(tableLog);
     if (workspaceBytes < w.perBlock + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / w.perBlock;
-    if (chunk > nBlocks) chunk = nBlocks;
+    if (chunk >= nBlocks) chunk = nBlocks;
     else chunk = round_chunk(chunk, fse_encode_blocks_per_round(w.maxTl));
     // carve the workspace
     u8* p = (u8*)d_workspace;
@@ -291,7 +291,7 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     const size_t per = fse_dws_per_block(maxLog);
     if (workspaceBytes < per + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / per;
-    if (chunk > nBlocks) chunk = nBlocks;
+    if (chunk >= nBlocks) chunk = nBlocks;
     else chunk = round_chunk(chunk, fse_decode_blocks_per_round(maxLog));
     u8* p = (u8*)d_workspace;
     FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
@@ -464,7 +464,7 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
     if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255) return (int)hipErrorInvalidValue;   // huf_compress.c:659-660 (see single-block wrapper)
     if (workspaceBytes < HUF_CWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / HUF_CWS_PER_BLOCK;
-    if (chunk > nBlocks) chunk = nBlocks;
+    if (chunk >= nBlocks) chunk = nBlocks;
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
     unsigned* counts = (unsigned*)carve(chunk * 1024);
@@ -510,7 +510,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
     if (nBlocks == 0) return 0;
     if (workspaceBytes < HUF_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / HUF_DWS_PER_BLOCK;
-    if (chunk > nBlocks) chunk = nBlocks;
+    if (chunk >= nBlocks) chunk = nBlocks;
     u8* p = (u8*)d_workspace;
     HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
     u32* dtables = (u32*)p;

@@ -20,6 +20,9 @@ def agg(path):
     out = collections.defaultdict(lambda: [0, 0.0, 0])
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]
+        k = k.split("<")[0]                       # template instances (k_fse_decode<true>) report under the kernel name
         a = out[k]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
