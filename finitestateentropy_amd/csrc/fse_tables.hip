@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
         if (lane == 0) img[0] = tl | (maxSV << 16);
     }
     __syncthreads();
-    wave_spread_rank(w, maxSV, tl, lane, [&](u32 u, u32 s, u32 r) { stateTable[(u32)cumAll[s] + r] = (u16)(ts + u); });   // :125-133
+    wave_spread_rank(w, maxSV, tl, lane, [&](u32 s) { return (u32)cumAll[s]; },
+                     [&](u32 u, u32 s, u32 r, u32 first) { (void)s; stateTable[first + r] = (u16)(ts + u); });   // :125-133
     u32* const out = a.ctables + b * a.ctStrideU32;
     const u32 words = 1 + (ts >> 1) + 2 * (maxSV + 1);
     for (u32 i = lane; i < words; i += 64) out[i] = img[i];
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
     *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
     __syncthreads();
     const u32 tl = m.tableLog, ts = 1u << tl;
-    const bool fast = wave_spread_rank(w, m.maxSV, tl, lane, [&](u32 u, u32 s, u32 r) {
-        const int n = w.nrm[s];
+    const bool fast = wave_spread_rank(w, m.maxSV, tl, lane, [&](u32 s) { return (u32)(int)w.nrm[s]; }, [&](u32 u, u32 s, u32 r, u32 nrm) {
+        (void)s;
+        const int n = (int)nrm;
         const u32 next = (n > 0 ? (u32)n : 1u) + r;                        // symbolNext[s]++, fse_decompress.c:117-122
         const u32 nb = tl - hibit32(next);
         const u32 ns = (next << nb) - ts;
@@ -152,6 +154,9 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
     if (lane == 0) a.meta[b].state = 1u | (fast ? 2u : 0u);
 }
 
+#ifdef FSE_WB_TIMING
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_wbTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wbTiming), sizeof(g_wbTiming)); }
+#endif
 hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;

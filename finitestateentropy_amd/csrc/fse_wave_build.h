@@ -8,23 +8,31 @@
 //      (CTable: stateTable[cumul[s] + rank] = tableSize + u;  DTable: nextState = symbolNext[s] + rank).
 // Restated without the loop-carried dependencies:
 //   1. step is odd, so m -> (m * step) mod tableSize is a bijection and the serial walk visits m = 0, 1, 2, ... in
-//      order; the k-th *kept* visit (u <= highThreshold) gets the symbol whose cumulative count range contains k.  Each lane
-//      takes a contiguous range of m, a wave prefix sum of the kept visits gives its first k, and it walks the
-//      (compacted) cumulative-count list from there.
+//      order; the k-th *kept* visit (u <= highThreshold) gets the symbol whose cumulative count range contains k.  Every
+//      symbol marks the first k of its range with symbol+1; each lane takes a contiguous range of m, a wave prefix sum of
+//      the kept visits gives its first k, and the symbol of a visit is the running maximum of the marks up to its k
+//      (a wave prefix maximum carries it across lanes).
 //   2. rank(u) = number of cells u' < u with the same symbol.  Lane l owns the contiguous cells [l*C, (l+1)*C);
 //      a byte matrix cnt[symbol][lane] counts the symbols per lane range (LDS atomic add with return = the rank inside
 //      the range), a per-symbol running sum over groups of 4 lanes gives the ranks of everything before the range.
-// The result is handed to `emit(u, symbol, rank)` once per cell, lane l emitting its own range in ascending u.
+// The result is handed to `emit(u, symbol, rank, payload(symbol))` once per cell, lane l emitting its own range in
+// ascending u; `payload` is a per-symbol LDS lookup of the caller's that is gathered together with the core's own.
 #pragma once
 #include "dev_common.h"
 
 #define WB_MAXSYM 256
 #define WB_TSTEP(ts) (((ts) >> 1) + ((ts) >> 3) + 3)     // lib/fse.h:683
 
+#ifdef FSE_WB_TIMING         // development aid: phase cycle accounting of the last table build of each workgroup
+__device__ unsigned long long g_wbTiming[4096 * 8];
+#define WBT(k) TT[k] = __builtin_readcyclecounter();
+#else
+#define WBT(k)
+#endif
 struct WaveBuildLds {        // LDS scratch of one wave, tableSize = 1 << tl <= capTs
     s16* nrm;                // [256] normalized counters, zero beyond maxSV (input)
-    u16* cumP;               // [257] cumulative positive counts of the symbols listed in symP
-    u8*  symP;               // [256] symbols with a positive count, ascending
+    u16* cumP;               // [257] (unused by the core; callers may use it)
+    u8*  symP;               // [256] symbols in use (counter != 0), ascending
     u8*  symTab;             // [capTs] symbol of every cell (output of the spread)
     u16* cell;               // [capTs] rank inside the lane range; the emitter may overwrite cell[u] with its result
     u32* cnt;                // [256 * 16] byte matrix cnt[symbol][lane]
@@ -56,66 +64,115 @@ DEV u32 wb_scan_excl(u32 v, u32 lane, u32* total)         // exclusive prefix su
 
 // All 64 lanes of one wave call this with uniform arguments; w.nrm holds the counters.  Uses __syncthreads(), so the
 // workgroup must be exactly this wave.  Returns the fastMode flag of FSE_buildDTable (no counter >= tableSize/2).
-template <class Emit>
-DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Emit&& emit)
+template <class Payload, class Emit>
+DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Payload&& payload, Emit&& emit)
 {
+#ifdef FSE_WB_TIMING
+    unsigned long long TT[8];
+#endif
+    WBT(0)
     const u32 ts = 1u << tl, mask = ts - 1, step = WB_TSTEP(ts);
+    const u32 C = ts >= 64 ? ts >> 6 : 1;                                 // cells (and visits) per lane
+    const bool act = lane * C < ts;
+    const u32 m0 = lane * C;
+    u16* const marks = w.cell;                                            // [ts] scratch of the spread (cell[] is not in use yet)
     // ---- per symbol: lane l looks after symbols 4l .. 4l+3
     int n[4];
     {   const uint2 raw = *(const uint2*)(w.nrm + 4 * lane);
         n[0] = (s16)(raw.x & 0xFFFFu); n[1] = (s16)(raw.x >> 16); n[2] = (s16)(raw.y & 0xFFFFu); n[3] = (s16)(raw.y >> 16);
     }
-    u32 lanePos = 0, laneLow = 0, lanePres = 0; bool big = false;
+    u32 lanePos = 0, laneLow = 0, laneAny = 0; bool big = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (4 * lane + i > maxSV) n[i] = 0;
-        lanePos += n[i] > 0 ? (u32)n[i] : 0u; laneLow += n[i] == -1; lanePres += n[i] > 0;
+        lanePos += n[i] > 0 ? (u32)n[i] : 0u; laneLow += n[i] == -1; laneAny += n[i] != 0;
         big |= n[i] >= (int)(ts >> 1);
     }
-    u32 sumPos, nLow, nPres;
-    u32 posBase = wb_scan_excl(lanePos, lane, &sumPos);
-    u32 lowBase = wb_scan_excl(laneLow, lane, &nLow);
-    u32 presBase = wb_scan_excl(lanePres, lane, &nPres);
+    // one packed scan: positive counts (<= 4096: 13 bits) | low-probability symbols (9 bits) | symbols in use (9 bits)
+    u32 totals;
+    const u32 base3 = wb_scan_excl(lanePos | (laneLow << 13) | (laneAny << 22), lane, &totals);
+    u32 posBase = base3 & 0x1FFFu, lowBase = (base3 >> 13) & 0x1FFu, anyBase = base3 >> 22;
+    const u32 nLow = (totals >> 13) & 0x1FFu, nAny = totals >> 22;
     const int high = (int)ts - 1 - (int)nLow;                             // highThreshold (-1: every cell is a low-probability one)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (n[i] > 0) { w.symP[presBase] = (u8)(4 * lane + i); w.cumP[presBase] = (u16)posBase; ++presBase; posBase += (u32)n[i]; }
-        else if (n[i] == -1) { w.symTab[ts - 1 - lowBase] = (u8)(4 * lane + i); ++lowBase; }
-    }
-    if (lane == 0) w.cumP[nPres] = (u16)sumPos;
-    // ---- clear the count matrix rows in use
+    // clear the spread marks and the count matrix rows in use
+    if (act) { if (C >= 8) for (u32 i = 0; i < C; i += 8) *(uint4*)(marks + m0 + i) = make_uint4(0, 0, 0, 0); else for (u32 i = 0; i < C; ++i) marks[m0 + i] = 0; }
     {   const u32 rows16 = (maxSV + 1) * 16;                              // dwords
         for (u32 i = 4 * lane; i < rows16; i += 256) *(uint4*)(w.cnt + i) = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-
-    // ---- spread: lane l visits m in [l*C, (l+1)*C)
-    const u32 C = ts >= 64 ? ts >> 6 : 1;
-    const bool act = lane * C < ts;
-    const u32 m0 = lane * C;
+    WBT(1)
+    // symbols in use (for the per-symbol pass below); low-probability symbols take the top cells; every symbol with a
+    // positive count marks the first of its kept visits with symbol+1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (n[i] != 0) w.symP[anyBase++] = (u8)(4 * lane + i);
+        if (n[i] > 0) { marks[posBase] = (u16)(4 * lane + i + 1); posBase += (u32)n[i]; }
+        else if (n[i] == -1) { w.symTab[ts - 1 - lowBase] = (u8)(4 * lane + i); ++lowBase; }
+    }
+    // ---- spread: lane l visits m in [l*C, (l+1)*C); the k-th kept visit belongs to the symbol of the last mark at or
+    //      before k, i.e. a running maximum over the marks (symbols ascend with k)
     u32 nv = 0;
     if (act) { u32 u = (m0 * step) & mask; for (u32 i = 0; i < C; ++i) { nv += (int)u <= high; u = (u + step) & mask; } }
     u32 totalKept;
-    u32 k = wb_scan_excl(nv, lane, &totalKept);
+    const u32 k0 = wb_scan_excl(nv, lane, &totalKept);
+    __syncthreads();
+    WBT(2)
+    // (eight marks at a time so that the LDS round trips overlap; indices are clamped, unused values are ignored)
+    u32 localMax = 0;
+    for (u32 i = 0; i < nv; i += 8) {
+        u32 v[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) { const u32 idx = k0 + i + j; v[j] = marks[idx < ts ? idx : ts - 1]; }
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) if (i + j < nv) localMax = v[j] > localMax ? v[j] : localMax;
+    }
+    u32 run = localMax;                                                   // inclusive prefix maximum over the lanes ...
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)run, off, WAVE); if ((int)lane >= off) run = o > run ? o : run; }
+    run = (u32)__shfl_up((int)run, 1, WAVE);                             // ... made exclusive
+    if (lane == 0) run = 0;
     if (act && nv) {
-        u32 lo = 0, hi = nPres;                                           // cumP[lo] <= k < cumP[hi]
-        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (w.cumP[mid] <= k) lo = mid; else hi = mid; }
-        u32 j = lo, nextCum = w.cumP[j + 1], cur = w.symP[j];
-        u32 u = (m0 * step) & mask;
-        for (u32 i = 0; i < C; ++i) {
-            if ((int)u <= high) {
-                while (k >= nextCum) { ++j; nextCum = w.cumP[j + 1]; cur = w.symP[j]; }
-                w.symTab[u] = (u8)cur; ++k;
+        u32 u = (m0 * step) & mask, k = k0;
+        u32 i = 0;
+        for (; i + 8 <= C; i += 8) {
+            u32 uu[8], v[8]; bool keep[8];
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                uu[j] = u; keep[j] = (int)u <= high;
+                v[j] = marks[k < ts ? k : ts - 1];
+                k += keep[j]; u = (u + step) & mask;
             }
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) if (keep[j]) { run = v[j] > run ? v[j] : run; w.symTab[uu[j]] = (u8)(run - 1u); }
+        }
+        for (; i < C; ++i) {
+            if ((int)u <= high) { const u32 v = marks[k++]; run = v > run ? v : run; w.symTab[u] = (u8)(run - 1u); }
             u = (u + step) & mask;
         }
     }
     __syncthreads();
+    WBT(3)
 
-    // ---- rank inside the lane range: LDS atomics return the previous count, in program order
+    // ---- rank inside the lane range: LDS atomics return the previous count, in program order.  Eight cells at a time so
+    //      that the LDS round trips overlap (the symbols of a lane's cells are contiguous bytes).
     const u32 sh8 = 8 * (lane & 3u), grp = lane >> 2;
     if (act) {
-        for (u32 i = 0; i < C; ++i) {
+        u32 i = 0;
+        for (; i + 8 <= C; i += 8) {
+            const uint2 sy = *(const uint2*)(w.symTab + m0 + i);
+            u32 old[8];
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                const u32 s = ((j < 4 ? sy.x : sy.y) >> (8 * (j & 3))) & 0xFFu;
+                old[j] = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
+            }
+            uint4 pk;
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) old[j] = (old[j] >> sh8) & 0xFFu;
+            pk.x = old[0] | (old[1] << 16); pk.y = old[2] | (old[3] << 16); pk.z = old[4] | (old[5] << 16); pk.w = old[6] | (old[7] << 16);
+            *(uint4*)(w.cell + m0 + i) = pk;
+        }
+        for (; i < C; ++i) {
             const u32 u = m0 + i;
             const u32 s = w.symTab[u];
             const u32 old = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
@@ -123,30 +180,55 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Em
         }
     }
     __syncthreads();
-    // ---- per symbol: running sum over the 16 lane groups
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (n[i] == 0) continue;
-        const u32 s = 4 * lane + i;
-        u32 run = 0;
-        for (u32 g4 = 0; g4 < 16; g4 += 4) {
-            const uint4 c = *(const uint4*)(w.cnt + s * 16 + g4);
-            const u32 r0 = run, r1 = r0 + wb_bytesum(c.x), r2 = r1 + wb_bytesum(c.y), r3 = r2 + wb_bytesum(c.z);
-            run = r3 + wb_bytesum(c.w);
-            *(uint2*)(w.coarse + s * 16 + g4) = make_uint2(r0 | (r1 << 16), r2 | (r3 << 16));
-        }
+    WBT(4)
+    // ---- per symbol in use (lane l: the l-th, l+64-th, ... of them): running sum over the 16 lane groups
+    for (u32 j = lane; j < nAny; j += 64) {
+        const u32 s = w.symP[j];
+        const uint4* const row = (const uint4*)(w.cnt + s * 16);
+        const uint4 c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
+        u32 r[16];
+        u32 acc = 0;
+#define WB_ACC(k, v) r[k] = acc; acc += wb_bytesum(v);
+        WB_ACC(0, c0.x) WB_ACC(1, c0.y) WB_ACC(2, c0.z) WB_ACC(3, c0.w) WB_ACC(4, c1.x) WB_ACC(5, c1.y) WB_ACC(6, c1.z) WB_ACC(7, c1.w)
+        WB_ACC(8, c2.x) WB_ACC(9, c2.y) WB_ACC(10, c2.z) WB_ACC(11, c2.w) WB_ACC(12, c3.x) WB_ACC(13, c3.y) WB_ACC(14, c3.z) WB_ACC(15, c3.w)
+#undef WB_ACC
+        uint4* const out = (uint4*)(w.coarse + s * 16);
+        out[0] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+        out[1] = make_uint4(r[8] | (r[9] << 16), r[10] | (r[11] << 16), r[12] | (r[13] << 16), r[14] | (r[15] << 16));
     }
     __syncthreads();
-    // ---- emit
+    WBT(5)
+    // ---- emit: everything a cell needs is gathered for eight cells before the first one is emitted
     if (act) {
         const u32 belowMask = (1u << sh8) - 1u;
-        for (u32 i = 0; i < C; ++i) {
+        u32 i = 0;
+        for (; i + 8 <= C; i += 8) {
+            const uint2 sy = *(const uint2*)(w.symTab + m0 + i);
+            const uint4 lr = *(const uint4*)(w.cell + m0 + i);
+            u32 s[8], co[8], cn[8], pl[8];
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                s[j] = ((j < 4 ? sy.x : sy.y) >> (8 * (j & 3))) & 0xFFu;
+                co[j] = w.coarse[s[j] * 16 + grp]; cn[j] = w.cnt[s[j] * 16 + grp]; pl[j] = payload(s[j]);
+            }
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                const u32 lrw = j < 2 ? lr.x : j < 4 ? lr.y : j < 6 ? lr.z : lr.w;
+                const u32 local = (lrw >> (16 * (j & 1))) & 0xFFFFu;
+                emit(m0 + i + j, s[j], local + co[j] + wb_bytesum(cn[j] & belowMask), pl[j]);
+            }
+        }
+        for (; i < C; ++i) {
             const u32 u = m0 + i;
             const u32 s = w.symTab[u];
             const u32 r = (u32)w.cell[u] + (u32)w.coarse[s * 16 + grp] + wb_bytesum(w.cnt[s * 16 + grp] & belowMask);
-            emit(u, s, r);
+            emit(u, s, r, payload(s));
         }
     }
     __syncthreads();
+    WBT(6)
+#ifdef FSE_WB_TIMING
+    if (lane == 0 && blockIdx.x < 4096) for (int q = 0; q < 6; ++q) g_wbTiming[8 * blockIdx.x + q] = TT[q + 1] - TT[q];
+#endif
     return !__any(big);
 }
