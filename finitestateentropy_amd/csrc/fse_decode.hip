@@ -1,22 +1,24 @@
 // fse_decode.hip -- a3: FSE_decompress_usingDTable over a batch
 // (reference: lib/fse_decompress.c:178-252, lib/fse.h:577-622, lib/bitstream.h:272-448).
 //
-// tANS decoding is one loop-carried chain per block (two interleaved states sharing one bit cursor), so
-// the mapping is "one lane per block, many blocks per CU": a 64-lane workgroup stages G DTables into LDS
-// (verbatim reference layout, coalesced copy) and lane g walks block g's stream.  Throughput comes from
-// the number of blocks resident per CU (bounded by LDS: 160 KiB / 8 KiB tables at tableLog 11) and from
-// the instruction count of the per-symbol step, because a wavefront issues one instruction every few
-// cycles no matter how many of its lanes are active.
+// tANS decoding is one loop-carried chain per block (two interleaved states sharing one bit cursor; a simulation of
+// speculative starts shows that this two-state decoder does not re-synchronise within thousands of symbols, so unlike
+// the encoder it cannot be split), hence "one lane per block, as many blocks per CU as LDS holds":
+//   * a workgroup = 1 decoder wave + 4 service waves over G = 15 blocks (tableLog 11); 2 workgroups per CU;
+//   * the decoder lane of a block walks the chain touching registers and LDS only: u16 table cells, a 512-byte ring of
+//     compressed input, a ring of decoded states;
+//   * the service waves own all global-memory traffic of the bulk loop, wave-cooperative and coalesced: they refill the
+//     input rings and turn state-ring records into output bytes (symbol gathers from an L2-resident byte table);
+//   * the two sides talk through per-block control words in LDS (acquire/release, workgroup scope).
+// Throughput = blocks resident per CU / latency of one iteration of the chain (two dependent LDS lookups).
 //
-// The kernel keeps the reference's own decoder state -- a 64-bit little-endian window at byte offset
-// `at` plus a consumed-bit count `used` (lib/bitstream.h:91-97) -- so results are identical by
-// construction, including on truncated / corrupt input:
-//   * `BitReader` is a literal device restatement of BIT_initDStream / BIT_readBits / BIT_reloadDStream;
-//   * the bulk loop is lib/fse_decompress.c:201-218 (4 symbols per reload) for as long as the window is at
-//     least 24 bytes above the stream start.  There the reload is always the "fast" one (:378-388), and
-//     the new window is not loaded but funnel-shifted out of two speculatively prefetched 8-byte words
-//     below it, so no memory latency sits on the dependent chain (gfx950 global memory accepts the
-//     unaligned 8-byte accesses this needs).
+// The kernel reproduces the reference's decoder state -- a 64-bit little-endian window at byte offset `at` plus a
+// consumed-bit count `used` (lib/bitstream.h:91-97) -- exactly, including on truncated / corrupt input:
+//   * `BitReader` is a literal device restatement of BIT_initDStream / BIT_readBits / BIT_reloadDStream and runs the
+//     initialisation and the last symbols of every stream;
+//   * the bulk loop is lib/fse_decompress.c:201-218 (4 symbols per reload) for as long as the window is at least 24
+//     bytes above the stream start, where every reload is the "fast" one (:378-388) and (ptr, bitsConsumed) are a
+//     function of the absolute bit position alone.
 #include "internal.h"
 #include <stdlib.h>
 
