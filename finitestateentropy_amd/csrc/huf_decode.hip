@@ -1,25 +1,57 @@
 // huf_decode.hip -- a5: HUF_decompress4X1_usingDTable over a batch
 // (reference: lib/huf_decompress.c:194-354, dispatcher :980-997; lib/bitstream.h:272-448).
 //
-// The 4-stream layout gives four independent serial chains per block, so the mapping is "one lane per
-// stream": a 128-lane workgroup stages G X1 tables (reference layout: 4-byte DTableDesc + 2-byte
-// {byte, nbBits} cells) into LDS with coalesced copies, then lane 4g+k decodes stream k of block g.
+// The 4-stream layout gives four independent serial chains per block (one table lookup per symbol on the chain), so
+// the mapping is "one lane per stream, as many blocks per CU as LDS holds", with the same division of labour as
+// fse_decode.hip:
+//   * a workgroup = 1 decoder wave + HD_SRV_WAVES service waves over G blocks (lane 4g+k of the decoder wave walks
+//     stream k of block g); 2 workgroups per CU;
+//   * the decoder lane touches registers and LDS only: the X1 table (2-byte cells, staged as {byte, 32 - nbBits}), a
+//     256-byte ring of compressed input and a ring of 4-symbol output words per stream;
+//   * the service waves own all global-memory traffic of the bulk loop, coalesced: 128-byte input refills, 256-byte
+//     output rows; the two sides talk through per-stream control words in LDS (acquire/release, workgroup scope).
 //
-// Per stream the kernel keeps the reference's own reader state (64-bit window at byte offset `at`, consumed
-// bits `used`), so the verdict -- every stream must end with BIT_endOfDStream, lib/huf_decompress.c:348-349 --
-// is the reference's by construction, also on corrupt input:
-//   * bulk loop = the 4-symbols-per-reload iterations (HUF_decodeStreamX1 :219-224 / the lock-step loop
-//     :310-331; both reload variants coincide while the window is >= 8 bytes above the stream start),
-//     with the next window funnel-shifted out of two prefetched 8-byte words instead of being loaded;
-//   * the last symbols of a stream run through the literal BitReader (bitreader.h).
-// A stream's decoded symbols and final reader state depend only on that stream, so decoding the four
-// streams independently (instead of in lock-step) yields the same result as the reference.
+// Per stream the kernel reproduces the reference's reader state (64-bit window at byte offset `at`, consumed bits
+// `used`), so the verdict -- every stream must end with BIT_endOfDStream, lib/huf_decompress.c:348-349 -- is the
+// reference's by construction, also on corrupt input:
+//   * bulk loop = the 4-symbols-per-reload iterations (HUF_decodeStreamX1 :219-224 / the lock-step loop :310-331) for
+//     as long as the window stays at least 24 bytes above the stream start, where every reload is the "fast" one
+//     (bitstream.h:378-388) and (ptr, bitsConsumed) are a function of the absolute bit position alone;
+//   * initialisation and the last symbols of a stream run through the literal BitReader (bitreader.h).
+// A stream's decoded symbols and final reader state depend only on that stream, so decoding the four streams
+// independently (instead of in lock-step) yields the same result as the reference.
 #include "internal.h"
 #include "bitreader.h"
 
-#define HUF_DEC_THREADS 128
+#define HD_PHASE 8               // bulk iterations per phase (4 symbols, <= 6 bytes each)
+#define HD_OUT_RING 64           // per-stream ring of output words (4 symbols each)
+#define HD_IN_RING 256           // per-stream ring of compressed input, direct-mapped by offset mod 256
+#define HD_IN_CHUNK 128          // refill granule: 32 lanes x 4 bytes
+#define HD_IN_MIRROR 16          // the first bytes are mirrored behind the ring so reads of 3 dwords never wrap
+#define HD_MAXG 16               // blocks per workgroup (64 streams = the lanes of the decoder wave)
+#define HD_SRV_WAVES 4
+#define HD_SRV_S (4 * HD_MAXG / HD_SRV_WAVES)       // streams per service wave
+#define HD_THREADS (64 * (1 + HD_SRV_WAVES))
+#define HD_SLOT_LOG 11u          // tables up to this tableLog live in LDS; larger ones are decoded by the literal path
 
-DEV u32 hufx1_step(BitReader& r, const u16* cells, u32 dtLog)                // HUF_decodeSymbolX1, :194-201
+struct HdCtl {             // per stream, in LDS
+    u32 pubIters;          // decoder -> service: bulk iterations completed (output words produced)
+    u32 pubPofs;           // decoder -> service: byte offset of the topmost dword still read; bit 31 = bulk finished
+    u32 srvFlushed;        // service -> decoder: output words already written to global memory
+    int srvValidLo;        // service -> decoder: the input ring holds stream bytes [validLo, validLo + 256); INT_MAX = not yet
+    int initValidLo;       // set-up constants for the service wave
+    int S32;
+    u32 inLo, inHi, outLo, outHi;
+    u32 pad[6];
+};
+#define HD_STREAM_AUX (HD_IN_RING + HD_IN_MIRROR + HD_OUT_RING * 4)     // rings of one stream, bytes
+
+DEV u32 hd_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV int hd_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void hd_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void hd_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+DEV u32 hufx1_step(BitReader& r, const u16* cells, u32 dtLog)                // HUF_decodeSymbolX1, :194-201 (reference cells)
 {
     const u32 v = (u32)((r.win << (r.used & 63u)) >> ((64u - dtLog) & 63u)); // BIT_lookBitsFast
     const u32 c = cells[v];
@@ -27,48 +59,197 @@ DEV u32 hufx1_step(BitReader& r, const u16* cells, u32 dtLog)                // 
     return c & 0xFFu;
 }
 
-#define HUF_BULK_STEP(SEL)                                                                 \
-    {   const u32 c = cells[(u32)(t >> 32) >> shIdx];                                      \
-        const u32 nb = c >> 8;                                                             \
-        t <<= nb; used += nb;                                                              \
-        word = __builtin_amdgcn_perm(c, word, SEL);                                        \
+struct HdBulk { u32 q, bq; };      // q = byte offset of the lowest of the 3 window dwords, bq = unread bits of the topmost
+
+// One phase = HD_PHASE iterations of 4 symbols for one lane, registers + LDS only.  cell = byte | (32 - nbBits) << 8.
+DEV void hd_bulk_phase(HdBulk& b, const u16* T, u32 idxShift, const u8* myIn, u32* ring)
+{
+    u32 q = b.q, bq = b.bq;
+#pragma unroll 2
+    for (int it = 0; it < HD_PHASE; ++it) {
+        const u32* const wp = (const u32*)(myIn + (q & (HD_IN_RING - 4)));
+        const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        u32 thi = __builtin_amdgcn_alignbit(d2, d1, bq), tlo = __builtin_amdgcn_alignbit(d1, d0, bq);   // next 64 unread bits
+        u32 word = 0, msum = 0;
+#define HD_SYM(SEL)                                                                        \
+        {   const u32 c = T[thi >> idxShift];                                              \
+            const u32 m = c >> 8;                                                          \
+            thi = __builtin_amdgcn_alignbit(thi, tlo, m); tlo <<= (32u - m);               \
+            msum += m;                                                                     \
+            word = __builtin_amdgcn_perm(c, word, SEL); }
+        HD_SYM(0x03020104u)                                      // byte 0 <- cell byte
+        HD_SYM(0x03020400u)
+        HD_SYM(0x03040100u)
+        HD_SYM(0x04020100u)
+#undef HD_SYM
+        const int left = (int)bq - (int)(128u - msum);           // unread bits of the topmost dword after this iteration (>= -48)
+        q += (u32)((left >> 5) << 2);
+        bq = (u32)left & 31u;
+        ring[it] = word;
+    }
+    b.q = q; b.bq = bq;
+}
+
+DEV void hd_ring_put(u32* rg, int off, u32 w)
+{
+    const u32 j = (u32)off & (HD_IN_RING - 1);
+    rg[j >> 2] = w;
+    if (j < HD_IN_MIRROR) rg[(HD_IN_RING + j) >> 2] = w;
+}
+
+// ---- service wave: looks after HD_SRV_S streams (lane l keeps the books of stream s0 + l)
+DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
+{
+    const int myS = s0 + (lane < HD_SRV_S ? lane : 0);
+    HdCtl* const ctl = ctlAll + myS;
+    const unsigned long long inBits = ((unsigned long long)ctl->inHi << 32) | ctl->inLo;
+    const unsigned long long outBits = ((unsigned long long)ctl->outHi << 32) | ctl->outLo;
+    const int S32 = ctl->S32;
+    int validLo = ctl->initValidLo;
+    u32 flushed = 0;
+    bool live = lane < HD_SRV_S && myS < nStreams && !(ctl->pubPofs >> 31);
+    const int half = lane >> 5, l32 = lane & 31;             // input refills: 32 lanes per stream, two streams per instruction
+
+    // initial fill: both chunks of every live stream (the topmost dword may straddle the end of the stream), then publish
+    {   const unsigned long long am = __ballot(live);
+#pragma unroll
+        for (int l = 0; l < HD_SRV_S; ++l) {
+            if (!((am >> l) & 1ull)) continue;               // uniform
+            const int vlo = __shfl(validLo, l, WAVE), Sg = __shfl(S32, l, WAVE);
+            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
+            u32* const rg = (u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX);
+            const int off = vlo + 4 * lane;                  // 64 lanes x 4 bytes = the whole ring
+            if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); hd_ring_put(rg, off, w); }
+            else if (off >= 0 && off < Sg) {
+                u32 w = 0;
+                for (int i = 0; i < 3; ++i) if (off + i < Sg) w |= (u32)ig[off + i] << (8 * i);
+                hd_ring_put(rg, off, w);
+            }
+        }
+        if (live) hd_store(&ctl->srvValidLo, validLo);
     }
 
-__global__ __launch_bounds__(HUF_DEC_THREADS) void k_huf_decode(HufDecArgs a)
+    u32 pend[HD_SRV_S / 2];
+    u32 outw[HD_SRV_S];
+#pragma unroll
+    for (int l = 0; l < HD_SRV_S / 2; ++l) pend[l] = 0;
+#pragma unroll
+    for (int l = 0; l < HD_SRV_S; ++l) outw[l] = 0;
+    for (;;) {
+        u32 pp = 0x80000000u, it = flushed;
+        if (live) { pp = hd_load(&ctl->pubPofs); it = hd_load(&ctl->pubIters); }   // finished flag before the count it guards
+        const bool fin = (pp >> 31) != 0;
+        const int P = (int)(pp & 0x7FFFFFFFu);
+        const u32 avail = it - flushed;
+        const bool wantFlush = live && (avail >= HD_OUT_RING / 2 || (fin && avail > 0));
+        // the chunk [validLo-128, validLo) lands on the ring bytes of [validLo+128, validLo+256): the decoder must be below
+        const bool wantFill = live && !fin && validLo > 0 && P + 4 <= validLo + HD_IN_CHUNK;
+        const unsigned long long fm = __ballot(wantFlush), rm = __ballot(wantFill);
+        if (live && fin && avail == 0) live = false;
+        if (!(fm | rm)) {
+            if (!__any(live)) break;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        // (1) request input chunks: streams 2p and 2p+1 of this wave share one load instruction (32 lanes each)
+#pragma unroll
+        for (int p = 0; p < HD_SRV_S / 2; ++p) {
+            if (!((rm >> (2 * p)) & 3ull)) continue;         // uniform
+            const int l = 2 * p + half;
+            const bool on = (rm >> l) & 1ull;
+            const int off = __shfl(validLo, l, WAVE) - HD_IN_CHUNK + 4 * l32;
+            const int Sg = __shfl(S32, l, WAVE);
+            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
+            u32 w = 0;
+            if (on && off >= 0 && off + 4 <= Sg) __builtin_memcpy(&w, ig + off, 4);
+            pend[p] = w;
+        }
+        // (2) read the output words of every stream with enough of them
+#pragma unroll
+        for (int l = 0; l < HD_SRV_S; ++l) {
+            if (!((fm >> l) & 1ull)) continue;               // uniform
+            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl = (u32)__shfl((int)flushed, l, WAVE);
+            const u32* const og = (const u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX + HD_IN_RING + HD_IN_MIRROR);
+            if ((u32)lane < cnt) outw[l] = og[(fl + lane) & (HD_OUT_RING - 1)];
+        }
+        // (3) install the input chunks and publish them
+#pragma unroll
+        for (int p = 0; p < HD_SRV_S / 2; ++p) {
+            if (!((rm >> (2 * p)) & 3ull)) continue;         // uniform
+            const int l = 2 * p + half;
+            const bool on = (rm >> l) & 1ull;
+            const int nlo = __shfl(validLo, l, WAVE) - HD_IN_CHUNK;
+            if (on) hd_ring_put((u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX), nlo + 4 * l32, pend[p]);
+        }
+        if (wantFill) { validLo -= HD_IN_CHUNK; hd_store(&ctl->srvValidLo, validLo); }
+        // (4) the output words are in registers: hand the slots back, then store them (256-byte rows)
+        if (wantFlush) hd_store(&ctl->srvFlushed, it);
+#pragma unroll
+        for (int l = 0; l < HD_SRV_S; ++l) {
+            if (!((fm >> l) & 1ull)) continue;               // uniform
+            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl = (u32)__shfl((int)flushed, l, WAVE);
+            u8* const og = (u8*)(uintptr_t)__shfl(outBits, l, WAVE) + 4ull * fl;
+            if ((u32)lane < cnt) __builtin_memcpy(og + 4u * lane, &outw[l], 4);
+        }
+        if (wantFlush) flushed = it;
+    }
+}
+
+// LDS: G tables (2-byte cells, 1 << HD_SLOT_LOG of them) | HdCtl[4 * HD_MAXG] | per stream: input ring (256 + 16 B), output ring (64 x 4 B)
+__global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const u32 tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t first = (size_t)blockIdx.x * a.G;
+    u8* const lds8 = (u8*)lds;
+    const u32 tabStride = 2u << HD_SLOT_LOG;
+    HdCtl* const ctlAll = (HdCtl*)(lds8 + (size_t)a.G * tabStride);
+    u8* const aux = (u8*)ctlAll + 4 * HD_MAXG * sizeof(HdCtl);
+    const int nStreams = 4 * a.G;
 
-    for (int g = 0; g < a.G; ++g) {                  // stage X1 tables: uniform control flow, coalesced
+    // ---- stage the X1 tables: reference cells {byte, nbBits} -> {byte, 32 - nbBits} (uniform control flow, all waves).
+    //      Tables that do not fit the slot (tableLog 12) stay in global memory and are decoded by the literal path.
+    for (int g = 0; g < a.G; ++g) {
         const size_t b = first + g;
         if (b >= a.nBlocks) break;
         if (a.meta && a.meta[b].state == 0) continue;
         const u32* t = a.dtables + b * a.dtStrideU32;
         const u32 desc = t[0];
         const u32 tl = (desc >> 16) & 0xFFu;
-        if (tl > a.maxTableLog || ((desc >> 8) & 0xFFu) != 0) continue;
-        const u32 words = 1 + (tl ? (1u << (tl - 1)) : 1u);
-        u32* s = lds + (size_t)g * a.slotU32;
-        for (u32 i = tid; i < words; i += blockDim.x) s[i] = t[i];
+        if (tl > a.maxTableLog || tl > HD_SLOT_LOG || tl < 1 || ((desc >> 8) & 0xFFu) != 0) continue;
+        const u32 words = 1u << (tl - 1);                        // two cells per word
+        u32* s = (u32*)(lds8 + (size_t)g * tabStride);
+        for (u32 i = tid; i < words; i += HD_THREADS) {
+            const u32 w = t[1 + i];                              // cells: byte | nbBits << 8, twice
+            s[i] = (w & 0x00FF00FFu) | ((0x20002000u - (w & 0xFF00FF00u)) & 0xFF00FF00u);
+        }
     }
     __syncthreads();
-    const u32 g = tid >> 2, k = tid & 3u;            // block slot, stream
+
+    // ---- per-stream set-up by the decoder wave: lane 4g+k = stream k of block first+g
+    const u32 g = (u32)lane >> 2, k = (u32)lane & 3u;
     const size_t b = first + g;
-    const bool live = (int)g < a.G && b < a.nBlocks && !(a.meta && a.meta[b].state == 0);
+    const bool live = wave == 0 && (int)g < a.G && b < a.nBlocks && !(a.meta && a.meta[b].state == 0);
 
     size_t ierr = 0;                                 // BIT_initDStream error of my stream (0 = none)
-    int endBad = 0;                                  // my stream did not end exactly
     size_t blockErr = 0;                             // errors detected before any stream is touched
     size_t dstSize = 0;
+    u32 dtLog = 0;
+    const u8* sp = nullptr; u8* out = nullptr;
+    size_t oStart = 0; long cnt = 0;
+    BitReader r; r.base = nullptr; r.size = 0; r.at = 0; r.win = 0; r.used = 0;
+    bool streamOk = false;                           // the stream was initialised and has to be decoded
+    const u16* gcells = nullptr;
     if (live) {
-        u32 hdr = a.meta ? a.meta[b].hdrSize : 0;
-        const u32 desc = a.dtables[b * a.dtStrideU32];
-        const u32 dtLog = (desc >> 16) & 0xFFu;
+        const u32 hdr = a.meta ? a.meta[b].hdrSize : 0;
+        const u32* const gt = a.dtables + b * a.dtStrideU32;
+        const u32 desc = gt[0];
+        dtLog = (desc >> 16) & 0xFFu;
+        gcells = (const u16*)(gt + 1);
         const u8* const in = view_ptr(a.csrc, b) + hdr;
         const size_t cSize = view_size(a.csrc, b) - hdr;
         dstSize = view_size(a.dstSizes, b);
-        u8* const out = a.dst + b * a.dstStride;
+        out = a.dst + b * a.dstStride;
         if (((desc >> 8) & 0xFFu) != 0) blockErr = FERR(GENERIC);                       // X2 table: huf_decompress.c:411-412
         else if (dtLog > a.maxTableLog) blockErr = FERR(tableLog_tooLarge);
         else if (cSize < 10) blockErr = FERR(corruption_detected);                      // :269
@@ -80,60 +261,85 @@ __global__ __launch_bounds__(HUF_DEC_THREADS) void k_huf_decode(HufDecArgs a)
                 const size_t seg = (dstSize + 3) / 4;
                 const size_t sStart = 6 + (k > 0 ? l1 : 0) + (k > 1 ? l2 : 0) + (k > 2 ? l3 : 0);
                 const size_t sLen = k == 0 ? l1 : k == 1 ? l2 : k == 2 ? l3 : l4;
-                const u8* const sp = in + sStart;
-                const size_t oStart = (size_t)k * seg;
+                sp = in + sStart;
+                oStart = (size_t)k * seg;
                 const size_t oEndRaw = k < 3 ? oStart + seg : dstSize;                  // pEnd of this stream (:292-299)
-                long cnt = oEndRaw > oStart ? (long)(oEndRaw - oStart) : 0;             // symbols to regenerate
-                const u16* const cells = (const u16*)(lds + (size_t)g * a.slotU32 + 1);
-                BitReader r;
+                cnt = oEndRaw > oStart ? (long)(oEndRaw - oStart) : 0;                  // symbols to regenerate
                 const size_t e = r.init(sp, sLen);                                      // :304-307
-                if (is_err(e)) ierr = e;
-                else {
-                    long p = 0;
-                    // bulk: reloads are the fast ones while at >= 24; each iteration = reload + 4 symbols
-                    if (r.at >= 24 && cnt >= 4 && dtLog >= 1) {
-                        u64 at = r.at; u32 used = r.used; u64 win = r.win;
-                        u64 lo1 = ldg64u(sp + at - 8), lo2 = ldg64u(sp + at - 16);
-                        const u32 shIdx = 32u - dtLog;
-                        long groups = cnt >> 2;
-                        do {
-                            const u32 k8 = used & ~7u;
-                            at -= used >> 3; used &= 7;
-                            win = (win << k8) | ((lo1 >> 1) >> (63 - k8));
-                            lo1 = (lo1 << k8) | ((lo2 >> 1) >> (63 - k8));
-                            lo2 = ldg64u(sp + at - 16);
-                            u64 t = win << used;
-                            u32 word = 0;
-                            HUF_BULK_STEP(0x03020104u)                                  // byte k <- c.byte0 (perm index 4)
-                            HUF_BULK_STEP(0x03020400u)
-                            HUF_BULK_STEP(0x03040100u)
-                            HUF_BULK_STEP(0x04020100u)
-                            const size_t o = oStart + (size_t)p;
-                            if (o + 4 <= dstSize) __builtin_memcpy(out + o, &word, 4);
-                            else for (u32 q = 0; q < 4; ++q) if (o + q < dstSize) out[o + q] = (u8)(word >> (8 * q));
-                            p += 4; --groups;
-                        } while (at >= 24 && groups > 0);
-                        r.at = (size_t)at; r.used = used; r.win = win;
-                    }
-                    // literal: HUF_decodeStreamX1 (:214-237)
-                    while ((r.reload() == BR_UNFINISHED) & (p < cnt - 3)) {
-                        for (u32 q = 0; q < 4; ++q) { const u32 sym = hufx1_step(r, cells, dtLog); if (oStart + p < dstSize) out[oStart + p] = (u8)sym; ++p; }
-                    }
-                    while (p < cnt) { const u32 sym = hufx1_step(r, cells, dtLog); if (oStart + p < dstSize) out[oStart + p] = (u8)sym; ++p; }
-                    if (!(r.at == 0 && r.used == 64)) endBad = 1;                       // BIT_endOfDStream, :348-349
-                }
+                if (is_err(e)) ierr = e; else streamOk = true;
             }
         }
     }
+    // bulk: iterations whose reload is certainly the fast one; 4 symbols each, all inside the stream's output range
+    const bool inLds = dtLog >= 1 && dtLog <= HD_SLOT_LOG;
+    bool can = streamOk && inLds && r.at >= 24 + 6 * HD_PHASE + 8 && cnt / 4 >= HD_PHASE && r.size < (1ull << 31)
+               && oStart + (size_t)cnt <= dstSize;      // (degenerate tiny blocks whose segments overhang go bytewise)
+    HdBulk bs; bs.q = 0; bs.bq = 0;
+    long groups = 0;
+    u32 iters = 0;
+    int validLo = 0;
+    if (can) {
+        const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the stream
+        bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
+        groups = cnt >> 2;
+        validLo = ((int)bs.q + 8 - 124) & ~127;                  // P - validLo in [124, 252): ring reaches up to P + 4 and down to P - 8 - 6*HD_PHASE
+    }
+    HdCtl* const ctl = ctlAll + lane;
+    if (wave == 0) {
+        ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
+        ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
+        ctl->initValidLo = validLo; ctl->S32 = (int)(r.size < (1ull << 31) ? r.size : 0);
+        const unsigned long long ib = (unsigned long long)(uintptr_t)sp, ob = (unsigned long long)(uintptr_t)(out + oStart);
+        ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32);
+    }
+    __syncthreads();
+    if (wave >= 1) { hd_service(nStreams, aux, ctlAll, lane, (wave - 1) * HD_SRV_S); return; }
+
+    __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
+    const u16* const T = (const u16*)(lds8 + (size_t)((int)g < a.G ? g : 0) * tabStride);
+    const u8* const myIn = aux + (size_t)lane * HD_STREAM_AUX;
+    u32* const myOut = (u32*)(aux + (size_t)lane * HD_STREAM_AUX + HD_IN_RING + HD_IN_MIRROR);
+    const u32 idxShift = 32u - dtLog;
+    while (__any(can)) {
+        bool ready = false;
+        if (can) {
+            const u32 fl = hd_load(&ctl->srvFlushed);
+            const int vlo = hd_load(&ctl->srvValidLo);
+            ready = (iters + HD_PHASE - fl <= HD_OUT_RING) && ((int)bs.q - 6 * HD_PHASE >= vlo);
+        }
+        if (ready) {
+            hd_bulk_phase(bs, T, idxShift, myIn, myOut + (iters & (HD_OUT_RING - 1)));
+            iters += HD_PHASE; groups -= HD_PHASE;
+            can = bs.q >= 24u + 6u * HD_PHASE && groups >= HD_PHASE;
+            hd_store(&ctl->pubIters, iters);
+            hd_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+        }
+        if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
+    }
+    int endBad = 0;                                  // my stream did not end exactly
+    if (streamOk) {
+        long p = 4 * (long)iters;
+        if (iters) {                                 // back to the reference's (ptr, bitsConsumed, container) after a reload
+            const u32 B = 8u * (bs.q + 8u) + bs.bq;
+            r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(sp + r.at);
+        }
+        u8* const o = out + oStart;
+        // literal: HUF_decodeStreamX1 (:214-237) on the reference cells
+        while ((r.reload() == BR_UNFINISHED) & (p < cnt - 3)) {
+            for (u32 q4 = 0; q4 < 4; ++q4) { const u32 sym = hufx1_step(r, gcells, dtLog); if (oStart + p < dstSize) o[p] = (u8)sym; ++p; }
+        }
+        while (p < cnt) { const u32 sym = hufx1_step(r, gcells, dtLog); if (oStart + p < dstSize) o[p] = (u8)sym; ++p; }
+        if (!(r.at == 0 && r.used == 64)) endBad = 1;                                   // BIT_endOfDStream, :348-349
+    }
     // combine the four streams of a block: all four inits come first and the first failing one is returned
     // (:304-307); otherwise every stream must have ended exactly (:348-349).  All lanes take part in the shuffles.
-    const u32 lane = tid & 63u, base4 = lane & ~3u;
+    const u32 base4 = (u32)lane & ~3u;
     size_t res = 0;
     int anyEnd = 0;
 #pragma unroll
-    for (u32 q = 0; q < 4; ++q) {
-        const unsigned long long iq = __shfl((unsigned long long)ierr, (int)(base4 + q), WAVE);
-        const int eq = __shfl(endBad, (int)(base4 + q), WAVE);
+    for (u32 q4 = 0; q4 < 4; ++q4) {
+        const unsigned long long iq = __shfl((unsigned long long)ierr, (int)(base4 + q4), WAVE);
+        const int eq = __shfl(endBad, (int)(base4 + q4), WAVE);
         if (res == 0 && iq != 0) res = (size_t)iq;
         anyEnd |= eq;
     }
@@ -147,22 +353,28 @@ __global__ __launch_bounds__(HUF_DEC_THREADS) void k_huf_decode(HufDecArgs a)
     }
 }
 
+static int huf_decode_G(size_t ldsBytes)
+{
+    const size_t perBlock = (2u << HD_SLOT_LOG) + 4 * HD_STREAM_AUX;
+    int g = (int)((ldsBytes - 4 * HD_MAXG * sizeof(HdCtl)) / perBlock);
+    return g > HD_MAXG ? HD_MAXG : g;
+}
+
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     static bool attrSet = false;
-    const size_t ldsBytes = 80 * 1024;
+    const size_t ldsBytes = 80 * 1024;               // two workgroups per CU
     if (!attrSet) {
         hipError_t e = hipFuncSetAttribute((const void*)k_huf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) return e;
         attrSet = true;
     }
-    a.slotU32 = (1 + (1u << (a.maxTableLog - 1))) | 1u;
-    a.G = (int)(ldsBytes / (a.slotU32 * 4));
-    if (a.G > HUF_DEC_THREADS / 4) a.G = HUF_DEC_THREADS / 4;
+    a.G = huf_decode_G(ldsBytes);
+    a.slotU32 = 0;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
     probe_before(PK_HUF_DECODE, s);
-    hipLaunchKernelGGL(k_huf_decode, dim3((unsigned)groups), dim3(HUF_DEC_THREADS), ldsBytes, s, a);
+    hipLaunchKernelGGL(k_huf_decode, dim3((unsigned)groups), dim3(HD_THREADS), ldsBytes, s, a);
     probe_after(PK_HUF_DECODE, s);
     return hipGetLastError();
 }
