@@ -79,6 +79,7 @@ template <bool NB0, bool FAST>
 DEV void fse_bulk_phase(BulkState& b, u32 tabOff, u32 myIn, uint2* ring)
 {
     u32 s1 = b.s1, s2 = b.s2, q = b.q, bq = b.bq;
+    uint2 prev = make_uint2(0, 0);
 #pragma unroll 2
     for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
         const u32 c1 = lds_cell(s1), c2 = lds_cell(s2);
@@ -101,7 +102,8 @@ DEV void fse_bulk_phase(BulkState& b, u32 tabOff, u32 myIn, uint2* ring)
         const int left = (int)bq - (int)(s12 + nb3 + nb4);       // unread bits of dword dp after this iteration (>= -48)
         q += (u32)((left >> 5) << 2);                            // arithmetic shift: 0, -1 or -2 dwords
         bq = (u32)left & 31u;
-        ring[it] = rec;
+        // records leave in pairs (one 16-byte LDS write per two iterations: LDS instructions are what a lone wave pays for)
+        if (it & 1) *(uint4*)(ring + it - 1) = make_uint4(prev.x, prev.y, rec.x, rec.y); else prev = rec;
     }
     b.s1 = s1; b.s2 = s2; b.q = q; b.bq = bq;
 }
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 
 static void fse_decode_geometry(unsigned maxTableLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
-    *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 8) / 4;   // rings (+8: rotating banks)
+    *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
     int g = (int)((ldsBytes - FSE_CTL_BYTES) / ((2u << maxTableLog) + *slotU32 * 4));
     if (g > FSE_MAXG) g = FSE_MAXG;
     if (const char* dbg = getenv("FSEHIP_DEBUG_G")) { int v = atoi(dbg); if (v >= 1 && v < g) g = v; }   // tuning aid

@@ -43,11 +43,13 @@ __global__ void iter4(const uint32_t* init, uint32_t* out, long long* cyc, int i
     uint32_t s1 = tab, s2 = tab + 64, thi = 0x9E3779B9u * (threadIdx.x + 1), tlo = thi * 7u, q = 1000;
 #define CELL(a) (*(lp)(uintptr_t)(base + ((a) & 0xFFFEu)))
 #define LINK(c, st, t, nb) { nb = ((c) >> 12) | 1u; const uint32_t bits = __builtin_amdgcn_ubfe(t, 32u - nb, nb); st = (bits << 1) + (((c) & 0xFFEu) | tab); }
+    uint2 pf = make_uint2(1, 2);
     uint32_t c1 = CELL(s1), c2 = CELL(s2);
     long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
         uint32_t n0 = 0, n1 = 0;
-        if (EXTRA) { const lp32 np = (lp32)(uintptr_t)(base + 61440u + (q & 508u)); n0 = np[0]; n1 = np[1]; }
+        if (EXTRA == 1 || EXTRA == 3) { const lp32 np = (lp32)(uintptr_t)(base + 61440u + (q & 508u)); n0 = np[0]; n1 = np[1]; }
+        if (EXTRA == 2) { n0 = pf.x; n1 = pf.y; __builtin_memcpy(&pf, (const char*)init + threadIdx.x * 512 + (q & 255u), 8); }
         uint32_t nb1, nb2, nb3, nb4;
         const uint32_t rx = s1 | (s2 << 16);
         LINK(c1, s1, thi, nb1) const uint32_t c3 = CELL(s1);
@@ -58,7 +60,7 @@ __global__ void iter4(const uint32_t* init, uint32_t* out, long long* cyc, int i
         LINK(c4, s2, t3 << nb3, nb4) c2 = CELL(s2);
         const uint32_t cons = nb1 + nb2 + nb3 + nb4;
         thi = __builtin_amdgcn_alignbit(thi, tlo, cons & 31u) ^ n0; tlo = (tlo << 7) + n1 + cons; q += cons;
-        if (EXTRA) { typedef __attribute__((address_space(3))) uint32_t* lpw32; lpw32 wp2 = (lpw32)(uintptr_t)(base + 63488u + ((i & 63) << 3)); wp2[0] = rx; wp2[1] = ry; }
+        if (EXTRA == 1 || EXTRA == 2 || EXTRA == 4) { typedef __attribute__((address_space(3))) uint32_t* lpw32; lpw32 wp2 = (lpw32)(uintptr_t)(base + 63488u + ((i & 63) << 3)); wp2[0] = rx; wp2[1] = ry; }
     }
     long long t1 = __builtin_readcyclecounter();
     out[threadIdx.x] = s1 + s2 + thi;
@@ -88,12 +90,15 @@ int main()
             }
             printf("mode %d lanes %2d : %.1f s_memtime units / link, %.1f ns / link\n", mode, lanes, (double)cy / iters, ms * 1e6 / iters);
         }
-    for (int extra = 0; extra < 2; ++extra)
-        for (int lanes : {1, 15}) {
+    for (int extra = 0; extra < 5; ++extra)
+        for (int lanes : {15}) {
             long long cy = 0; float ms = 0;
-            for (int rep = 0; rep < 2; ++rep) {
+            for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
-                if (extra) hipLaunchKernelGGL(iter4<1>, dim3(1), dim3(64), 65536, 0, d, o, c, iters, lanes);
+                if (extra == 4) hipLaunchKernelGGL(iter4<4>, dim3(1), dim3(64), 65536, 0, d, o, c, iters, lanes);
+                else if (extra == 3) hipLaunchKernelGGL(iter4<3>, dim3(1), dim3(64), 65536, 0, d, o, c, iters, lanes);
+                else if (extra == 2) hipLaunchKernelGGL(iter4<2>, dim3(1), dim3(64), 65536, 0, d, o, c, iters, lanes);
+                else if (extra) hipLaunchKernelGGL(iter4<1>, dim3(1), dim3(64), 65536, 0, d, o, c, iters, lanes);
                 else hipLaunchKernelGGL(iter4<0>, dim3(1), dim3(64), 65536, 0, d, o, c, iters, lanes);
                 hipEventRecord(e1); hipDeviceSynchronize();
                 hipEventElapsedTime(&ms, e0, e1);
