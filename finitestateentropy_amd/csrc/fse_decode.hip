@@ -20,7 +20,6 @@
 //     bytes above the stream start, where every reload is the "fast" one (:378-388) and (ptr, bitsConsumed) are a
 //     function of the absolute bit position alone.
 #include "internal.h"
-#include <stdlib.h>
 
 #include "bitreader.h"
 
@@ -461,7 +460,6 @@ static void fse_decode_geometry(unsigned maxTableLog, size_t ldsBytes, unsigned*
     *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
     int g = (int)((ldsBytes - FSE_CTL_BYTES) / ((2u << maxTableLog) + *slotU32 * 4));
     if (g > FSE_MAXG) g = FSE_MAXG;
-    if (const char* dbg = getenv("FSEHIP_DEBUG_G")) { int v = atoi(dbg); if (v >= 1 && v < g) g = v; }   // tuning aid
     *G = g;
 }
 #define FSE_DEC_LDS (80 * 1024)   // two workgroups per CU (measured: 2 x 80 KiB are co-resident on gfx950)
@@ -477,8 +475,7 @@ hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     static bool attrSet = false;
-    size_t ldsBytes = FSE_DEC_LDS;
-    if (const char* dbg = getenv("FSEHIP_DEBUG_LDS")) ldsBytes = (size_t)atoi(dbg);   // tuning aid
+    const size_t ldsBytes = FSE_DEC_LDS;
     if (!attrSet) {
         hipError_t e = hipFuncSetAttribute((const void*)k_fse_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fse_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
