@@ -54,7 +54,7 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decTiming(uns
 #else
 #define TIMING(x)
 #endif
-struct BulkState { u32 s1, s2, q, bq; };
+struct BulkState { u32 s, q, bq; };     // this lane's state (cell address) and the pair's bit cursor
 
 // One symbol of the bulk loop.  The decoder lane keeps its two states as LDS byte addresses of their table cells.
 //   FAST (maxTableLog <= 11): cell = 2*newState (12 bits) | nbBits << 12 and the tables sit on table-size aligned LDS
@@ -73,38 +73,51 @@ DEV void fse_bulk_sym(u32 c, u32& sA, u32 t, u32& nb, u32 tabOff)
     else      sA = ((((c & 0xFFFu) | bits)) << 1) + tabOff;
 }
 
-// One phase = FSE_CHECK_EVERY iterations for one lane, registers + LDS only.
+DEV u32 dpp_swap(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // value of the neighbour lane (quad_perm [1,0,3,2])
+
+// One phase = FSE_CHECK_EVERY iterations, registers + LDS only.
+// A lone wave pays for every LDS *instruction* (they hardly overlap within a wave), so a block is walked by a pair of
+// lanes: lane A (even) owns state 1, lane B (odd) owns state 2.  One ds_read then fetches the cells of both states, one
+// ds_read2 the four window dwords (two per lane), one ds_write the states both lanes decoded from; what the other lane
+// needs (the neighbour's cell for its bit count, the window dwords) moves through DPP, which costs a VALU slot.
+// Both lanes keep identical copies of the bit cursor (q, bq).  maskB = all ones in lane B: its symbol's bits come
+// after lane A's.
 template <bool NB0, bool FAST>
-DEV void fse_bulk_phase(BulkState& b, u32 tabOff, u32 myIn, uint2* ring)
+DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn, u32 half, u32 maskB, uint2* ringMine)
 {
-    u32 s1 = b.s1, s2 = b.s2, q = b.q, bq = b.bq;
-    uint2 prev = make_uint2(0, 0);
+    u32 s = sMine, q = qRef, bq = bqRef;
+    u32 prev = 0;
 #pragma unroll 2
     for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
-        const u32 c1 = lds_cell(s1), c2 = lds_cell(s2);
-        const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (q & (FSE_IN_RING - 4)));
-        const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        const u32 c = lds_cell(s);                               // lane A: state 1's cell, lane B: state 2's
+        const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (q & (FSE_IN_RING - 4)) + 8u * half);
+        const u32 x0 = wp[0], x1 = wp[1];                        // lane A: window dwords d0, d1; lane B: d2, (d3)
+        const u32 o0 = dpp_swap(x0), o1 = dpp_swap(x1);
+        const u32 d0 = half ? o0 : x0, d1 = half ? o1 : x1, d2 = half ? x0 : o0;
         const u32 thi = __builtin_amdgcn_alignbit(d2, d1, bq), tlo = __builtin_amdgcn_alignbit(d1, d0, bq);
-        uint2 rec;
-        rec.x = __builtin_amdgcn_perm(s2, s1, 0x05040100u);      // low 16 bits of both cell addresses
-        u32 nb1, nb2, nb3, nb4;
-        fse_bulk_sym<FAST>(c1, s1, thi, nb1, tabOff);
-        const u32 c3 = lds_cell(s1);
-        fse_bulk_sym<FAST>(c2, s2, thi << nb1, nb2, tabOff);
-        const u32 c4 = lds_cell(s2);
-        const u32 s12 = nb1 + nb2;
+        const u32 cO = dpp_swap(c);
+        const u32 nbM = c >> 12, nbO = cO >> 12;
+        const u32 sStart = s;
+        {   const u32 t = thi << (nbO & maskB);
+            const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nbM, nbM);
+            s = FAST ? (bits << 1) + ((c & 0xFFFu) | tabOff) : ((((c & 0xFFFu) | bits)) << 1) + tabOff; }
+        const u32 c2 = lds_cell(s);
+        const u32 s12 = nbM + nbO;
         u32 t3 = __builtin_amdgcn_alignbit(thi, tlo, 32u - s12);
         if (NB0) t3 = s12 ? t3 : thi;
-        rec.y = __builtin_amdgcn_perm(s2, s1, 0x05040100u);
-        fse_bulk_sym<FAST>(c3, s1, t3, nb3, tabOff);
-        fse_bulk_sym<FAST>(c4, s2, t3 << nb3, nb4, tabOff);
-        const int left = (int)bq - (int)(s12 + nb3 + nb4);       // unread bits of dword dp after this iteration (>= -48)
+        const u32 rec = __builtin_amdgcn_perm(s, sStart, 0x05040100u);   // low 16 bits of the two cell addresses this lane decoded from
+        const u32 cO2 = dpp_swap(c2);
+        const u32 nbM2 = c2 >> 12, nbO2 = cO2 >> 12;
+        {   const u32 t = t3 << (nbO2 & maskB);
+            const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nbM2, nbM2);
+            s = FAST ? (bits << 1) + ((c2 & 0xFFFu) | tabOff) : ((((c2 & 0xFFFu) | bits)) << 1) + tabOff; }
+        const int left = (int)bq - (int)(s12 + nbM2 + nbO2);     // unread bits of dword dp after this iteration (>= -48)
         q += (u32)((left >> 5) << 2);                            // arithmetic shift: 0, -1 or -2 dwords
         bq = (u32)left & 31u;
-        // records leave in pairs (one 16-byte LDS write per two iterations: LDS instructions are what a lone wave pays for)
-        if (it & 1) *(uint4*)(ring + it - 1) = make_uint4(prev.x, prev.y, rec.x, rec.y); else prev = rec;
+        // two iterations per ring slot pair: this lane's half of slot pair (it >> 1) holds its states of both iterations
+        if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
     }
-    b.s1 = s1; b.s2 = s2; b.q = q; b.bq = bq;
+    sMine = s; qRef = q; bqRef = bq;
 }
 
 // Per-block control words in LDS: the decoder wave and the service wave of a workgroup talk through these only.
@@ -218,11 +231,14 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
             const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, l, WAVE);
             if ((u32)lane < cnt) {
-                const uint2 rec = ((const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff))[(fl_g + lane) & (FSE_DEC_RING - 1)];
+                // iteration i lives in slot pair (i >> 1): 16 bytes = lane A's {iteration 2p, 2p+1} words, then lane B's
+                const u32 ri = (fl_g + lane) & (FSE_DEC_RING - 1);
+                const u32* const rw = (const u32*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff) + 4u * (ri >> 1) + (ri & 1u);
+                uint2 rec; rec.x = rw[0]; rec.y = rw[2];      // x: state 1 before symbols 0 / 2, y: state 2 before symbols 1 / 3
                 // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+maxTableLog)
                 const u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.maxTableLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.maxTableLog);
                 const u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.maxTableLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.maxTableLog);
-                yq[l][0] = tg[x0 << symShift]; yq[l][1] = tg[x1 << symShift]; yq[l][2] = tg[x2 << symShift]; yq[l][3] = tg[x3 << symShift];
+                yq[l][0] = tg[x0 << symShift]; yq[l][2] = tg[x1 << symShift]; yq[l][1] = tg[x2 << symShift]; yq[l][3] = tg[x3 << symShift];
             }
         }
         // (3) install the input chunks and publish them
@@ -344,9 +360,12 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     const u32 badMask = flagsSh[0];
     const bool nb0 = flagsSh[1] != 0;
 
-    // ---- per-block set-up by the decoder wave (lane g owns block first+g)
-    const size_t b = first + (size_t)lane;
-    bool owner = wave == 0 && lane < a.G && b < a.nBlocks;
+    // ---- per-block set-up by the decoder wave: lanes 2g and 2g+1 walk block first+g together and both run this set-up
+    //      (identical values in both; only the even lane publishes, finishes the block and writes its result)
+    const int gsl = lane >> 1;
+    const u32 half = (u32)lane & 1u, maskB = half ? ~0u : 0u;
+    const size_t b = first + (size_t)gsl;
+    bool owner = wave == 0 && gsl < a.G && b < a.nBlocks;
     u32 hdr = 0;
     if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
     u32 tl = 0; bool fast = false;
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // table-size alignment of the FAST address arithmetic relies on
     const u32 ldsBase = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds8;
     if (ldsBase & (tabStride - 1)) __builtin_trap();
-    const u32 tabOff = ldsBase + (u32)(lane < a.G ? lane : 0) * tabStride;
+    const u32 tabOff = ldsBase + (u32)(gsl < a.G ? gsl : 0) * tabStride;
     const u16* const A = (const u16*)(lds8 + (tabOff - ldsBase));
     const u8* in = nullptr; size_t S = 0; u8* out = nullptr;
     const long omax = (long)a.dstCapacity;
@@ -391,8 +410,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // (>= 16 output groups left and the window stays >= 24 bytes above the stream start: at >= 24 + 16*6), so the
     // 16 iterations of a phase run without any per-iteration bookkeeping; whatever is left goes to the literal tail.
     // Bulk state uses p = at+1, u = used+8 (u in [8,16) after a reload), so no shift amount is ever 0 or 32.
-    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> lane) & 1u);
-    BulkState bs; bs.s1 = tabOff + 2u * s1; bs.s2 = tabOff + 2u * s2; bs.q = 0; bs.bq = 0;   // states as cell addresses
+    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> gsl) & 1u);
+    BulkState bs; bs.s = tabOff + 2u * (half ? s2 : s1); bs.q = 0; bs.bq = 0;   // my state as a cell address
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + 512)
@@ -404,8 +423,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         // read, P - 8 - 6*16 = P - 104
         validLo = ((int)bs.q + 8 - 232) & ~255;
     }
-    DecCtl* const ctl = ctlAll + (lane < FSE_MAXG ? lane : 0);
-    if (wave == 0 && lane < FSE_MAXG) {
+    DecCtl* const ctl = ctlAll + (gsl < FSE_MAXG ? gsl : 0);
+    if (wave == 0 && gsl < FSE_MAXG && half == 0) {
         ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S : 0);
@@ -416,8 +435,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     if (wave >= 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G); return; }
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
-    uint2* const myRing = (uint2*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + ringOff);
-    const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(lane < a.G ? lane : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
+    uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
+    const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
     TIMING(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
     while (__any(can)) {
         bool ready = false;
@@ -429,23 +448,26 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         }
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
-            if (nb0) fse_bulk_phase<true, FAST>(bs, tabOff, myIn, ring);
-            else     fse_bulk_phase<false, FAST>(bs, tabOff, myIn, ring);
+            if (nb0) fse_bulk_phase<true, FAST>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
+            else     fse_bulk_phase<false, FAST>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
             iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
             // the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
             can = bs.q >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
-            ctl_store(&ctl->pubIters, iters);
-            ctl_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+            if (half == 0) {
+                ctl_store(&ctl->pubIters, iters);
+                ctl_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+            }
         }
         TIMING({ const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB; })
         if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
     }
     TIMING(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[0] = tRun; t[1] = tWait; t[2] = nRun; t[3] = nWait; })
-    if (!owner) return;
+    const u32 sOther = dpp_swap(bs.s);               // (all lanes of the wave are still here)
+    if (!owner || half) return;
     op = 4 * (long)iters;
     if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container) after a reload
         const u32 B = 8u * (bs.q + 8u) + bs.bq;
-        r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s1 - tabOff) >> 1; s2 = (bs.s2 - tabOff) >> 1;
+        r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s - tabOff) >> 1; s2 = (sOther - tabOff) >> 1;
     }
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
