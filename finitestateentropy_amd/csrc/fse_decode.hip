@@ -87,14 +87,18 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
 {
     u32 s = sMine, q = qRef, bq = bqRef;
     u32 prev = 0;
+    (void)half;
+    // window {w2:w1:w0} = payload dwords at q+8, q+4, q in registers (both lanes identical); the two dwords below it are
+    // read at the top of every iteration so that the read is off the dependent chain, and the window slides by selects
+    u32 w0, w1, w2;
+    {   const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (q & (FSE_IN_RING - 4)));
+        w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; }
 #pragma unroll 2
     for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
         const u32 c = lds_cell(s);                               // lane A: state 1's cell, lane B: state 2's
-        const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (q & (FSE_IN_RING - 4)) + 8u * half);
-        const u32 x0 = wp[0], x1 = wp[1];                        // lane A: window dwords d0, d1; lane B: d2, (d3)
-        const u32 o0 = dpp_swap(x0), o1 = dpp_swap(x1);
-        const u32 d0 = half ? o0 : x0, d1 = half ? o1 : x1, d2 = half ? x0 : o0;
-        const u32 thi = __builtin_amdgcn_alignbit(d2, d1, bq), tlo = __builtin_amdgcn_alignbit(d1, d0, bq);
+        const lds_u32_ptr np = (lds_u32_ptr)(uintptr_t)(myIn + ((q - 8u) & (FSE_IN_RING - 4)));
+        const u32 n0 = np[0], n1 = np[1];                        // payload dwords at q-8, q-4
+        const u32 thi = __builtin_amdgcn_alignbit(w2, w1, bq), tlo = __builtin_amdgcn_alignbit(w1, w0, bq);
         const u32 cO = dpp_swap(c);
         const u32 nbM = c >> 12, nbO = cO >> 12;
         const u32 sStart = s;
@@ -112,6 +116,10 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
             const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nbM2, nbM2);
             s = FAST ? (bits << 1) + ((c2 & 0xFFFu) | tabOff) : ((((c2 & 0xFFFu) | bits)) << 1) + tabOff; }
         const int left = (int)bq - (int)(s12 + nbM2 + nbO2);     // unread bits of dword dp after this iteration (>= -48)
+        const bool k1 = left < 0, k2 = left < -32;               // the window slides down by one / two dwords
+        w2 = k2 ? w0 : (k1 ? w1 : w2);
+        w1 = k2 ? n1 : (k1 ? w0 : w1);
+        w0 = k2 ? n0 : (k1 ? n1 : w0);
         q += (u32)((left >> 5) << 2);                            // arithmetic shift: 0, -1 or -2 dwords
         bq = (u32)left & 31u;
         // two iterations per ring slot pair: this lane's half of slot pair (it >> 1) holds its states of both iterations
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             const u32 fl = ctl_load(&ctl->srvFlushed);
             const int vlo = ctl_load(&ctl->srvValidLo);
             // room for 16 more records, and the lowest byte this phase can read (p - 6*16 - 16) is in the ring
-            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - 6 * FSE_CHECK_EVERY >= vlo);
+            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - 6 * FSE_CHECK_EVERY - 8 >= vlo);
         }
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
