@@ -65,11 +65,16 @@ struct HdBulk { u32 q, bq; };      // q = byte offset of the lowest of the 3 win
 DEV void hd_bulk_phase(HdBulk& b, const u16* T, u32 idxShift, const u8* myIn, u32* ring)
 {
     u32 q = b.q, bq = b.bq;
+    // window {w2:w1:w0} = stream dwords at q+8, q+4, q in registers; the two dwords below it are read at the top of every
+    // iteration (off the dependent chain) and the window slides down by 0, 1 or 2 dwords through selects
+    u32 w0, w1, w2;
+    {   const u32* const wp = (const u32*)(myIn + (q & (HD_IN_RING - 4)));
+        w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; }
 #pragma unroll 2
     for (int it = 0; it < HD_PHASE; ++it) {
-        const u32* const wp = (const u32*)(myIn + (q & (HD_IN_RING - 4)));
-        const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
-        u32 thi = __builtin_amdgcn_alignbit(d2, d1, bq), tlo = __builtin_amdgcn_alignbit(d1, d0, bq);   // next 64 unread bits
+        const u32* const np = (const u32*)(myIn + ((q - 8u) & (HD_IN_RING - 4)));
+        const u32 n0 = np[0], n1 = np[1];                        // stream dwords at q-8, q-4
+        u32 thi = __builtin_amdgcn_alignbit(w2, w1, bq), tlo = __builtin_amdgcn_alignbit(w1, w0, bq);   // next 64 unread bits
         u32 word = 0, msum = 0;
 #define HD_SYM(SEL)                                                                        \
         {   const u32 c = T[thi >> idxShift];                                              \
@@ -83,6 +88,10 @@ DEV void hd_bulk_phase(HdBulk& b, const u16* T, u32 idxShift, const u8* myIn, u3
         HD_SYM(0x04020100u)
 #undef HD_SYM
         const int left = (int)bq - (int)(128u - msum);           // unread bits of the topmost dword after this iteration (>= -48)
+        const bool k1 = left < 0, k2 = left < -32;
+        w2 = k2 ? w0 : (k1 ? w1 : w2);
+        w1 = k2 ? n1 : (k1 ? w0 : w1);
+        w0 = k2 ? n0 : (k1 ? n1 : w0);
         q += (u32)((left >> 5) << 2);
         bq = (u32)left & 31u;
         ring[it] = word;
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the stream
         bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
         groups = cnt >> 2;
-        validLo = ((int)bs.q + 8 - 124) & ~127;                  // P - validLo in [124, 252): ring reaches up to P + 4 and down to P - 8 - 6*HD_PHASE
+        validLo = ((int)bs.q + 8 - 124) & ~127;                  // P - validLo in [124, 252): ring reaches up to P + 4 and down to P - 16 - 6*HD_PHASE
     }
     HdCtl* const ctl = ctlAll + lane;
     if (wave == 0) {
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         if (can) {
             const u32 fl = hd_load(&ctl->srvFlushed);
             const int vlo = hd_load(&ctl->srvValidLo);
-            ready = (iters + HD_PHASE - fl <= HD_OUT_RING) && ((int)bs.q - 6 * HD_PHASE >= vlo);
+            ready = (iters + HD_PHASE - fl <= HD_OUT_RING) && ((int)bs.q - 6 * HD_PHASE - 8 >= vlo);
         }
         if (ready) {
             hd_bulk_phase(bs, T, idxShift, myIn, myOut + (iters & (HD_OUT_RING - 1)));
