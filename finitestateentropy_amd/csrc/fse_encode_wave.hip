@@ -25,8 +25,8 @@
 
 // Warm-up symbols (half per chain) in front of every range.  Two states fed the same symbols merge with probability
 // ~ present/tableSize per step (sum_s p_s / norm_s), so the warm-up is sized as a multiple of tableSize/present.
-#define FSE_WV_WARM_FACTOR 26u
-#define FSE_WV_WARM_MIN 128u
+#define FSE_WV_WARM_FACTOR 4u
+#define FSE_WV_WARM_MIN 64u
 #define FSE_WV_WARM_MAX 4096u
 
 #define WV_STEP(ST, sym, nb)                                                                         \
