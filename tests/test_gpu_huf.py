@@ -196,3 +196,29 @@ def test_huf_full_size_roundtrip_config4(hip, oracle):
     out, dres = hip.huf_decompress_batch(dst, res, 32768)
     assert (dres.cpu().numpy() == 32768).all()
     assert torch.equal(out, src)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_huf_randomized_differential(hip, oracle, seed):
+    """One-shot Huff0 compress + decompress on blocks of assorted statistics and sizes: results and bytes identical to the
+    CPU oracle; decoding the oracle's streams regenerates the input (results 0 / 1 = stored raw / RLE by the caller)."""
+    from test_gpu_fse import _random_blocks
+    rng = np.random.default_rng(2000 + seed)
+    for size in (300, 2048, int(rng.integers(2049, 40000)), 65536, 131072):
+        for hl in (11, int(rng.choice([8, 9, 10, 12]))):
+            blocks = _random_blocks(rng, 24, size)
+            src = torch.from_numpy(blocks).cuda()
+            dst, res = hip.huf_compress_batch(src, table_log=hl)
+            dst, res = dst.cpu().numpy(), res.cpu().numpy()
+            _, ores, odst = oracle.compress_batch(1, blocks, table_log=hl)
+            for b in range(len(blocks)):
+                r = int(ores[b])
+                assert res[b] == s64(r), (seed, size, hl, b, res[b], r)
+                if not is_error(r) and r > 1:
+                    assert (dst[b][:r] == odst[b][:r]).all(), (seed, size, hl, b)
+            ok = np.array([(not is_error(int(r))) and int(r) > 1 for r in ores])
+            if ok.any():
+                d_c = torch.from_numpy(odst[ok]).cuda(); d_sz = torch.from_numpy(ores[ok].astype(np.int64)).cuda()
+                out, dres = hip.huf_decompress_batch(d_c, d_sz, size)
+                assert (dres.cpu().numpy() == size).all(), (seed, size, hl)
+                assert (out.cpu().numpy()[:, :size] == blocks[ok]).all(), (seed, size, hl)
