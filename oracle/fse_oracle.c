@@ -1152,3 +1152,135 @@ u64 orc_xxh64(const void* data, size_t len, u64 seed)
     h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
     return h;
 }
+
+
+/* =====================================================================================================
+ *  .fse frame: programs/fileio.c:266-432 (writer), :462-626 (reader), restated on memory buffers.
+ *  XXH32: public algorithm (xxhash by Y. Collet), one-shot form.
+ * ===================================================================================================== */
+static uint32_t rd32le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+uint32_t orc_xxh32(const void* data, size_t len, uint32_t seed)
+{
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const uint8_t* p = (const uint8_t*)data;
+    const uint8_t* const end = p + len;
+    uint32_t h;
+    if (len >= 16) {
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const uint8_t* const limit = end - 16;
+        do {
+            v1 = rotl32(v1 + rd32le(p) * P2, 13) * P1; p += 4;
+            v2 = rotl32(v2 + rd32le(p) * P2, 13) * P1; p += 4;
+            v3 = rotl32(v3 + rd32le(p) * P2, 13) * P1; p += 4;
+            v4 = rotl32(v4 + rd32le(p) * P2, 13) * P1; p += 4;
+        } while (p <= limit);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else h = seed + P5;
+    h += (uint32_t)len;
+    while (p + 4 <= end) { h = rotl32(h + rd32le(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; p++; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
+#define FRAME_MAGIC_FSE 0x183E2309u      /* fileio.c:121 */
+#define FRAME_MAGIC_HUF 0x183E3309u      /* fileio.c:122 */
+#define FRAME_MAX_BSID 6                 /* 64 KB blocks */
+enum { FBT_COMPRESSED = 0, FBT_RAW = 1, FBT_RLE = 2, FBT_CRC = 3 };   /* fileio.c:137 */
+
+static size_t orc_fse_compress_bound(size_t n) { return 512 + n + (n >> 7) + 4 + sizeof(size_t); }   /* FSE_COMPRESSBOUND, fse.h:290-292 */
+static size_t frame_block_size(unsigned id) { return (size_t)1024 << id; }   /* fileio.c:219 */
+
+size_t orc_frame_compress_bound(size_t srcSize, unsigned blockSizeId)
+{
+    const size_t bs = frame_block_size(blockSizeId);
+    const size_t nb = (srcSize + bs - 1) / bs;
+    return 5 + srcSize + 5 * nb + 3;      /* header, worst case raw blocks with 3..5-byte headers, end mark */
+}
+
+size_t orc_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec)
+{
+    uint8_t* const out = (uint8_t*)dst;
+    const uint8_t* const in = (const uint8_t*)src;
+    if (blockSizeId > FRAME_MAX_BSID) return ERR(GENERIC);
+    if (dstCapacity < orc_frame_compress_bound(srcSize, blockSizeId)) return ERR(dstSize_tooSmall);
+    const size_t bs = frame_block_size(blockSizeId);
+    const uint32_t magic = codec == 1 ? FRAME_MAGIC_HUF : FRAME_MAGIC_FSE;
+    size_t o = 0, pos = 0;
+    uint8_t* tmp = (uint8_t*)malloc(orc_fse_compress_bound(bs) + 8);
+    if (!tmp) return ERR(GENERIC);
+    out[0] = (uint8_t)magic; out[1] = (uint8_t)(magic >> 8); out[2] = (uint8_t)(magic >> 16); out[3] = (uint8_t)(magic >> 24);
+    out[4] = (uint8_t)blockSizeId; o = 5;                                        /* fileio.c:324-325 */
+    while (pos < srcSize) {
+        const size_t inSize = srcSize - pos < bs ? srcSize - pos : bs;
+        const size_t cap = orc_fse_compress_bound(bs);                            /* FSE_compressBound(inputBlockSize), :340 */
+        const size_t cSize = codec == 1 ? orc_huf_compress2(tmp, cap, in + pos, inSize, 255, 11)     /* HUF_compress */
+                                        : orc_fse_compress2(tmp, cap, in + pos, inSize, 255, 11);    /* FSE_compress */
+        const int full = inSize == bs;
+        if (orc_is_error(cSize)) { free(tmp); return cSize; }
+        if (cSize == 0 || cSize == 1) {                                           /* raw / rle, :347-379 */
+            const unsigned bt = cSize == 0 ? FBT_RAW : FBT_RLE;
+            if (full) out[o++] = (uint8_t)((bt << 6) + 0x20);
+            else { out[o++] = (uint8_t)(bt << 6); out[o++] = (uint8_t)(inSize >> 8); out[o++] = (uint8_t)inSize; }
+            if (cSize == 0) { memcpy(out + o, in + pos, inSize); o += inSize; }
+            else out[o++] = in[pos];
+        } else {                                                                  /* compressed, :381-401 */
+            if (full) out[o++] = (uint8_t)((FBT_COMPRESSED << 6) + 0x20);
+            else { out[o++] = (uint8_t)(FBT_COMPRESSED << 6); out[o++] = (uint8_t)(inSize >> 8); out[o++] = (uint8_t)inSize; }
+            out[o++] = (uint8_t)(cSize >> 8); out[o++] = (uint8_t)cSize;
+            memcpy(out + o, tmp, cSize); o += cSize;
+        }
+        pos += inSize;
+    }
+    {   const uint32_t checksum = (orc_xxh32(in, srcSize, 0) >> 5) & ((1u << 22) - 1);   /* :408-416 */
+        out[o++] = (uint8_t)((checksum >> 16) + (FBT_CRC << 6));
+        out[o++] = (uint8_t)(checksum >> 8);
+        out[o++] = (uint8_t)checksum;
+    }
+    free(tmp);
+    return o;
+}
+
+size_t orc_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    uint8_t* const out = (uint8_t*)dst;
+    const uint8_t* const in = (const uint8_t*)src;
+    size_t ip = 0, o = 0;
+    int codec;
+    if (srcSize < 5 + 3) return ERR(srcSize_wrong);
+    {   const uint32_t magic = rd32le(in);
+        if (magic == FRAME_MAGIC_FSE) codec = 0; else if (magic == FRAME_MAGIC_HUF) codec = 1; else return ERR(GENERIC);   /* :484-499 */
+    }
+    if (in[4] > FRAME_MAX_BSID) return ERR(GENERIC);                               /* :502-504 */
+    const size_t bs = frame_block_size(in[4]);
+    ip = 5;
+    for (;;) {
+        if (ip >= srcSize) return ERR(srcSize_wrong);
+        const unsigned b0 = in[ip++];
+        const unsigned bt = b0 >> 6;
+        size_t rSize = bs, cSize;
+        if (bt == FBT_CRC) {                                                       /* :600-606 */
+            if (ip + 2 > srcSize) return ERR(srcSize_wrong);
+            const uint32_t saved = in[ip + 1] + ((uint32_t)in[ip] << 8) + ((uint32_t)(b0 & 0x3F) << 16);
+            const uint32_t calc = (orc_xxh32(out, o, 0) >> 5) & ((1u << 22) - 1);
+            if (saved != calc) return ERR(corruption_detected);
+            return o;
+        }
+        if (!(b0 & 0x20)) { if (ip + 2 > srcSize) return ERR(srcSize_wrong); rSize = ((size_t)in[ip] << 8) + in[ip + 1]; ip += 2; }   /* :527-532 */
+        if (bt == FBT_COMPRESSED) { if (ip + 2 > srcSize) return ERR(srcSize_wrong); cSize = ((size_t)in[ip] << 8) + in[ip + 1]; ip += 2; }
+        else if (bt == FBT_RAW) cSize = rSize; else cSize = 1;
+        if (ip + cSize > srcSize) return ERR(srcSize_wrong);
+        if (bt == FBT_COMPRESSED) {
+            if (o + rSize > dstCapacity) return ERR(dstSize_tooSmall);
+            const size_t r = codec == 1 ? orc_huf_decompress(out + o, rSize, in + ip, cSize) : orc_fse_decompress(out + o, rSize, in + ip, cSize);   /* :570-573 */
+            if (orc_is_error(r)) return r;
+            o += r;
+        } else {
+            if (o + rSize > dstCapacity) return ERR(dstSize_tooSmall);
+            if (bt == FBT_RAW) memcpy(out + o, in + ip, rSize); else memset(out + o, in[ip], rSize);
+            o += rSize;
+        }
+        ip += cSize;
+    }
+}

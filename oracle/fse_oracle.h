@@ -67,6 +67,13 @@ double orc_compress_batch(int codec, const uint8_t* src, size_t srcStride, size_
 double orc_decompress_batch(int codec, const uint8_t* cSrc, size_t cStride, const uint64_t* cSizes, uint8_t* dst,
                             size_t dstStride, size_t dstSize, uint64_t* results, size_t nBlocks, int nthreads);
 
+/* ---- .fse frame (the container written by the reference's command-line tool, programs/fileio.c:266-285):
+ *      magic (LE32) | block-size id | { block header | block }* | 3-byte end mark with a 22-bit XXH32 of the content */
+size_t orc_frame_compress_bound(size_t srcSize, unsigned blockSizeId);
+size_t orc_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec /* 0 fse, 1 huf */);
+size_t orc_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+uint32_t orc_xxh32(const void* data, size_t len, uint32_t seed);
+
 /* XXH64 (public algorithm by Y. Collet; used only to check SURVEY Appendix B known-answer vectors) */
 uint64_t orc_xxh64(const void* data, size_t len, uint64_t seed);
 

@@ -278,6 +278,26 @@ class Oracle(_Base):
                                     t.ctypes.data_as(C.c_void_p), C.c_uint32(first_seed))
         return out
 
+    # ---- .fse frames (only the Oracle class restates them; the Ref class has the CLI binary, see ref_cli_*) -------
+    def frame_compress(self, src, block_size_id=5, codec=0):
+        src, ps = _u8(src)
+        cap = int(self._call("orc_frame_compress_bound", self.sz, self.sz(src.size), C.c_uint(block_size_id)))
+        out = np.zeros(cap + 8, dtype=np.uint8)
+        r = int(self._call("orc_frame_compress", self.sz, out.ctypes.data_as(self.vp), self.sz(cap), ps, self.sz(src.size),
+                           C.c_uint(block_size_id), C.c_int(codec)))
+        return r, out
+
+    def frame_decompress(self, frame, cap):
+        frame, pf = _u8(frame)
+        out = np.zeros(max(cap, 1) + 8, dtype=np.uint8)
+        r = int(self._call("orc_frame_decompress", self.sz, out.ctypes.data_as(self.vp), self.sz(cap), pf, self.sz(frame.size)))
+        return r, out
+
+    def xxh32(self, data, seed=0):
+        data, p = _u8(data)
+        self.lib.orc_xxh32.restype = C.c_uint32
+        return int(self.lib.orc_xxh32(p, C.c_size_t(data.size), C.c_uint32(seed)))
+
     def xxh64(self, data, seed=0):
         data, p = _u8(data)
         self.lib.orc_xxh64.restype = C.c_uint64

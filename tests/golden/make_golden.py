@@ -3,7 +3,8 @@
 Run in the build container (where /root/reference exists):   python tests/golden/make_golden.py
 The reference cannot travel to the GPU box, these vectors can.  Every vector is an output of the
 reference's own functions (FSE_compress2, HUF_compress2, FSE_normalizeCount, FSE_writeNCount,
-FSE_buildCTable, FSE_buildDTable, HUF_buildCTable, HUF_writeCTable, HUF_readDTableX1, HIST_count) on
+FSE_buildCTable, FSE_buildDTable, HUF_buildCTable, HUF_writeCTable, HUF_readDTableX1, HIST_count; frames from its
+command-line tool, programs/fileio.c) on
 probagen blocks (programs/probaGenerator.c restated in oracle/fse_oracle.c, checked against SURVEY
 Appendix B source hashes).
 """
@@ -65,6 +66,17 @@ def main():
             out["celt_%d" % i] = (celt[:msv + 1] & 0x00FFFFFF)
             out["hufhdr_%d" % i] = whdr[:whs].copy()
             out["hufdt_%d" % i] = hdt[:1 + (1 << mb)]
+    # .fse frames written by the reference's command-line tool (oracle/_ref/fse_cli): 2.5 blocks of P14 + an RLE block + noise
+    import subprocess, tempfile
+    rng = np.random.default_rng(1)
+    fsrc = np.concatenate([o.probagen_batch(14, 1, 81920, 21)[0], np.full(32768, 3, np.uint8), rng.integers(0, 256, 5000, dtype=np.uint8)])
+    cli = os.path.join(ROOT, "oracle", "_ref", "fse_cli")
+    with tempfile.TemporaryDirectory() as d:
+        fsrc.tofile(os.path.join(d, "in"))
+        for key, flag in (("frame_fse", "-fqq"), ("frame_huf", "-fqqh")):
+            subprocess.run([cli, flag, os.path.join(d, "in"), os.path.join(d, key)], check=True, capture_output=True)
+            out[key] = np.fromfile(os.path.join(d, key), dtype=np.uint8)
+    out["frame_src"] = fsrc
     out["meta"] = np.array(meta, dtype=np.uint64)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
     np.savez_compressed(path, **out)
