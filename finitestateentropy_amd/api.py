@@ -58,7 +58,8 @@ class FseHip:
                      "FSEHIP_HUF_decompress4X_usingDTable", "FSEHIP_HUF_decompress4X1_usingDTable",
                      "FSEHIP_HUF_compress", "FSEHIP_HUF_compress2", "FSEHIP_HUF_decompress",
                      "FSEHIP_FSE_compress_batch_workspaceSize", "FSEHIP_FSE_decompress_batch_workspaceSize",
-                     "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize"):
+                     "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize",
+                     "FSEHIP_frame_compressBound", "FSEHIP_frame_compress", "FSEHIP_frame_decompress"):
             if hasattr(L, name):
                 getattr(L, name).restype = SZ
         L.FSEHIP_getErrorName.restype = C.c_char_p
@@ -282,3 +283,23 @@ def _huf_methods():
 
 
 _huf_methods()
+
+
+def _frame_methods():
+    # .fse frames on host buffers (programs/fileio.c): FSEHIP_frame_compress / FSEHIP_frame_decompress
+    def frame_compress(self, src, block_size_id=5, codec=0, cap=None):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        self.lib.FSEHIP_frame_compressBound.restype = C.c_size_t
+        bound = int(self.lib.FSEHIP_frame_compressBound(SZ(src.size), C.c_uint(block_size_id)))
+        if cap is None:
+            cap = bound if bound < (1 << 62) else 16
+        return self._single("FSEHIP_frame_compress", cap, src, C.c_uint(block_size_id), C.c_int(codec))
+
+    def frame_decompress(self, frame, cap):
+        return self._single("FSEHIP_frame_decompress", cap, frame)
+
+    for f in (frame_compress, frame_decompress):
+        setattr(FseHip, f.__name__, f)
+
+
+_frame_methods()

@@ -1,0 +1,244 @@
+// frame.hip -- the .fse frame around the block codecs, on host buffers
+// (reference: programs/fileio.c:266-285 format, :286-432 writer, :462-626 reader).
+//
+//   frame = magic (LE32: 0x183E2309 FSE / 0x183E3309 Huff0) | block-size id (1 KB << id, id <= 6) |
+//           { block header | block }* | end mark: 3 bytes = type 3 + 22 bits of XXH32(content, seed 0) >> 5
+//   block header: byte0 = type << 6 (0 compressed, 1 raw, 2 RLE) | 0x20 if the block regenerates exactly the
+//           block size, else 2 bytes regenerated size (big endian) follow; compressed blocks add 2 bytes compressed size.
+//
+// The blocks are independent, so the writer codes all of them with one batched device call (FSE_compress /
+// HUF_compress semantics per block: result 0 -> stored raw, 1 -> RLE, as fileio.c:347-401 does) and assembles the frame on
+// the host; the reader parses the headers on the host, decodes every compressed block with one batched device call and
+// checks the content checksum.  Host side of the boundary: PCIe and host memory bandwidth bound, not a throughput path.
+#include "internal.h"
+#include <string.h>
+#include <stdlib.h>
+#include <thread>
+#include <vector>
+
+namespace {
+struct DevMem {
+    void* p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    ~DevMem() { if (p) (void)hipFree(p); }
+};
+#define FK(x) do { if ((x) != hipSuccess) return FSEHIP_ERROR(GENERIC); } while (0)
+struct HostMem {           // uninitialised host staging (a std::vector would zero-fill hundreds of megabytes)
+    u8* p = nullptr;
+    bool alloc(size_t n) { p = (u8*)malloc(n ? n : 1); return p != nullptr; }
+    ~HostMem() { free(p); }
+};
+// XXH32 of the content runs on its own host thread while the device codes the blocks
+struct Checksum {
+    u32 value = 0; std::thread th;
+    void start(const u8* p, size_t n);
+    u32 get() { if (th.joinable()) th.join(); return value; }
+    ~Checksum() { if (th.joinable()) th.join(); }
+};
+
+const u32 MAGIC_FSE = 0x183E2309u, MAGIC_HUF = 0x183E3309u;      // fileio.c:121-122
+const unsigned MAX_BSID = 6;
+enum { BT_COMPRESSED = 0, BT_RAW = 1, BT_RLE = 2, BT_CRC = 3 };  // fileio.c:137
+
+inline u32 rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+inline u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+// XXH32, one-shot (public algorithm; the reference streams the same function over the content, fileio.c:303,339,408)
+u32 xxh32(const u8* p, size_t len, u32 seed)
+{
+    const u32 P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const u8* const end = p + len;
+    u32 h;
+    if (len >= 16) {
+        u32 v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const u8* const limit = end - 16;
+        do {
+            v1 = rotl(v1 + rd32(p) * P2, 13) * P1; v2 = rotl(v2 + rd32(p + 4) * P2, 13) * P1;
+            v3 = rotl(v3 + rd32(p + 8) * P2, 13) * P1; v4 = rotl(v4 + rd32(p + 12) * P2, 13) * P1;
+            p += 16;
+        } while (p <= limit);
+        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+    } else h = seed + P5;
+    h += (u32)len;
+    while (p + 4 <= end) { h = rotl(h + rd32(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl(h + (*p) * P5, 11) * P1; ++p; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+void Checksum::start(const u8* p, size_t n) { th = std::thread([this, p, n] { value = (xxh32(p, n, 0) >> 5) & ((1u << 22) - 1); }); }
+inline size_t block_size(unsigned id) { return (size_t)1024 << id; }   // fileio.c:219
+inline size_t cbound(size_t n) { return FSEHIP_FSE_COMPRESSBOUND(n); }
+
+// one-shot block coder over `n` uniform blocks already on the device
+int code_blocks(int codec, void* d_dst, size_t stride, size_t* d_res, const void* d_src, size_t blockBytes, size_t n, DevMem& ws, size_t wsBytes)
+{
+    if (n == 0) return 0;
+    if (codec == 1) return FSEHIP_HUF_compress_batch(d_dst, stride, stride, d_res, d_src, blockBytes, nullptr, blockBytes, 255, FSEHIP_HUF_TABLELOG_DEFAULT, n, ws.p, wsBytes, nullptr);
+    return FSEHIP_FSE_compress_batch(d_dst, stride, stride, d_res, d_src, blockBytes, nullptr, blockBytes, 255, FSEHIP_FSE_DEFAULT_TABLELOG, n, ws.p, wsBytes, nullptr);
+}
+}   // namespace
+
+extern "C" size_t FSEHIP_frame_compressBound(size_t srcSize, unsigned blockSizeId)
+{
+    if (blockSizeId > MAX_BSID) return FSEHIP_ERROR(GENERIC);
+    const size_t bs = block_size(blockSizeId);
+    return 5 + srcSize + 5 * ((srcSize + bs - 1) / bs) + 3;
+}
+
+extern "C" size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec)
+{
+    if (blockSizeId > MAX_BSID || (codec != 0 && codec != 1)) return FSEHIP_ERROR(GENERIC);
+    if (dstCapacity < FSEHIP_frame_compressBound(srcSize, blockSizeId)) return FSEHIP_ERROR(dstSize_tooSmall);
+    u8* const out = (u8*)dst;
+    const u8* const in = (const u8*)src;
+    const size_t bs = block_size(blockSizeId);
+    const size_t nFull = srcSize / bs, tail = srcSize % bs, nBlocks = nFull + (tail ? 1 : 0);
+    const size_t stride = (cbound(bs) + 15) & ~(size_t)15;               // FSE_compressBound(inputBlockSize), fileio.c:340
+    std::vector<size_t> res(nBlocks);
+    HostMem comp;
+    size_t pitch = 0;                                                     // bytes kept per block on the host = the largest result
+    Checksum crc; crc.start(in, srcSize);
+    if (nBlocks) {
+        DevMem dsrc, ddst, dres, dws;
+        const size_t wsBytes = codec == 1 ? FSEHIP_HUF_compress_batch_workspaceSize(nFull ? nFull : 1)
+                                          : FSEHIP_FSE_compress_batch_workspaceSize(nFull ? nFull : 1, FSEHIP_FSE_DEFAULT_TABLELOG);
+        FK(dsrc.alloc(srcSize)); FK(ddst.alloc(nBlocks * stride)); FK(dres.alloc(nBlocks * sizeof(size_t))); FK(dws.alloc(wsBytes));
+        FK(hipMemcpy(dsrc.p, in, srcSize, hipMemcpyHostToDevice));
+        if (code_blocks(codec, ddst.p, stride, (size_t*)dres.p, dsrc.p, bs, nFull, dws, wsBytes)) return FSEHIP_ERROR(GENERIC);
+        if (tail && code_blocks(codec, (u8*)ddst.p + nFull * stride, stride, (size_t*)dres.p + nFull, (const u8*)dsrc.p + nFull * bs, tail, 1, dws, wsBytes))
+            return FSEHIP_ERROR(GENERIC);
+        FK(hipMemcpy(res.data(), dres.p, nBlocks * sizeof(size_t), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < nBlocks; ++b) if (!FSEHIP_isError(res[b]) && res[b] > pitch) pitch = res[b];
+        pitch = (pitch + 15) & ~(size_t)15;
+        if (pitch) {
+            if (!comp.alloc(nBlocks * pitch)) return FSEHIP_ERROR(GENERIC);
+            FK(hipMemcpy2D(comp.p, pitch, ddst.p, stride, pitch, nBlocks, hipMemcpyDeviceToHost));
+        }
+    }
+    size_t o = 0;
+    const u32 magic = codec == 1 ? MAGIC_HUF : MAGIC_FSE;
+    out[0] = (u8)magic; out[1] = (u8)(magic >> 8); out[2] = (u8)(magic >> 16); out[3] = (u8)(magic >> 24); out[4] = (u8)blockSizeId; o = 5;
+    for (size_t b = 0; b < nBlocks; ++b) {
+        const size_t inSize = b < nFull ? bs : tail;
+        const size_t cSize = res[b];
+        const bool full = inSize == bs;
+        if (FSEHIP_isError(cSize)) return cSize;                                   // fileio.c:341
+        const unsigned bt = cSize == 0 ? BT_RAW : cSize == 1 ? BT_RLE : BT_COMPRESSED;
+        if (full) out[o++] = (u8)((bt << 6) + 0x20);
+        else { out[o++] = (u8)(bt << 6); out[o++] = (u8)(inSize >> 8); out[o++] = (u8)inSize; }
+        if (bt == BT_RAW) { memcpy(out + o, in + b * bs, inSize); o += inSize; }
+        else if (bt == BT_RLE) out[o++] = in[b * bs];
+        else { out[o++] = (u8)(cSize >> 8); out[o++] = (u8)cSize; memcpy(out + o, comp.p + b * pitch, cSize); o += cSize; }
+    }
+    const u32 checksum = crc.get();                                               // fileio.c:408-416
+    out[o++] = (u8)((checksum >> 16) + (BT_CRC << 6)); out[o++] = (u8)(checksum >> 8); out[o++] = (u8)checksum;
+    return o;
+}
+
+extern "C" size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    u8* const out = (u8*)dst;
+    const u8* const in = (const u8*)src;
+    if (srcSize < 5 + 3) return FSEHIP_ERROR(srcSize_wrong);
+    int codec;
+    {   const u32 magic = rd32(in);
+        if (magic == MAGIC_FSE) codec = 0; else if (magic == MAGIC_HUF) codec = 1; else return FSEHIP_ERROR(GENERIC);   // fileio.c:484-499
+    }
+    if (in[4] > MAX_BSID) return FSEHIP_ERROR(GENERIC);                           // :502-504
+    const size_t bs = block_size(in[4]);
+
+    // ---- pass 1 (host): parse the block headers.  The first structural problem ends the walk with its error; the
+    //      blocks before it are still decoded, because a decoding error in an earlier block has precedence (the
+    //      reference reads and decodes sequentially).
+    struct Blk { unsigned bt; size_t rSize, cSize, at; };
+    std::vector<Blk> blocks;
+    size_t ip = 5, frameErr = 0;
+    u32 savedCrc = 0;
+    for (;;) {
+        if (ip >= srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; }
+        const unsigned b0 = in[ip++];
+        Blk k; k.bt = b0 >> 6; k.rSize = bs; k.cSize = 0; k.at = 0;
+        if (k.bt == BT_CRC) {
+            if (ip + 2 > srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; }
+            savedCrc = in[ip + 1] + ((u32)in[ip] << 8) + ((u32)(b0 & 0x3F) << 16);
+            break;
+        }
+        if (!(b0 & 0x20)) { if (ip + 2 > srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; } k.rSize = ((size_t)in[ip] << 8) + in[ip + 1]; ip += 2; }
+        if (k.bt == BT_COMPRESSED) { if (ip + 2 > srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; } k.cSize = ((size_t)in[ip] << 8) + in[ip + 1]; ip += 2; }
+        else k.cSize = k.bt == BT_RAW ? k.rSize : 1;
+        if (ip + k.cSize > srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; }
+        k.at = ip; ip += k.cSize;
+        blocks.push_back(k);
+    }
+
+    // ---- pass 2 (device): every compressed block in one batch per distinct capacity (full blocks together; the
+    //      reference passes the announced regenerated size as the capacity, fileio.c:570)
+    const size_t nB = blocks.size();
+    std::vector<size_t> result(nB, 0);                       // regenerated size or error, per block
+    std::vector<size_t> slot(nB, (size_t)-1);                // position in the device batch
+    std::vector<size_t> order;                               // compressed blocks, full ones first
+    for (size_t b = 0; b < nB; ++b) if (blocks[b].bt == BT_COMPRESSED && blocks[b].rSize == bs) order.push_back(b);
+    const size_t nFullC = order.size();
+    for (size_t b = 0; b < nB; ++b) if (blocks[b].bt == BT_COMPRESSED && blocks[b].rSize != bs) order.push_back(b);
+    const size_t nC = order.size();
+    HostMem regen;
+    size_t cStride = 16;
+    for (size_t i = 0; i < nC; ++i) if (blocks[order[i]].cSize > cStride) cStride = blocks[order[i]].cSize;
+    cStride = (cStride + 15) & ~(size_t)15;
+    const size_t oStride = bs;
+    // common case: every block is a full compressed one -> the regenerated blocks are contiguous and land in dst directly
+    const bool direct = nC == nB && nFullC == nB && nB * bs <= dstCapacity;
+    if (nC) {
+        HostMem stage;
+        if (!stage.alloc(nC * cStride)) return FSEHIP_ERROR(GENERIC);
+        std::vector<size_t> cs(nC), rs(nC), rr(nC);
+        for (size_t i = 0; i < nC; ++i) {
+            const Blk& k = blocks[order[i]];
+            slot[order[i]] = i; cs[i] = k.cSize; rs[i] = k.rSize;
+            memcpy(stage.p + i * cStride, in + k.at, k.cSize);
+        }
+        DevMem dc, dcs, drs, dout, dres, dws;
+        const size_t wsBytes = codec == 1 ? FSEHIP_HUF_decompress_batch_workspaceSize(nC) : FSEHIP_FSE_decompress_batch_workspaceSize(nC, FSEHIP_FSE_MAX_TABLELOG);
+        FK(dc.alloc(nC * cStride)); FK(dcs.alloc(nC * 8)); FK(drs.alloc(nC * 8)); FK(dout.alloc(nC * oStride)); FK(dres.alloc(nC * 8)); FK(dws.alloc(wsBytes));
+        FK(hipMemcpy(dc.p, stage.p, nC * cStride, hipMemcpyHostToDevice));
+        FK(hipMemcpy(dcs.p, cs.data(), nC * 8, hipMemcpyHostToDevice));
+        FK(hipMemcpy(drs.p, rs.data(), nC * 8, hipMemcpyHostToDevice));
+        if (codec == 1) {
+            if (FSEHIP_HUF_decompress_batch(dout.p, oStride, (const size_t*)drs.p, 0, (size_t*)dres.p, dc.p, cStride, (const size_t*)dcs.p, 0, nC, dws.p, wsBytes, nullptr))
+                return FSEHIP_ERROR(GENERIC);
+        } else {
+            if (nFullC && FSEHIP_FSE_decompress_batch(dout.p, oStride, bs, (size_t*)dres.p, dc.p, cStride, (const size_t*)dcs.p, 0, FSEHIP_FSE_MAX_TABLELOG, nFullC, dws.p, wsBytes, nullptr))
+                return FSEHIP_ERROR(GENERIC);
+            for (size_t i = nFullC; i < nC; ++i)             // blocks with their own announced size (normally only the last one)
+                if (FSEHIP_FSE_decompress_batch((u8*)dout.p + i * oStride, oStride, rs[i], (size_t*)dres.p + i, (const u8*)dc.p + i * cStride, cStride,
+                                                (const size_t*)dcs.p + i, 0, FSEHIP_FSE_MAX_TABLELOG, 1, dws.p, wsBytes, nullptr))
+                    return FSEHIP_ERROR(GENERIC);
+        }
+        FK(hipMemcpy(rr.data(), dres.p, nC * 8, hipMemcpyDeviceToHost));
+        bool allFull = direct;
+        for (size_t i = 0; i < nC && allFull; ++i) allFull = rr[i] == bs;
+        if (allFull) FK(hipMemcpy(out, dout.p, nC * oStride, hipMemcpyDeviceToHost));
+        else {
+            if (!regen.alloc(nC * oStride)) return FSEHIP_ERROR(GENERIC);
+            FK(hipMemcpy(regen.p, dout.p, nC * oStride, hipMemcpyDeviceToHost));
+        }
+        for (size_t i = 0; i < nC; ++i) result[order[i]] = rr[i];
+    }
+
+    // ---- pass 3 (host): lay the blocks out in order, first error wins
+    size_t o = 0;
+    for (size_t b = 0; b < nB; ++b) {
+        const Blk& k = blocks[b];
+        if (o + k.rSize > dstCapacity) return FSEHIP_ERROR(dstSize_tooSmall);
+        if (k.bt == BT_COMPRESSED) {
+            const size_t r = result[b];
+            if (FSEHIP_isError(r)) return r;                                       // fileio.c:571-572
+            if (regen.p) memcpy(out + o, regen.p + slot[b] * oStride, r);      // (otherwise already in place)
+            o += r;
+        } else if (k.bt == BT_RAW) { memcpy(out + o, in + k.at, k.rSize); o += k.rSize; }
+        else { memset(out + o, in[k.at], k.rSize); o += k.rSize; }
+    }
+    if (frameErr) return frameErr;
+    const u32 calc = (xxh32(out, o, 0) >> 5) & ((1u << 22) - 1);                  // :604-607
+    if (calc != savedCrc) return FSEHIP_ERROR(corruption_detected);
+    return o;
+}

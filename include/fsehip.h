@@ -173,6 +173,18 @@ FSEHIP_API void FSEHIP_probagen_table(uint8_t table4096[4096], double p);
 FSEHIP_API int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
                                      const uint8_t h_table4096[4096], uint32_t firstSeed, void* stream);
 
+/* ---- .fse frames on HOST buffers: the container written / read by the reference's command-line tool
+ * (programs/fileio.c:266-285 format, FIO_compressFilename :286-432, FIO_decompressFilename :462-626) around blocks of
+ * 1 KB << blockSizeId (id 0..6, the tool's default is 5 = 32 KB).  codec 0 = FSE_compress blocks (magic 0x183E2309),
+ * 1 = HUF_compress blocks (magic 0x183E3309); blocks the codec declines are stored raw, single-byte blocks as RLE, and
+ * the frame ends with 22 bits of XXH32 over the content, exactly as the tool writes them.  All blocks of a frame are
+ * coded by one batched device call.  Returns the frame size / the regenerated size, or an error code (bad magic or
+ * block-size id: GENERIC; truncated frame: srcSize_wrong; checksum mismatch: corruption_detected; a block decoder's
+ * own code otherwise).  The zlibh mode of the tool is not supported. */
+FSEHIP_API size_t FSEHIP_frame_compressBound(size_t srcSize, unsigned blockSizeId);
+FSEHIP_API size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec);
+FSEHIP_API size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+
 /* Kernel timing probe for benchmarks: between probe_begin and probe_collect every kernel launch of the library is
  * bracketed by HIP events on its own stream.  probe_collect synchronises and returns, per kernel id
  * (0 hist, 1 fse_cprep, 2 fse_encode [lane per block], 3 fse_dprep, 4 fse_decode, 5 huf_cprep, 6 huf_encode, 7 huf_dprep,

@@ -1,0 +1,58 @@
+"""GPU parity of the .fse frame calls (FSEHIP_frame_compress / FSEHIP_frame_decompress, host buffers) against the CPU
+oracle, whose frames are pinned against the reference's command-line tool (tests/test_frame_oracle.py)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import is_error
+from test_frame_oracle import _inputs
+from test_gpu_fse import s64
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frames_match_oracle(hip, oracle):
+    for name, data in _inputs(oracle):
+        for codec in (0, 1):
+            r, out = oracle.frame_compress(data, 5, codec)
+            rg, og = hip.frame_compress(data, 5, codec)
+            assert rg == r and (og[:r] == out[:r]).all(), (name, codec, rg, r)
+            r2, o2 = hip.frame_decompress(out[:r], len(data))
+            assert r2 == len(data) and (o2[:r2] == data).all(), (name, codec)
+            r3, o3 = hip.frame_decompress(out[:r], len(data) + 100)      # larger destination
+            assert r3 == len(data) and (o3[:r3] == data).all(), (name, codec)
+
+
+def test_frame_block_sizes_golden_and_errors(hip, oracle, golden):
+    data = oracle.probagen_batch(14, 1, 150000, 9)[0]
+    for bsid in range(0, 7):
+        for codec in (0, 1):
+            r, out = oracle.frame_compress(data, bsid, codec)
+            rg, og = hip.frame_compress(data, bsid, codec)
+            assert rg == r and (og[:r] == out[:r]).all(), (bsid, codec)
+            r2, o2 = hip.frame_decompress(out[:r], len(data))
+            assert r2 == len(data) and (o2[:r2] == data).all(), (bsid, codec)
+    if "frame_fse" in golden:                                              # frames written by the reference tool itself
+        src = golden["frame_src"]
+        for key, codec in (("frame_fse", 0), ("frame_huf", 1)):
+            rg, og = hip.frame_compress(src, 5, codec)
+            assert rg == len(golden[key]) and (og[:rg] == golden[key]).all(), key
+            r2, o2 = hip.frame_decompress(golden[key], len(src))
+            assert r2 == len(src) and (o2[:r2] == src).all(), key
+    # error behaviour follows the oracle: corrupt checksum / magic / payload, truncation, small destination, bad id
+    r, out = oracle.frame_compress(data, 5, 0)
+    frame = out[:r]
+    cases = []
+    for pos in (r - 1, 0, 4, 5, 6, 7, 40, 2000, r - 3, r - 5):
+        bad = frame.copy(); bad[pos] ^= 0x55; cases.append((bad, len(data)))
+    cases += [(frame[:r - 4], len(data)), (frame[:9], len(data)), (frame[:5], len(data)), (frame, len(data) - 1), (frame, 1000)]
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        bad = frame.copy(); idx = rng.integers(5, r, 3); bad[idx] = rng.integers(0, 256, 3); cases.append((bad, len(data)))
+    for bad, cap in cases:
+        ro, oo = oracle.frame_decompress(bad, cap)
+        rg, og = hip.frame_decompress(bad, cap)
+        assert rg == ro or (is_error(rg) and is_error(ro) and s64(rg) == s64(ro)), (rg, ro)
+        if not is_error(ro):
+            assert (og[:ro] == oo[:ro]).all()
+    assert is_error(hip.frame_compress(data, 7, 0)[0])
+    assert is_error(hip.frame_compress(data, 5, 0, cap=1000)[0])
