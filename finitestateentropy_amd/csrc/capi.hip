@@ -447,11 +447,12 @@ extern "C" int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t ds
 //  one-shot Huff0 block API over a batch
 // =====================================================================================================
 static const size_t HUF_CWS_PER_BLOCK = 1024 + 4 + 8 + sizeof(HufMeta) + 1024 + 4096;
+static const size_t HUF_CWS_NODE_PAD = 64 * 4096;   // node scratch is interleaved per workgroup of 64 blocks: the last workgroup needs a whole slab
 extern "C" size_t FSEHIP_HUF_compress_batch_workspaceSize(size_t nBlocks)
 {
     size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
     if (c == 0) c = 1;
-    return c * HUF_CWS_PER_BLOCK + WS_SLACK;
+    return c * HUF_CWS_PER_BLOCK + HUF_CWS_NODE_PAD + WS_SLACK;
 }
 
 extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
@@ -462,8 +463,8 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
     hipStream_t s = (hipStream_t)stream;
     if (nBlocks == 0) return 0;
     if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255) return (int)hipErrorInvalidValue;   // huf_compress.c:659-660 (see single-block wrapper)
-    if (workspaceBytes < HUF_CWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
-    size_t chunk = (workspaceBytes - WS_SLACK) / HUF_CWS_PER_BLOCK;
+    if (workspaceBytes < HUF_CWS_PER_BLOCK + HUF_CWS_NODE_PAD + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK - HUF_CWS_NODE_PAD) / HUF_CWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };

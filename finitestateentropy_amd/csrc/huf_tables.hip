@@ -16,10 +16,19 @@
 
 struct hnode_t { u32 count; u16 parent; u8 byte; u8 nbBits; };        // lib/huf_compress.c:201-206
 
+// Node array of one lane inside the workgroup's scratch: element i of lane l sits at (i * 64 + l), so that the 64 lanes
+// of a wave, which walk their trees in lock step, touch one contiguous 512-byte row per access.
+struct NodeArr {
+    hnode_t* p;
+    DEV hnode_t& operator[](int i) const { return p[(ptrdiff_t)i * 64]; }
+    DEV hnode_t& operator[](u32 i) const { return p[(size_t)i * 64]; }
+    DEV NodeArr operator+(int k) const { NodeArr r; r.p = p + (ptrdiff_t)k * 64; return r; }
+};
+
 // ---------------------------------------------------------------------------------------------------
 //  HUF_setMaxHeight (lib/huf_compress.c:215-291)
 // ---------------------------------------------------------------------------------------------------
-__device__ u32 huf_limit_height(hnode_t* node, u32 lastNonNull, u32 maxNbBits)
+__device__ u32 huf_limit_height(NodeArr node, u32 lastNonNull, u32 maxNbBits)
 {
     const u32 largest = node[lastNonNull].nbBits;
     if (largest <= maxNbBits) return largest;
@@ -77,7 +86,7 @@ __device__ u32 huf_limit_height(hnode_t* node, u32 lastNonNull, u32 maxNbBits)
 }
 
 // HUF_sort (lib/huf_compress.c:307-329)
-__device__ void huf_sort_nodes(hnode_t* node, const unsigned* count, u32 maxSV)
+__device__ void huf_sort_nodes(NodeArr node, const unsigned* count, u32 maxSV)
 {
     u32 base[32], cur[32];
     for (u32 n = 0; n < 32; n++) base[n] = 0;
@@ -95,15 +104,15 @@ __device__ void huf_sort_nodes(hnode_t* node, const unsigned* count, u32 maxSV)
 }
 
 // HUF_buildCTable_wksp (lib/huf_compress.c:338-410).  celt[s] = val | nbBits << 16 (struct HUF_CElt_s, :106-109).
-// node0: scratch of 2*256 entries (global memory).
-__device__ size_t huf_build_ctable(u32* celt, const unsigned* count, u32 maxSV, u32 maxNbBits, hnode_t* node0)
+// node0: scratch of 2*256 entries (global memory, interleaved across the lanes of the wave).
+__device__ size_t huf_build_ctable(u32* celt, const unsigned* count, u32 maxSV, u32 maxNbBits, NodeArr node0)
 {
     const int START = HUF_MAX_SV + 1;
-    hnode_t* const node = node0 + 1;
+    const NodeArr node = node0 + 1;
     int last, lowS, lowN, nodeNb = START, root, n;
     if (maxNbBits == 0) maxNbBits = HUF_DEF_TL;
     if (maxSV > HUF_MAX_SV) return FERR(maxSymbolValue_tooLarge);
-    {   u32* z = (u32*)node0; for (u32 i = 0; i < 2 * 512; i++) z[i] = 0; }
+    {   hnode_t z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; for (u32 i = 0; i < 512; i++) node0[i] = z; }
     huf_sort_nodes(node, count, maxSV);
     last = (int)maxSV;
     while (node[last].count == 0) last--;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a, hnode_t* nodeS
         const u32 maxSV = a.maxSVs[b];
         u32 huffLog = fse_optimal_tablelog(a.huffLogReq ? a.huffLogReq : HUF_DEF_TL, n, maxSV, 1);   // :691, :48-51
         u32* const celt = a.ctables + b * a.ctStrideU32;
-        {   const size_t mb = huf_build_ctable(celt, a.counts + b * 256, maxSV, huffLog, nodeScratch + b * 512);
+        {   const size_t mb = huf_build_ctable(celt, a.counts + b * 256, maxSV, huffLog, NodeArr{nodeScratch + (size_t)blockIdx.x * 64 * 512 + threadIdx.x});
             if (is_err(mb)) { result = mb; break; }
             huffLog = (u32)mb;
         }
