@@ -103,6 +103,35 @@ __device__ void huf_sort_nodes(NodeArr node, const unsigned* count, u32 maxSV)
     }
 }
 
+// The same order -- count descending, ties in symbol order (the insertion above only moves an element in front of strictly
+// smaller counts, and the buckets run from the largest counts down) -- by a stable bottom-up merge sort: n log n steps
+// instead of a quadratic number on flat histograms.  Ping-pongs between node0[0..255] and node0[256..511]; leaves the
+// result in node0[1 .. n] with everything else zero.
+__device__ void huf_sort_nodes_merge(NodeArr node0, const unsigned* count, u32 maxSV)
+{
+    const u32 n = maxSV + 1;
+    NodeArr src = node0, dst = node0 + 256;
+    for (u32 i = 0; i < n; i++) { hnode_t h; h.count = count[i]; h.parent = 0; h.byte = (u8)i; h.nbBits = 0; src[i] = h; }
+    for (u32 width = 1; width < n; width <<= 1) {
+        for (u32 lo = 0; lo < n; lo += 2 * width) {
+            const u32 mid = lo + width < n ? lo + width : n, hi = lo + 2 * width < n ? lo + 2 * width : n;
+            u32 i = lo, j = mid;
+            hnode_t a = src[i < n ? i : 0], bb = src[j < n ? j : 0];
+            for (u32 k = lo; k < hi; k++) {
+                const bool left = i < mid && (j >= hi || a.count >= bb.count);   // ties: the earlier (smaller) symbol first
+                dst[k] = left ? a : bb;
+                if (left) { ++i; if (i < mid) a = src[i]; } else { ++j; if (j < hi) bb = src[j]; }
+            }
+        }
+        const NodeArr t = src; src = dst; dst = t;
+    }
+    hnode_t z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0;
+    if (src.p == node0.p) { for (u32 i = n; i > 0; i--) node0[i] = node0[i - 1]; }        // shift up by one
+    else { for (u32 i = 0; i < n; i++) node0[1 + i] = src[i]; }                           // ascending: never overtakes its source
+    node0[0] = z;
+    for (u32 i = n + 1; i < 512; i++) node0[i] = z;
+}
+
 // HUF_buildCTable_wksp (lib/huf_compress.c:338-410).  celt[s] = val | nbBits << 16 (struct HUF_CElt_s, :106-109).
 // node0: scratch of 2*256 entries (global memory, interleaved across the lanes of the wave).
 __device__ size_t huf_build_ctable(u32* celt, const unsigned* count, u32 maxSV, u32 maxNbBits, NodeArr node0)
@@ -112,8 +141,10 @@ __device__ size_t huf_build_ctable(u32* celt, const unsigned* count, u32 maxSV, 
     int last, lowS, lowN, nodeNb = START, root, n;
     if (maxNbBits == 0) maxNbBits = HUF_DEF_TL;
     if (maxSV > HUF_MAX_SV) return FERR(maxSymbolValue_tooLarge);
-    {   hnode_t z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; for (u32 i = 0; i < 512; i++) node0[i] = z; }
-    huf_sort_nodes(node, count, maxSV);
+    if (maxSV < 96) {                                      // small alphabets: the reference's bucket + insertion sort is cheapest
+        hnode_t z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; for (u32 i = 0; i < 512; i++) node0[i] = z;
+        huf_sort_nodes(node, count, maxSV);
+    } else huf_sort_nodes_merge(node0, count, maxSV);
     last = (int)maxSV;
     while (node[last].count == 0) last--;
     lowS = last; root = nodeNb + lowS - 1; lowN = nodeNb;
