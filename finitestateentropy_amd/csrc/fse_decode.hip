@@ -93,7 +93,7 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
     u32 w0, w1, w2;
     {   const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (q & (FSE_IN_RING - 4)));
         w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; }
-#pragma unroll 2
+#pragma unroll 8
     for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
         const u32 c = lds_cell(s);                               // lane A: state 1's cell, lane B: state 2's
         const lds_u32_ptr np = (lds_u32_ptr)(uintptr_t)(myIn + ((q - 8u) & (FSE_IN_RING - 4)));

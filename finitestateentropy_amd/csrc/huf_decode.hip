@@ -70,7 +70,7 @@ DEV void hd_bulk_phase(HdBulk& b, const u16* T, u32 idxShift, const u8* myIn, u3
     u32 w0, w1, w2;
     {   const u32* const wp = (const u32*)(myIn + (q & (HD_IN_RING - 4)));
         w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; }
-#pragma unroll 2
+#pragma unroll 8
     for (int it = 0; it < HD_PHASE; ++it) {
         const u32* const np = (const u32*)(myIn + ((q - 8u) & (HD_IN_RING - 4)));
         const u32 n0 = np[0], n1 = np[1];                        // stream dwords at q-8, q-4
