@@ -10,7 +10,8 @@
 //   * the service waves own all global-memory traffic of the bulk loop, wave-cooperative and coalesced: they refill the
 //     input rings and turn state-ring records into output bytes (symbol gathers from an L2-resident byte table);
 //   * the two sides talk through per-block control words in LDS (acquire/release, workgroup scope).
-// Throughput = blocks resident per CU / latency of one iteration of the chain (two dependent LDS lookups).
+// Throughput = blocks resident per CU (LDS capacity: 30 at tableLog 11) / latency of one iteration of the chain (two
+// dependent LDS lookups and the VALU ops between them; a lone wave also pays ~7 cycles per instruction it issues).
 //
 // The kernel reproduces the reference's decoder state -- a 64-bit little-endian window at byte offset `at` plus a
 // consumed-bit count `used` (lib/bitstream.h:91-97) -- exactly, including on truncated / corrupt input:
@@ -23,21 +24,24 @@
 
 #include "bitreader.h"
 
-// Bulk decoding against the compact LDS table A[x] = newState (12 bits) | nbBits << 12, full-rate 32-bit ops only
-// (64-bit shifts are quarter rate on gfx950).  FSE_buildDTable makes the low nbBits of newState zero
-// (lib/fse_decompress.c:121-122), so "newState + bits" is an OR; tables that violate this take the literal path.
+// Two bulk loops share the kernel:
+//   * fse_bulk_phase_rev (k_fse_decode<true>): tables from k_fse_dbuild with maxTableLog <= 11, bit-reversed layout --
+//     the one the one-shot decompressor uses; described at the function;
+//   * fse_bulk_phase (k_fse_decode<false>): caller-built reference-layout DTables (staged as A[x] = newState (12 bits) |
+//     nbBits << 12) and maxTableLog 12.  FSE_buildDTable makes the low nbBits of newState zero
+//     (lib/fse_decompress.c:121-122), so "newState + bits" is an OR; tables that violate this take the literal path.
 //
-// Window: bq = number of still unread bits of stream dword dp (its low bits; 0..31); q = 4*dp - 8 is the payload byte
-// offset of the lowest of the three dwords {d2:d1:d0} = dwords dp, dp-1, dp-2 (dword-aligned with respect to the payload
-// start, which is how the LDS input ring is laid out).  One iteration of lib/fse_decompress.c:201-218 = 4 symbols = at
-// most 48 bits:
-//   the three dwords are read from the input ring together with the two table cells (same LDS round trip);
+// Window of fse_bulk_phase: bq = number of still unread bits of stream dword dp (its low bits; 0..31); q = 4*dp - 8 is the
+// payload byte offset of the lowest of the three dwords {d2:d1:d0} = dwords dp, dp-1, dp-2 (dword-aligned with respect to
+// the payload start, which is how the LDS input ring is laid out).  One iteration of lib/fse_decompress.c:201-218 = 4
+// symbols = at most 48 bits:
 //   {thi:tlo} = the next 64 unread bits (two v_alignbit);
 //   symbol 1 reads the top of thi, symbol 2 the top of thi << nb1 (>= 20 valid bits), symbols 3/4 the same from
 //   t3 = the 32 bits that follow the first two symbols (one more v_alignbit) -- no per-symbol window shifting;
-//   then bq -= consumed, carrying into q.
+//   then bq -= consumed, carrying into q; the window registers slide by selects and the two dwords below them are
+//   prefetched at the top of the iteration.
 // The reference's (ptr, bitsConsumed) pair is a function of the absolute bit position alone while its reloads are
-// the fast ones (bitstream.h:378-388), so it is reconstructed from (q, bq) when the bulk loop ends.
+// the fast ones (bitstream.h:378-388), so it is reconstructed from the cursor when the bulk loop ends.
 // NB0 = some cell of some table staged by this workgroup has nbBits == 0: a v_alignbit by 32 would return the low
 // word, so that one select is made explicit.
 #define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration
@@ -56,22 +60,10 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decTiming(uns
 #endif
 struct BulkState { u32 s, q, bq; };     // this lane's state (cell address) and the pair's bit cursor
 
-// One symbol of the bulk loop.  The decoder lane keeps its two states as LDS byte addresses of their table cells.
-//   FAST (maxTableLog <= 11): cell = 2*newState (12 bits) | nbBits << 12 and the tables sit on table-size aligned LDS
-//   addresses, so the next address is (cell & 0xFFF | tableBase) + 2*bits: one and_or off the dependent chain, one
-//   shift-add on it.   Otherwise: cell = newState | nbBits << 12, next address = ((cell & 0xFFF | bits) << 1) + tableBase.
+// The decoder lanes keep their states as absolute LDS byte addresses of the table cells.
 typedef const __attribute__((address_space(3))) u16* lds_u16_ptr;
 typedef const __attribute__((address_space(3))) u32* lds_u32_ptr;
 DEV u32 lds_cell(u32 addr) { return *(lds_u16_ptr)(uintptr_t)addr; }   // absolute LDS byte address -> table cell
-
-template <bool FAST>
-DEV void fse_bulk_sym(u32 c, u32& sA, u32 t, u32& nb, u32 tabOff)
-{
-    nb = c >> 12;
-    const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nb, nb);
-    if (FAST) sA = (bits << 1) + ((c & 0xFFFu) | tabOff);
-    else      sA = ((((c & 0xFFFu) | bits)) << 1) + tabOff;
-}
 
 DEV u32 dpp_swap(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // value of the neighbour lane (quad_perm [1,0,3,2])
 
@@ -82,7 +74,7 @@ DEV u32 dpp_swap(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF
 // needs (the neighbour's cell for its bit count, the window dwords) moves through DPP, which costs a VALU slot.
 // Both lanes keep identical copies of the bit cursor (q, bq).  maskB = all ones in lane B: its symbol's bits come
 // after lane A's.
-template <bool NB0, bool FAST>
+template <bool NB0>
 DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn, u32 half, u32 maskB, uint2* ringMine)
 {
     u32 s = sMine, q = qRef, bq = bqRef;
@@ -104,7 +96,7 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
         const u32 sStart = s;
         {   const u32 t = thi << (nbO & maskB);
             const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nbM, nbM);
-            s = FAST ? (bits << 1) + ((c & 0xFFFu) | tabOff) : ((((c & 0xFFFu) | bits)) << 1) + tabOff; }
+            s = (((c & 0xFFFu) | bits) << 1) + tabOff; }
         const u32 c2 = lds_cell(s);
         const u32 s12 = nbM + nbO;
         u32 t3 = __builtin_amdgcn_alignbit(thi, tlo, 32u - s12);
@@ -114,7 +106,7 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
         const u32 nbM2 = c2 >> 12, nbO2 = cO2 >> 12;
         {   const u32 t = t3 << (nbO2 & maskB);
             const u32 bits = __builtin_amdgcn_ubfe(t, 32u - nbM2, nbM2);
-            s = FAST ? (bits << 1) + ((c2 & 0xFFFu) | tabOff) : ((((c2 & 0xFFFu) | bits)) << 1) + tabOff; }
+            s = (((c2 & 0xFFFu) | bits) << 1) + tabOff; }
         const int left = (int)bq - (int)(s12 + nbM2 + nbO2);     // unread bits of dword dp after this iteration (>= -48)
         const bool k1 = left < 0, k2 = left < -32;               // the window slides down by one / two dwords
         w2 = k2 ? w0 : (k1 ? w1 : w2);
@@ -126,6 +118,54 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
         if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
     }
     sMine = s; qRef = q; bqRef = bq;
+}
+
+// ---- bit-reversed bulk loop (maxTableLog <= 11, tables from k_fse_dbuild) ----------------------------------------
+// A lone wave is bound by the number of instructions it issues (about one per 7 cycles), so this variant is laid out to
+// need as few as possible: 6 VALU per symbol and 11 per iteration for the bit cursor.
+//   * The input ring holds the stream in CONSUMPTION order: ring dword m = bit-reversed payload dword (Stop/4 - 1 - m)
+//     (Stop = payload size rounded up to 4), written that way by the service waves.  The cursor is one number,
+//     P = 8*Stop - (unread bits): the next bit to read is bit P & 31 of ring dword P >> 5, and bits are taken from the
+//     low end -- v_bfe_u32(window, offset, nbBits) with the offset and width operands used as they come (the hardware
+//     reads their low 5 bits), no per-iteration select of window registers, no special case for nbBits == 0.
+//   * Taking bits low-end-first yields them bit-reversed, so the table is stored bit-reversed too: the cell of state x
+//     sits at index rev(x), and holds nbBits (low 5 bits) | rev(newState) << (16 - maxTableLog).  newState is a
+//     multiple of 1 << nbBits (lib/fse_decompress.c:121-122), hence rev(newState + bits) = rev(newState) | rev_nb(bits) << (tableLog - nbBits):
+//     next address = tableBase | cell >> (15 - maxTableLog) | bits << (tableLog + 1 - nbBits)   (v_lshrrev, v_or, v_sub, v_lshl_or).
+//   * Lane B's bits follow lane A's: its offset is lane A's nbBits, fetched and masked by one v_and_b32_dpp
+//     (maskB = 31 in lane B, 0 in lane A); the pair's bit count is one v_add_u32_dpp.
+// One iteration = 2 symbols per lane = at most 44 bits out of the 64+ bits {d2:d1:d0} >> (P & 31) read at its top.
+DEV u32 dpp_swap_and(u32 v, u32 m) { return dpp_swap(v) & m; }      // (the compiler folds these into v_and_b32_dpp / v_add_u32_dpp)
+DEV u32 dpp_swap_add(u32 v, u32 w) { return dpp_swap(v) + w; }
+// instruction selection helpers: keep the shapes the instruction count above relies on
+DEV u32 lshl_or(u32 v, u32 sh, u32 o) { u32 r; __asm__("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(sh), "v"(o)); return r; }   // (v << sh[4:0]) | o
+DEV u32 ring_dword(u32 P) { u32 r; __asm__("v_bfe_u32 %0, %1, 5, 7" : "=v"(r) : "v"(P)); return r; }                                      // (P >> 5) & 127
+DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
+{
+    u32 s = sMine, P = Pref;
+    u32 prev = 0;
+    __asm__ volatile("" : "+v"(myIn));                           // one register: the three window reads then differ by their immediate offsets
+#pragma unroll 8
+    for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
+        const u32 c = lds_cell(s);                               // lane A: state 1's cell, lane B: state 2's
+        const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (ring_dword(P) << 2));
+        const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        const u32 lo = __builtin_amdgcn_alignbit(d1, d0, P), hi = __builtin_amdgcn_alignbit(d2, d1, P);
+        const u32 sStart = s;
+        {   const u32 bits = __builtin_amdgcn_ubfe(lo, dpp_swap_and(c, maskB), c);
+            s = lshl_or(bits, K - c, (c >> cellShift) | tabOff); }
+        const u32 c2 = lds_cell(s);
+        const u32 n1 = dpp_swap_add(c, c);                       // low 5 bits: bits of this symbol pair
+        const u32 lo2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+        const u32 rec = __builtin_amdgcn_perm(s, sStart, 0x05040100u);   // low 16 bits of the two cell addresses this lane decoded from
+        {   const u32 bits = __builtin_amdgcn_ubfe(lo2, dpp_swap_and(c2, maskB), c2);
+            s = lshl_or(bits, K - c2, (c2 >> cellShift) | tabOff); }
+        const u32 n2 = dpp_swap_add(c2, c2);
+        P += (n1 & 31u) + (n2 & 31u);
+        // two iterations per ring slot pair: this lane's half of slot pair (it >> 1) holds its states of both iterations
+        if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
+    }
+    sMine = s; Pref = P;
 }
 
 // Per-block control words in LDS: the decoder wave and the service wave of a workgroup talk through these only.
@@ -162,7 +202,11 @@ DEV void fse_ring_put(u32* rg, int off, u32 w)
     rg[j >> 2] = w;
     if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = w;
 }
-DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0)
+// rev: the ring is kept in consumption order for the bit-reversed bulk loop -- payload dword at offset o goes, bit-reversed,
+// to ring offset (Stop - 4 - o) mod 512 (Stop = payload size rounded up to 4).  Either way ring byte x <-> payload byte is
+// a bijection on windows of 512 aligned-dword bytes, so the validLo protocol is the same.
+DEV void fse_ring_put_rev(u32* rg, int Sg, int off, u32 w) { fse_ring_put(rg, ((Sg + 3) & ~3) - 4 - off, __brev(w)); }
+DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev)
 {
     const u32 symShift = a.atab ? 0u : 2u;
     const int myG = g0 + (lane < FSE_SRV_G ? lane : 0);      // lane l of this wave keeps the books of block g0 + l
@@ -187,11 +231,11 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int off = vlo + FSE_IN_CHUNK * c + 4 * lane;
-                if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); fse_ring_put(rg, off, w); }
+                if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); if (rev) fse_ring_put_rev(rg, Sg, off, w); else fse_ring_put(rg, off, w); }
                 else if (off >= 0 && off < Sg) {
                     u32 w = 0;
                     for (int i = 0; i < 3; ++i) if (off + i < Sg) w |= (u32)ig[off + i] << (8 * i);
-                    fse_ring_put(rg, off, w);
+                    if (rev) fse_ring_put_rev(rg, Sg, off, w); else fse_ring_put(rg, off, w);
                 }
             }
         }
@@ -254,7 +298,8 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         for (int l = 0; l < FSE_SRV_G; ++l) {
             if (!((rm >> l) & 1ull)) continue;               // uniform
             const int nlo = __shfl(validLo, l, WAVE) - FSE_IN_CHUNK;
-            fse_ring_put((u32*)(ldsb + (size_t)(g0 + l) * slotBytes + inOff), nlo + 4 * lane, pend[l]);
+            u32* const rg = (u32*)(ldsb + (size_t)(g0 + l) * slotBytes + inOff);
+            if (rev) fse_ring_put_rev(rg, __shfl(S32, l, WAVE), nlo + 4 * lane, pend[l]); else fse_ring_put(rg, nlo + 4 * lane, pend[l]);
         }
         if (wantFill) { validLo -= FSE_IN_CHUNK; ctl_store(&ctl->srvValidLo, validLo); }
         // (4) the ring records are in registers now: hand the slots back, then pack and store the symbols
@@ -278,8 +323,10 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 // cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
 struct FseCellsRef { const u32* cells;
     DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = cells[st]; ns = c & 0xFFFFu; sym = (c >> 16) & 0xFFu; nb = c >> 24; } };
-struct FseCellsCompact { const u16* A; const u8* syms; u32 nsShift;      // nsShift = 1 for the FAST cell format (2*newState)
-    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = A[st]; ns = (c & 0xFFFu) >> nsShift; nb = c >> 12; sym = syms[st]; } };
+struct FseCellsCompact { const u16* A; const u8* syms;
+    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = A[st]; ns = c & 0xFFFu; nb = c >> 12; sym = syms[st]; } };
+struct FseCellsRev { const u16* A; const u8* syms; u32 tl, cellShift;       // bit-reversed tables (see fse_bulk_phase_rev): cell shift = 16 - maxTableLog
+    DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 i = __brev(st) >> (32u - tl); const u32 c = A[i]; nb = c & 31u; ns = __brev(c >> cellShift) >> (32u - tl); sym = syms[i]; } };
 template <class Cells>
 DEV u32 fse_tail_step(const Cells& t, u32& state, BitReader& r, bool fast)          // FSE_decodeSymbol(Fast), fse.h:600-622
 {
@@ -346,6 +393,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
                 anyNb0 |= !(a.meta[b].state & 2u);               // a cell with nbBits == 0 needs a counter > tableSize/2
                 continue;
             }
+            if (FAST) __builtin_trap();                          // the bit-reversed loop takes k_fse_dbuild tables only (launch_fse_decode)
             const u32* t = a.dtables + b * a.dtStrideU32;
             const u32 tl = t[0] & 0xFFFFu;
             if (tl > a.maxTableLog) continue;
@@ -355,9 +403,9 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             for (u32 i = tid; i < ts; i += FSE_DEC_THREADS) {
                 const u32 c = t[1 + i];
                 const u32 ns = c & 0xFFFFu, nb = c >> 24;
-                bad |= (ns >= (FAST ? 0x800u : 0x1000u)) | (nb > 15u) | ((ns & ((1u << (nb & 15u)) - 1u)) != 0);
+                bad |= (ns >= 0x1000u) | (nb > 15u) | ((ns & ((1u << (nb & 15u)) - 1u)) != 0);
                 anyNb0 |= (nb == 0);
-                A[i] = (u16)((((FAST ? 2u * ns : ns)) & 0xFFFu) | (nb << 12));
+                A[i] = (u16)((ns & 0xFFFu) | (nb << 12));
             }
             if (bad) badBits |= 1u << g;
         }
@@ -418,14 +466,18 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // (>= 16 output groups left and the window stays >= 24 bytes above the stream start: at >= 24 + 16*6), so the
     // 16 iterations of a phase run without any per-iteration bookkeeping; whatever is left goes to the literal tail.
     // Bulk state uses p = at+1, u = used+8 (u in [8,16) after a reload), so no shift amount is ever 0 or 32.
-    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 31) && !((badMask >> gsl) & 1u);
-    BulkState bs; bs.s = tabOff + 2u * (half ? s2 : s1); bs.q = 0; bs.bq = 0;   // my state as a cell address
+    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 28) && !((badMask >> gsl) & 1u);
+    BulkState bs; bs.q = 0; bs.bq = 0;
+    {   const u32 st = half ? s2 : s1;                                           // my state as a cell address
+        bs.s = tabOff + 2u * (FAST ? __brev(st) >> (32u - (tl ? tl : 1u)) : st); }
+    const u32 R8 = 8u * (((u32)S + 3u) & ~3u);                                   // bit-reversed loop: cursor P = R8 - unread bits
+    u32 P = 0;
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + 512)
     if (can) {
         const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the payload
-        bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
+        bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u; P = R8 - B;
         groups = (omax - 3 - op + 3) >> 2;
         // P = q + 8 = byte offset of dword dp.  The ring must reach up to P + 4 and down to the lowest byte a phase can
         // read, P - 8 - 6*16 = P - 104
@@ -440,7 +492,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
     }
     __syncthreads();
-    if (wave >= 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G); return; }
+    if (wave >= 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G, FAST); return; }
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
@@ -456,8 +508,13 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         }
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
-            if (nb0) fse_bulk_phase<true, FAST>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
-            else     fse_bulk_phase<false, FAST>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
+            if (FAST) {
+                fse_bulk_phase_rev(bs.s, P, tl + 1u, 15u - a.maxTableLog, tabOff, myIn, maskB & 31u, ring);
+                const u32 B = R8 - P;
+                bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
+            }
+            else if (nb0) fse_bulk_phase<true>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
+            else          fse_bulk_phase<false>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
             iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
             // the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
             can = bs.q >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
@@ -476,11 +533,13 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container) after a reload
         const u32 B = 8u * (bs.q + 8u) + bs.bq;
         r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s - tabOff) >> 1; s2 = (sOther - tabOff) >> 1;
+        if (FAST) { s1 = __brev(s1) >> (32u - tl); s2 = __brev(s2) >> (32u - tl); }
     }
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
     size_t result;
-    if (compact) result = fse_tail(FseCellsCompact{A, syms, FAST ? 1u : 0u}, s1, s2, r, out, op, omax, fast);
+    if (FAST)         result = fse_tail(FseCellsRev{A, syms, tl, 16u - a.maxTableLog}, s1, s2, r, out, op, omax, fast);
+    else if (compact) result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
     else         result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
 }
@@ -516,7 +575,7 @@ hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
     probe_before(PK_FSE_DECODE, s);
-    if (a.maxTableLog <= FSE_DEC_FAST_MAXLOG) hipLaunchKernelGGL(k_fse_decode<true>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    if (a.atab && a.maxTableLog <= FSE_DEC_FAST_MAXLOG) hipLaunchKernelGGL(k_fse_decode<true>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     else hipLaunchKernelGGL(k_fse_decode<false>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     probe_after(PK_FSE_DECODE, s);
     return hipGetLastError();

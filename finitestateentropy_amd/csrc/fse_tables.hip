@@ -105,8 +105,8 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
 //   k_fse_dparse : one lane per block -- FSE_readNCount (a serial bit parser, lib/entropy_common.c:41-144) and the
 //                  checks of FSE_decompress_wksp (lib/fse_decompress.c:264-269); leaves the counters in scratch;
 //   k_fse_dbuild : one wave per block -- FSE_buildDTable (lib/fse_decompress.c:71-126) with the wave-cooperative
-//                  spread / rank of fse_wave_build.h, emitting the decoder's compact cell format
-//                  (cell = newState | nbBits << 12, symbol in a separate byte table) with coalesced stores.
+//                  spread / rank of fse_wave_build.h, emitting the decoder's compact cell formats (u16 cell, symbol in
+//                  a separate byte table; bit-reversed layout when maxLog <= 11, see fse_decode.hip) with coalesced stores.
 __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
 {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -137,20 +137,35 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
     *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
     __syncthreads();
     const u32 tl = m.tableLog, ts = 1u << tl;
+    const bool rev = a.maxLog <= FSE_DEC_FAST_MAXLOG;                      // uniform
     const bool fast = wave_spread_rank(w, m.maxSV, tl, lane, [&](u32 s) { return (u32)(int)w.nrm[s]; }, [&](u32 u, u32 s, u32 r, u32 nrm) {
         (void)s;
         const int n = (int)nrm;
         const u32 next = (n > 0 ? (u32)n : 1u) + r;                        // symbolNext[s]++, fse_decompress.c:117-122
         const u32 nb = tl - hibit32(next);
         const u32 ns = (next << nb) - ts;
-        w.cell[u] = (u16)((((a.maxLog <= FSE_DEC_FAST_MAXLOG ? 2u * ns : ns)) & 0xFFFu) | (nb << 12));
+        // bit-reversed format (see fse_decode.hip): nbBits | rev_tl(newState) << (16 - maxLog); the cell of state u goes
+        // to position rev_tl(u), which the copy-out below takes care of
+        if (rev) w.cell[u] = (u16)(nb | ((__brev(ns) >> (32u - tl)) << (16u - a.maxLog)));
+        else     w.cell[u] = (u16)((ns & 0xFFFu) | (nb << 12));
     });
     u32* const A32 = (u32*)(a.atab + b * capTs);
-    const u32* const c32 = (const u32*)w.cell;
-    for (u32 i = lane; i < ts / 2; i += 64) A32[i] = c32[i];
     u32* const S32 = (u32*)(a.symtab + b * capTs);
-    const u32* const y32 = (const u32*)w.symTab;
-    for (u32 i = lane; i < ts / 4; i += 64) S32[i] = y32[i];
+    if (rev) {
+        const u32 rs = 32u - tl;                                           // tl >= FSE_MIN_TABLELOG = 5
+        for (u32 i = lane; i < ts / 2; i += 64)
+            A32[i] = (u32)w.cell[__brev(2u * i) >> rs] | ((u32)w.cell[__brev(2u * i + 1u) >> rs] << 16);
+        for (u32 i = lane; i < ts / 4; i += 64) {
+            u32 y = 0;
+            for (u32 k = 0; k < 4; ++k) y |= (u32)w.symTab[__brev(4u * i + k) >> rs] << (8u * k);
+            S32[i] = y;
+        }
+    } else {
+        const u32* const c32 = (const u32*)w.cell;
+        for (u32 i = lane; i < ts / 2; i += 64) A32[i] = c32[i];
+        const u32* const y32 = (const u32*)w.symTab;
+        for (u32 i = lane; i < ts / 4; i += 64) S32[i] = y32[i];
+    }
     if (lane == 0) a.meta[b].state = 1u | (fast ? 2u : 0u);
 }
 

@@ -76,8 +76,8 @@ struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCo
     BlockView csrc;
     unsigned maxLog;
     // outputs, `capTs` = 1 << maxLog cells per block: the decoder's own table format (fse_decode.hip)
-    u16* atab;                   // cell x: newState (12 bits; 2*newState when maxLog <= FSE_DEC_FAST_MAXLOG) | nbBits << 12
-    u8* symtab;                  // cell x: symbol
+    u16* atab;                   // maxLog <= FSE_DEC_FAST_MAXLOG: cell rev(x) = nbBits | rev(newState) << (16 - maxLog) (fse_decode.hip); else cell x = newState | nbBits << 12
+    u8* symtab;                  // symbol of the cell at the same index
     s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
     FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1
     size_t* results;
