@@ -5,7 +5,7 @@
 // speculative starts shows that this two-state decoder does not re-synchronise within thousands of symbols, so unlike
 // the encoder it cannot be split), hence "one lane per block, as many blocks per CU as LDS holds":
 //   * a workgroup = 1 decoder wave + 4 service waves over G = 15 blocks (tableLog 11); 2 workgroups per CU;
-//   * the decoder lane of a block walks the chain touching registers and LDS only: u16 table cells, a 512-byte ring of
+//   * the decoder lane of a block walks the chain touching registers and LDS only: u16 table cells, a 256-byte ring of
 //     compressed input, a ring of decoded states;
 //   * the service waves own all global-memory traffic of the bulk loop, wave-cooperative and coalesced: they refill the
 //     input rings and turn state-ring records into output bytes (symbol gathers from an L2-resident byte table);
@@ -45,8 +45,10 @@
 // NB0 = some cell of some table staged by this workgroup has nbBits == 0: a v_alignbit by 32 would return the low
 // word, so that one select is made explicit.
 #define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration
-#define FSE_IN_RING 512          // per-block LDS input ring (bytes of compressed stream, direct-mapped by offset mod 512)
-#define FSE_IN_CHUNK 256         // refill granule: one coalesced 4-byte load per lane
+#define FSE_IN_RING 256          // per-block LDS input ring (bytes of compressed stream, direct-mapped by offset mod 256)
+#define FSE_IN_RING_LOG 8
+#define FSE_IN_CHUNK 64          // refill granule: one 4-byte load per lane of a 16-lane group (one group per block of a service wave)
+#define FSE_IN_LANES (FSE_IN_CHUNK / 4)
 #define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so reads of 2 dwords never wrap
 #define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
 #define FSE_MAXG 16              // blocks per workgroup
@@ -139,7 +141,7 @@ DEV u32 dpp_swap_and(u32 v, u32 m) { return dpp_swap(v) & m; }      // (the comp
 DEV u32 dpp_swap_add(u32 v, u32 w) { return dpp_swap(v) + w; }
 // instruction selection helpers: keep the shapes the instruction count above relies on
 DEV u32 lshl_or(u32 v, u32 sh, u32 o) { u32 r; __asm__("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(sh), "v"(o)); return r; }   // (v << sh[4:0]) | o
-DEV u32 ring_dword(u32 P) { u32 r; __asm__("v_bfe_u32 %0, %1, 5, 7" : "=v"(r) : "v"(P)); return r; }                                      // (P >> 5) & 127
+DEV u32 ring_dword(u32 P) { u32 r; __asm__("v_bfe_u32 %0, %1, 5, %2" : "=v"(r) : "v"(P), "n"(FSE_IN_RING_LOG - 2)); return r; }              // (P >> 5) mod ring dwords
 DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
 {
     u32 s = sMine, P = Pref;
@@ -173,7 +175,7 @@ struct DecCtl {
     u32 pubIters;      // decoder -> service: bulk iterations completed (state-ring records produced)
     u32 pubPofs;       // decoder -> service: window position p = at+1; bit 31 = bulk finished (pubIters is final)
     u32 srvFlushed;    // service -> decoder: state-ring records already turned into output bytes
-    int srvValidLo;    // service -> decoder: the input ring holds stream bytes [validLo, validLo + 512); INT_MAX = not yet
+    int srvValidLo;    // service -> decoder: the input ring holds stream bytes [validLo, validLo + FSE_IN_RING); INT_MAX = not yet
     int initValidLo;   // set-up constants for the service wave
     int S32;
     u32 inLo, inHi, outLo, outHi, symLo, symHi;
@@ -203,8 +205,8 @@ DEV void fse_ring_put(u32* rg, int off, u32 w)
     if (j < FSE_IN_MIRROR) rg[(FSE_IN_RING + j) >> 2] = w;
 }
 // rev: the ring is kept in consumption order for the bit-reversed bulk loop -- payload dword at offset o goes, bit-reversed,
-// to ring offset (Stop - 4 - o) mod 512 (Stop = payload size rounded up to 4).  Either way ring byte x <-> payload byte is
-// a bijection on windows of 512 aligned-dword bytes, so the validLo protocol is the same.
+// to ring offset (Stop - 4 - o) mod FSE_IN_RING (Stop = payload size rounded up to 4).  Either way ring byte x <-> payload
+// byte is a bijection on windows of FSE_IN_RING aligned-dword bytes, so the validLo protocol is the same.
 DEV void fse_ring_put_rev(u32* rg, int Sg, int off, u32 w) { fse_ring_put(rg, ((Sg + 3) & ~3) - 4 - off, __brev(w)); }
 DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev)
 {
@@ -220,32 +222,33 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
     u32 flushed = 0;
     bool live = lane < FSE_SRV_G && myG < a.G && !(ctl->pubPofs >> 31);   // blocks that never enter the bulk loop need no service
 
-    // initial fill: two chunks per live block (the topmost dword may straddle the end of the payload), then publish
-    {   const unsigned long long am = __ballot(live);
+    // Input refills: the 16-lane group k of this wave serves block g0 + k, so one load instruction and one LDS store
+    // refill all blocks of the wave that ask for it in the same round.
+    static_assert(64 / FSE_IN_LANES == FSE_SRV_G, "one 16-lane group per block of a service wave");
+    const int grp = lane / FSE_IN_LANES, sub = lane % FSE_IN_LANES;
+    const int SgK = __shfl(S32, grp, WAVE);
+    const u8* const igK = (const u8*)(uintptr_t)__shfl(inBits, grp, WAVE);
+    u32* const rgK = (u32*)(ldsb + (size_t)(g0 + grp) * slotBytes + inOff);
+    // initial fill: the whole ring of every live block (the topmost dword may straddle the end of the payload), then publish
+    {   const bool liveK = (__ballot(live) >> grp) & 1ull;
+        const int vlo = __shfl(validLo, grp, WAVE);
 #pragma unroll
-        for (int l = 0; l < FSE_SRV_G; ++l) {
-            if (!((am >> l) & 1ull)) continue;               // uniform
-            const int vlo = __shfl(validLo, l, WAVE), Sg = __shfl(S32, l, WAVE);
-            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
-            u32* const rg = (u32*)(ldsb + (size_t)(g0 + l) * slotBytes + inOff);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int off = vlo + FSE_IN_CHUNK * c + 4 * lane;
-                if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); if (rev) fse_ring_put_rev(rg, Sg, off, w); else fse_ring_put(rg, off, w); }
-                else if (off >= 0 && off < Sg) {
-                    u32 w = 0;
-                    for (int i = 0; i < 3; ++i) if (off + i < Sg) w |= (u32)ig[off + i] << (8 * i);
-                    if (rev) fse_ring_put_rev(rg, Sg, off, w); else fse_ring_put(rg, off, w);
-                }
+        for (int c = 0; c < FSE_IN_RING / FSE_IN_CHUNK; ++c) {
+            const int off = liveK ? vlo + FSE_IN_CHUNK * c + 4 * sub : -1;
+            if (off >= 0 && off + 4 <= SgK) { u32 w; __builtin_memcpy(&w, igK + off, 4); if (rev) fse_ring_put_rev(rgK, SgK, off, w); else fse_ring_put(rgK, off, w); }
+            else if (off >= 0 && off < SgK) {
+                u32 w = 0;
+                for (int i = 0; i < 3; ++i) if (off + i < SgK) w |= (u32)igK[off + i] << (8 * i);
+                if (rev) fse_ring_put_rev(rgK, SgK, off, w); else fse_ring_put(rgK, off, w);
             }
         }
         if (live) ctl_store(&ctl->srvValidLo, validLo);
     }
 
-    u32 pend[FSE_SRV_G];
+    u32 pend = 0;
     u32 yq[FSE_SRV_G][4];
 #pragma unroll
-    for (int l = 0; l < FSE_SRV_G; ++l) { pend[l] = 0; yq[l][0] = yq[l][1] = yq[l][2] = yq[l][3] = 0; }
+    for (int l = 0; l < FSE_SRV_G; ++l) { yq[l][0] = yq[l][1] = yq[l][2] = yq[l][3] = 0; }
     TIMING(unsigned long long sBusy = 0; unsigned long long sIdle = 0; unsigned long long nBusy = 0; unsigned long long sA = __builtin_readcyclecounter();)
     for (;;) {
         // snapshot of the decoder's progress (the finished flag is read before the iteration count it guards)
@@ -255,8 +258,8 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         const int P = (int)(pp & 0x7FFFFFFFu);               // byte offset of the topmost dword the decoder still reads
         const u32 avail = it - flushed;
         const bool wantFlush = live && (avail >= 32u || (fin && avail > 0));
-        // the chunk [validLo-256, validLo) lands on the ring bytes of [validLo+256, validLo+512): the decoder must be below
-        const bool wantFill = live && !fin && validLo > 0 && P + 4 <= validLo + FSE_IN_CHUNK;
+        // the chunk [validLo-CHUNK, validLo) lands on the ring bytes of [validLo+RING-CHUNK, validLo+RING): the decoder must be below
+        const bool wantFill = live && !fin && validLo > 0 && P + 4 <= validLo + (FSE_IN_RING - FSE_IN_CHUNK);
         const unsigned long long fm = __ballot(wantFlush), rm = __ballot(wantFill);
         if (live && fin && avail == 0) live = false;
         if (!(fm | rm)) {
@@ -266,15 +269,12 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             continue;
         }
         // (1) request the next input chunk of every block that is about to need it
-#pragma unroll
-        for (int l = 0; l < FSE_SRV_G; ++l) {
-            if (!((rm >> l) & 1ull)) continue;               // uniform
-            const int off = __shfl(validLo, l, WAVE) - FSE_IN_CHUNK + 4 * lane;
-            const int Sg = __shfl(S32, l, WAVE);
-            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
-            u32 w = 0;
-            if (off >= 0 && off + 4 <= Sg) __builtin_memcpy(&w, ig + off, 4);
-            pend[l] = w;
+        const bool fillK = (rm >> grp) & 1ull;
+        int fillOff = -1;
+        if (rm) {                                            // uniform
+            fillOff = __shfl(validLo, grp, WAVE) - FSE_IN_CHUNK + 4 * sub;
+            pend = 0;
+            if (fillK && fillOff >= 0 && fillOff + 4 <= SgK) __builtin_memcpy(&pend, igK + fillOff, 4);
         }
         // (2) issue the symbol gathers of every block with enough records
 #pragma unroll
@@ -294,13 +294,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             }
         }
         // (3) install the input chunks and publish them
-#pragma unroll
-        for (int l = 0; l < FSE_SRV_G; ++l) {
-            if (!((rm >> l) & 1ull)) continue;               // uniform
-            const int nlo = __shfl(validLo, l, WAVE) - FSE_IN_CHUNK;
-            u32* const rg = (u32*)(ldsb + (size_t)(g0 + l) * slotBytes + inOff);
-            if (rev) fse_ring_put_rev(rg, __shfl(S32, l, WAVE), nlo + 4 * lane, pend[l]); else fse_ring_put(rg, nlo + 4 * lane, pend[l]);
-        }
+        if (fillK) { if (rev) fse_ring_put_rev(rgK, SgK, fillOff, pend); else fse_ring_put(rgK, fillOff, pend); }
         if (wantFill) { validLo -= FSE_IN_CHUNK; ctl_store(&ctl->srvValidLo, validLo); }
         // (4) the ring records are in registers now: hand the slots back, then pack and store the symbols
         if (wantFlush) { ctl_store(&ctl->srvFlushed, it); }
@@ -359,7 +353,7 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
 }
 
 // LDS: G tables A[2^maxTableLog] (u16) on table-size aligned addresses | DecCtl[FSE_MAXG] | per block: state ring
-// (64 x 8 B), input ring (512 + 16 B)
+// (64 x 8 B), input ring (256 + 16 B)
 template <bool FAST>
 __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
@@ -474,14 +468,14 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     u32 P = 0;
     long groups = 0;
     u32 iters = 0;
-    int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + 512)
+    int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + FSE_IN_RING)
     if (can) {
         const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the payload
         bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u; P = R8 - B;
         groups = (omax - 3 - op + 3) >> 2;
         // P = q + 8 = byte offset of dword dp.  The ring must reach up to P + 4 and down to the lowest byte a phase can
         // read, P - 8 - 6*16 = P - 104
-        validLo = ((int)bs.q + 8 - 232) & ~255;
+        validLo = ((int)bs.q + 8 - 112) & ~(FSE_IN_CHUNK - 1);          // the ring then reaches from below q - 104 up to above q + 12
     }
     DecCtl* const ctl = ctlAll + (gsl < FSE_MAXG ? gsl : 0);
     if (wave == 0 && gsl < FSE_MAXG && half == 0) {
@@ -504,7 +498,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             const u32 fl = ctl_load(&ctl->srvFlushed);
             const int vlo = ctl_load(&ctl->srvValidLo);
             // room for 16 more records, and the lowest byte this phase can read (p - 6*16 - 16) is in the ring
-            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - 6 * FSE_CHECK_EVERY - 8 >= vlo);
+            // (bit-reversed loop: 16 iterations of at most 44 bits, three window dwords below the last one -> 92 bytes below q + 8)
+            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - (FAST ? 84 : 6 * FSE_CHECK_EVERY + 8) >= vlo);
         }
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
