@@ -175,7 +175,7 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_encTiming(uns
 #define FSE_WV_WAVES 1               // blocks (waves) per workgroup; the waves never synchronise with each other
 __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArgs a, u32 slotWords, u32 tableWords)
 {
-    ETIMING(unsigned long long T0 = __builtin_readcyclecounter(); unsigned long long T1 = 0; unsigned long long T2 = 0; unsigned long long T3 = 0; unsigned long long T4 = 0; u32 rounds = 0;)
+    ETIMING(unsigned long long T0 = __builtin_readcyclecounter(); unsigned long long T1 = 0; unsigned long long T2 = 0; unsigned long long T3 = 0; unsigned long long T4 = 0; u32 rounds = 0; u32 nBad0 = 0; u32 firstBad = 99;)
     extern __shared__ __attribute__((aligned(16))) u32 ldsAll[];
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     u32* const lds = ldsAll + wv * slotWords;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
             xb = wv_init_state(lds0, ttb, src[n - 2]);
             wv_count(lds0, ttb, src, n, 2, j0, xa, xb);
         } else {
-            xa = xb = 1u << tl;                                             // any state will do: it is verified below
+            xa = xb = 1u << tl;                                             // any state will do (measured: the choice does not matter): it is verified below
             wv_count(lds0, ttb, src, n, j0 - warm, j0, xa, xb);
         }
         start = xa | (xb << 16);
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
         const u32 prevEnd = (u32)__shfl_up((int)end, 1, WAVE);
         const bool bad = mine && lane > 0 && start != prevEnd;
         if (!__any(bad)) break;
+        ETIMING(if (rounds == 0) { const unsigned long long bm = __ballot(bad); nBad0 = (u32)__builtin_popcountll(bm); firstBad = (u32)__builtin_ctzll(bm); })
         if (bad) {
             start = prevEnd;
             xa = start & 0xFFFFu; xb = start >> 16;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
         const uintptr_t ad = (uintptr_t)p;
         atomicOr((u32*)(ad & ~(uintptr_t)3), prevTail << (8u * (u32)(ad & 3u)));
     }
-    ETIMING(T4 = __builtin_readcyclecounter(); if (lane == 0 && b < 4096) { unsigned long long* t = g_encTiming + 8 * b; t[0] = T1 - T0; t[1] = T2 - T1; t[2] = T3 - T2; t[3] = T4 - T3; t[4] = rounds; })
+    ETIMING(T4 = __builtin_readcyclecounter(); if (lane == 0 && b < 4096) { unsigned long long* t = g_encTiming + 8 * b; t[0] = T1 - T0; t[1] = T2 - T1; t[2] = T3 - T2; t[3] = T4 - T3; t[4] = rounds; t[5] = nBad0; t[6] = firstBad; })
     if (lane == 0) a.results[b] = result;
 }
 

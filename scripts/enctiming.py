@@ -16,3 +16,4 @@ for P in [int(x) for x in sys.argv[2:]] or [14]:
     m = t.mean(0)
     print("P%d cycles/block: stage %.0f  warm+count %.0f  repair %.0f (rounds mean %.2f max %.0f)  prefix+emit %.0f  total %.0f" % (
         P, m[0], m[1], m[2], m[4], t[:, 4].max(), m[3], m[:4].sum()))
+    print("    lanes repaired in round 1: mean %.2f" % m[5])
