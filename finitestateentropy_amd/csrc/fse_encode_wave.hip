@@ -29,19 +29,40 @@
 #define FSE_WV_WARM_MIN 64u
 #define FSE_WV_WARM_MAX 4096u
 
-#define WV_STEP(ST, sym, nb)                                                                         \
-    {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
-        const u32 f2_ = e_.x, dn_ = e_.y;                                                             \
-        nb = ((ST) + dn_) >> 16;                                                                      \
-        (ST) = *(const u16*)(lds0 + ((((ST) >> nb) << 1) + f2_));                                     \
+// LDS is addressed by absolute byte addresses (u32) through address_space(3) pointers, so that address arithmetic is
+// plain 32-bit VALU work.  The kernel is bound by the CU's LDS pipe (two table reads per symbol for every lane), so the
+// per-symbol entry is packed into 4 bytes whenever the state fits 12 bits (maxTableLog <= 11):
+//   TT4 entry = d16 | fs16 << 16, with deltaNbBits = (maxBitsOut << 16) - minStatePlus (fse_compress.c:131-154):
+//     d16  = (maxBitsOut << 12) - minStatePlus   ->  nbBits = (state + d16) >> 12     (state, minStatePlus <= 4096)
+//     fs16 = deltaFindState + (absolute LDS address of stateTable[0]) / 2, signed     ->  next = lds16[((state >> nbBits) + fs16) << 1]
+//   TT8 entry (maxTableLog 12) = {2*deltaFindState + address of the stateTable, deltaNbBits}: nbBits = (state + deltaNbBits) >> 16.
+typedef const __attribute__((address_space(3))) u16* wv_lds_u16;
+typedef const __attribute__((address_space(3))) u32* wv_lds_u32;
+typedef u32 wv_u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) wv_u32x2* wv_lds_u64;
+DEV u32 wv_lds_addr(const void* p) { return (u32)(uintptr_t)(const __attribute__((address_space(3))) u8*)p; }
+template <bool TT4>
+DEV void wv_step(u32& st, u32 ttb, u32 sym, u32& nb)                    // FSE_encodeSymbol (fse.h:514-521) without the bit output
+{
+    if (TT4) {
+        const u32 e = *(wv_lds_u32)(uintptr_t)(ttb + 4u * sym);
+        nb = (st + (e & 0xFFFFu)) >> 12;
+        st = *(wv_lds_u16)(uintptr_t)(((st >> nb) + (u32)((int)e >> 16)) << 1);
+    } else {
+        const wv_u32x2 e = *(wv_lds_u64)(uintptr_t)(ttb + 8u * sym);
+        nb = (st + e.y) >> 16;
+        st = *(wv_lds_u16)(uintptr_t)(((st >> nb) << 1) + e.x);
     }
-#define WV_STEP_BITS(ST, sym, nb, bits)                                                              \
-    {   const uint2 e_ = *(const uint2*)(ttb + 8u * (sym));                                           \
-        const u32 f2_ = e_.x, dn_ = e_.y;                                                             \
-        nb = ((ST) + dn_) >> 16;                                                                      \
-        bits = __builtin_amdgcn_ubfe((ST), 0u, nb);                                                   \
-        (ST) = *(const u16*)(lds0 + ((((ST) >> nb) << 1) + f2_));                                     \
-    }
+}
+template <bool TT4>
+DEV void wv_step_bits(u32& st, u32 ttb, u32 sym, u32& nb, u32& bits)
+{
+    const u32 before = st;
+    wv_step<TT4>(st, ttb, sym, nb);
+    bits = __builtin_amdgcn_ubfe(before, 0u, nb);
+}
+#define WV_STEP(ST, sym, nb) wv_step<TT4>(ST, ttb, sym, nb);
+#define WV_STEP_BITS(ST, sym, nb, bits) wv_step_bits<TT4>(ST, ttb, sym, nb, bits);
 
 DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
@@ -86,8 +107,8 @@ struct WvSink {
 // Run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even).  Returns the
 // number of bits they emit; with EMIT the bits also go to the sink.  The source is streamed downwards: 64 bytes (four
 // 16-byte loads of one 64-byte segment, so the segment is fetched from memory once) one segment ahead of its use.
-template <bool EMIT>
-DEV u32 wv_run(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink* k)
+template <bool EMIT, bool TT4>
+DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink* k)
 {
     u32 bits = 0, j = ja;
     u32 na, nbb, ba, bb;
@@ -126,25 +147,32 @@ DEV u32 wv_run(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 
     }
     return bits;
 }
-DEV u32 wv_count(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
-{ return wv_run<false>(lds0, ttb, src, n, ja, jb, xa, xb, nullptr); }
-DEV void wv_emit(const u8* lds0, const u8* ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
-{ wv_run<true>(lds0, ttb, src, n, ja, jb, xa, xb, &k); }
+template <bool TT4> DEV u32 wv_count(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
+{ return wv_run<false, TT4>(ttb, src, n, ja, jb, xa, xb, nullptr); }
+template <bool TT4> DEV void wv_emit(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
+{ wv_run<true, TT4>(ttb, src, n, ja, jb, xa, xb, &k); }
 
-DEV u32 wv_init_state(const u8* lds0, const u8* ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
+template <bool TT4>
+DEV u32 wv_init_state(u32 ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
 {
-    const uint2 e = *(const uint2*)(ttb + 8u * sym);
+    if (TT4) {                                           // nbBitsOut = maxBitsOut, value = minStatePlus (see the entry format)
+        const u32 e = *(wv_lds_u32)(uintptr_t)(ttb + 4u * sym);
+        const u32 d = e & 0xFFFFu, nb = (d >> 12) + 1u, msp = (nb << 12) - d;
+        return *(wv_lds_u16)(uintptr_t)(((msp >> nb) + (u32)((int)e >> 16)) << 1);
+    }
+    const wv_u32x2 e = *(wv_lds_u64)(uintptr_t)(ttb + 8u * sym);
     const u32 nb = (e.y + (1u << 15)) >> 16;
-    return *(const u16*)(lds0 + (((((nb << 16) - e.y) >> nb) << 1) + e.x));
+    return *(wv_lds_u16)(uintptr_t)(((((nb << 16) - e.y) >> nb) << 1) + e.x);
 }
 
 // the whole block by one lane, byte by byte (lib/fse_compress.c:554-623 as written): used when a lane's share of the
 // output is shorter than one byte, which the word-wise writer above does not handle
-DEV size_t wv_serial(const u8* lds0, const u8* ttb, const u8* src, u32 n, u8* dst, size_t cap, u32 tl)
+template <bool TT4>
+DEV size_t wv_serial(u32 ttb, const u8* src, u32 n, u8* dst, size_t cap, u32 tl)
 {
     const u32 lim = (u32)(cap - 8);
     u64 acc = 0; u32 nacc = 0, pos = 0;
-    u32 xa = wv_init_state(lds0, ttb, src[n - 1]), xb = wv_init_state(lds0, ttb, src[n - 2]);
+    u32 xa = wv_init_state<TT4>(ttb, src[n - 1]), xb = wv_init_state<TT4>(ttb, src[n - 2]);
     for (u32 j = 2; j < n; ++j) {
         const u32 sym = src[n - 1 - j];
         u32 nb, bits;
@@ -172,109 +200,127 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_encTiming(uns
 #define ETIMING(x)
 #endif
 
-#define FSE_WV_WAVES 1               // blocks (waves) per workgroup; the waves never synchronise with each other
+#define FSE_WV_WAVES 1               // waves per workgroup; the waves never synchronise with each other
+// Lanes per block.  A range must be long compared with the time two encoders need to merge (P14: ~90 symbols per chain,
+// so with 64 ranges of 512 symbols over half of the speculated starts fail and the repair rounds cost as much as the
+// counting pass); 32 lanes per block = two blocks per wave, ranges twice as long, half as many links to verify.
+#define WV_LANES 32u
+#define WV_BPW (64u / WV_LANES)      // blocks per wave
+template <bool TT4>
 __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArgs a, u32 slotWords, u32 tableWords)
 {
     ETIMING(unsigned long long T0 = __builtin_readcyclecounter(); unsigned long long T1 = 0; unsigned long long T2 = 0; unsigned long long T3 = 0; unsigned long long T4 = 0; u32 rounds = 0; u32 nBad0 = 0; u32 firstBad = 99;)
     extern __shared__ __attribute__((aligned(16))) u32 ldsAll[];
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    u32* const lds = ldsAll + wv * slotWords;
-    const u8* const ldsb = (const u8*)lds;
-    const u32 ldsOff = wv * slotWords * 4u;                                 // LDS byte address of this wave's slot
-    const size_t b = (size_t)blockIdx.x * FSE_WV_WAVES + wv;
-    if (b >= a.nBlocks) return;
+    const u32 part = lane / WV_LANES, hl = lane % WV_LANES;                 // my block of this wave, my lane within it
+    const u32 partBase = lane - hl;
+    const u32 slot = wv * WV_BPW + part;
+    u32* const lds = ldsAll + slot * slotWords;
+    const u32 ldsOff = wv_lds_addr(ldsAll) + slot * slotWords * 4u;         // absolute LDS byte address of this block's slot
+    const size_t b = ((size_t)blockIdx.x * FSE_WV_WAVES + wv) * WV_BPW + part;
 
+    // ---- per-block set-up; `on` = this block is (still) being encoded by its lanes.  Everything below is uniform per block,
+    //      the blocks of a wave diverge freely; wave-wide shuffles are only read inside a block's own lanes.
+    bool on = b < a.nBlocks;
     u32 hdr = 0;
-    if (a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) return; hdr = a.meta[b].hdrSize; }
-    const u32* const gct = a.ctables + b * a.ctStrideU32;
-    const u32 h0 = gct[0];
-    const u32 tl = h0 & 0xFFFFu, msv = h0 >> 16;
-    if (tl > a.maxTableLog || msv > 255u) { if (lane == 0) a.results[b] = FERR(tableLog_tooLarge); return; }
-    const u8* const src = view_ptr(a.src, b);
-    const size_t n64 = view_size(a.src, b);
-    u8* const dst = a.dst + b * a.dstStride + hdr;
+    if (on && a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) on = false; else hdr = a.meta[b].hdrSize; }
+    const u32* const gct = a.ctables + (on ? b : 0) * a.ctStrideU32;
+    u32 tl = 0, msv = 0;
+    if (on) {
+        const u32 h0 = gct[0];
+        tl = h0 & 0xFFFFu; msv = h0 >> 16;
+        if (tl > a.maxTableLog || msv > 255u) { if (hl == 0) a.results[b] = FERR(tableLog_tooLarge); on = false; }
+    }
+    const u8* const src = on ? view_ptr(a.src, b) : nullptr;
+    const size_t n64 = on ? view_size(a.src, b) : 0;
+    u8* const dst = a.dst + (on ? b : 0) * a.dstStride + hdr;
     const size_t cap = a.dstCapacity - hdr;
-    if (n64 >= ((size_t)1 << 31)) { if (lane == 0) a.results[b] = FERR(srcSize_wrong); return; }
+    if (on && n64 >= ((size_t)1 << 31)) { if (hl == 0) a.results[b] = FERR(srcSize_wrong); on = false; }
     const u32 n = (u32)n64;
-    if (n <= 2 || cap <= 8) { if (lane == 0) a.results[b] = 0; return; }    // fse_compress.c:566-568
+    if (on && (n <= 2 || cap <= 8)) { if (hl == 0) a.results[b] = 0; on = false; }    // fse_compress.c:566-568
 
     // ---- stage the CTable (coalesced): word 0 header, stateTable at byte 4, symbolTT rebased to LDS byte addresses
     const u32 ttStart = 1 + (tl ? (1u << (tl - 1)) : 1u);
     const u32 ttAl = (ttStart + 1u) & ~1u;                                  // 8-byte aligned symbolTT copy
-    const u32 words = ttStart + 2 * (msv + 1);
     u32 presentLane = 0;
-    for (u32 i = lane; i < words; i += 64) {
-        u32 v = gct[i];
-        if (i >= ttStart) {
-            if (((i - ttStart) & 1u) == 0) v = 2u * v + 4u + ldsOff;
-            else presentLane += v != ((tl + 1) << 16) - (1u << tl);           // deltaNbBits of a symbol that does not occur (fse_compress.c:143)
-            lds[i - ttStart + ttAl] = v;
-        } else lds[i] = v;
+    if (on) {
+        for (u32 i = hl; i < ttStart; i += WV_LANES) lds[i] = gct[i];
+        for (u32 sy = hl; sy <= msv; sy += WV_LANES) {
+            const u32 dfs = gct[ttStart + 2 * sy], dnb = gct[ttStart + 2 * sy + 1];
+            presentLane += dnb != ((tl + 1) << 16) - (1u << tl);             // deltaNbBits of a symbol that does not occur (fse_compress.c:143)
+            if (TT4) {
+                const u32 mbo = (dnb >> 16) + 1u, msp = (mbo << 16) - dnb;    // 1 <= minStatePlus <= 2 * tableSize
+                lds[ttAl + sy] = (((mbo << 12) - msp) & 0xFFFFu) | ((dfs + 2u + (ldsOff >> 1)) << 16);
+            } else {
+                lds[ttAl + 2 * sy] = 2u * dfs + 4u + ldsOff;
+                lds[ttAl + 2 * sy + 1] = dnb;
+            }
+        }
     }
     u32 present = presentLane;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) present += (u32)__shfl_xor((int)present, off, WAVE);
+    for (int off = (int)WV_LANES / 2; off > 0; off >>= 1) present += (u32)__shfl_xor((int)present, off, WAVE);
     u32 warm = (FSE_WV_WARM_FACTOR << tl) / (present ? present : 1u);
     warm = (warm + 63u) & ~63u;
     warm = warm < FSE_WV_WARM_MIN ? FSE_WV_WARM_MIN : (warm > FSE_WV_WARM_MAX ? FSE_WV_WARM_MAX : warm);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // the slot is private to this wave: LDS is in order per wave
-    const u8* const ttb = ldsb + 4u * ttAl;
-    const u8* const lds0 = (const u8*)ldsAll;                              // symbolTT holds absolute LDS byte addresses
-    u32* const ringBase = lds + tableWords;                                // 64 output rings behind the table
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // the slots are private to this wave: LDS is in order per wave
+    const u32 ttb = ldsOff + 4u * ttAl;                                    // absolute LDS address of the symbolTT copy
+    u32* const ringBase = lds + tableWords;                                // WV_LANES output rings behind the table
     ETIMING(T1 = __builtin_readcyclecounter();)
 
-    // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains).  Lane t owns
+    // ---- ranges in emission order: symbols j = 2 .. n-1 (j = 0, 1 only initialise the chains).  Lane t of the block owns
     //      [bound(t), bound(t+1)); the boundaries are even (every range starts on chain A) and, for blocks of >= 4 KiB,
     //      shifted so that the ranges above lane 0's end on 64-byte aligned source addresses (whole segments per load group)
-    const u32 m = n - 2;
-    u32 C = (m + 63u) / 64u;
+    const u32 m = on ? n - 2 : 0u;
+    u32 C = (m + WV_LANES - 1u) / WV_LANES;
     C = m >= 4096u ? (C + 63u) & ~63u : (C + 1u) & ~1u;
+    C = C ? C : 2u;
     const u32 delta = m >= 4096u ? (u32)((0 - ((uintptr_t)src + n - 2u)) & 62u) : 0u;   // < 64 <= C, even
-    const u32 lo0 = lane ? 2 + lane * C - delta : 2u, hi0 = 2 + (lane + 1) * C - delta;
+    const u32 lo0 = hl ? 2 + hl * C - delta : 2u, hi0 = 2 + (hl + 1) * C - delta;
     const u32 j0 = lo0 < n ? lo0 : n;
-    const u32 j1 = (lane == 63u || hi0 > n) ? n : hi0;
-    const bool mine = j0 < n;                                               // non-empty range
-    const u32 lastLane = (m + delta - 1) / C < 63u ? (m + delta - 1) / C : 63u;   // owner of the final states
+    const u32 j1 = (hl == WV_LANES - 1u || hi0 > n) ? n : hi0;
+    const bool mine = on && j0 < n;                                         // non-empty range
+    const u32 lastLane = m ? ((m + delta - 1) / C < WV_LANES - 1u ? (m + delta - 1) / C : WV_LANES - 1u) : 0u;   // owner of the final states
 
     // ---- pass 1: speculated start, bit count, end states
     u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
     if (mine) {
         if (j0 <= 2 + warm) {                                        // the warm-up would reach the block end: be exact
-            xa = wv_init_state(lds0, ttb, src[n - 1]);
-            xb = wv_init_state(lds0, ttb, src[n - 2]);
-            wv_count(lds0, ttb, src, n, 2, j0, xa, xb);
+            xa = wv_init_state<TT4>(ttb, src[n - 1]);
+            xb = wv_init_state<TT4>(ttb, src[n - 2]);
+            wv_count<TT4>(ttb, src, n, 2, j0, xa, xb);
         } else {
             xa = xb = 1u << tl;                                             // any state will do (measured: the choice does not matter): it is verified below
-            wv_count(lds0, ttb, src, n, j0 - warm, j0, xa, xb);
+            wv_count<TT4>(ttb, src, n, j0 - warm, j0, xa, xb);
         }
         start = xa | (xb << 16);
-        bits = wv_count(lds0, ttb, src, n, j0, j1, xa, xb);
+        bits = wv_count<TT4>(ttb, src, n, j0, j1, xa, xb);
         end = xa | (xb << 16);
     }
     ETIMING(T2 = __builtin_readcyclecounter();)
     // ---- verification / repair: start[t] must equal end[t-1]; lane 0 (and every lane that ran from the block end) is exact
     for (;;) {
         const u32 prevEnd = (u32)__shfl_up((int)end, 1, WAVE);
-        const bool bad = mine && lane > 0 && start != prevEnd;
+        const bool bad = mine && hl > 0 && start != prevEnd;
         if (!__any(bad)) break;
         ETIMING(if (rounds == 0) { const unsigned long long bm = __ballot(bad); nBad0 = (u32)__builtin_popcountll(bm); firstBad = (u32)__builtin_ctzll(bm); })
         if (bad) {
             start = prevEnd;
             xa = start & 0xFFFFu; xb = start >> 16;
-            bits = wv_count(lds0, ttb, src, n, j0, j1, xa, xb);
+            bits = wv_count<TT4>(ttb, src, n, j0, j1, xa, xb);
             end = xa | (xb << 16);
         }
         ETIMING(++rounds;)
     }
     ETIMING(T3 = __builtin_readcyclecounter();)
 
-    // ---- prefix sum of the bit counts
+    // ---- prefix sum of the bit counts over the block's lanes
     u32 incl = bits;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    for (int off = 1; off < (int)WV_LANES; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)hl >= off) incl += o; }
     const u32 excl = incl - bits;
-    const u64 bodyBits = (u32)__shfl((int)incl, 63, WAVE);
-    const u32 fin = (u32)__shfl((int)end, (int)lastLane, WAVE);
+    const u64 bodyBits = (u32)__shfl((int)incl, (int)(partBase + WV_LANES - 1u), WAVE);
+    const u32 fin = (u32)__shfl((int)end, (int)(partBase + lastLane), WAVE);
 
     // ---- verdict (BIT_closeCStream, bitstream.h:254-260): total bits incl. the two states and the end mark
     const u64 totalBits = bodyBits + 2u * tl + 1u;
@@ -282,30 +328,31 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     size_t csize = (whole >= cap - 8) ? 0 : (size_t)((totalBits + 7) >> 3);
     size_t result = csize;
     if (a.meta) result = (csize != 0 && (size_t)hdr + csize < n64 - 1) ? (size_t)hdr + csize : 0;   // fse_compress.c:668-676
-    if (result == 0) { if (lane == 0) a.results[b] = 0; return; }
+    if (on && result == 0) { if (hl == 0) a.results[b] = 0; on = false; }
 
     // ---- pass 2.  The word-wise writer needs every range (but the last) to span at least one byte of output
-    if (__any(mine && lane < lastLane && bits < 8u)) {
-        if (a.meta && a.onlyState == FSE_ENC_PAR) {                         // the lane-per-block kernel runs right after this one
-            if (lane == 0) const_cast<FseMeta*>(a.meta)[b].state = FSE_ENC_LANE;
-            return;
+    {   const unsigned long long thin = __ballot(on && mine && hl < lastLane && bits < 8u);
+        const unsigned long long partMask = (WV_LANES == 64u ? ~0ull : ((1ull << (WV_LANES & 63u)) - 1ull)) << partBase;
+        if (on && (thin & partMask)) {
+            if (a.meta && a.onlyState == FSE_ENC_PAR) {                     // the lane-per-block kernel runs right after this one
+                if (hl == 0) const_cast<FseMeta*>(a.meta)[b].state = FSE_ENC_LANE;
+            } else if (hl == 0) {
+                const size_t cs = wv_serial<TT4>(ttb, src, n, dst, cap, tl);
+                a.results[b] = a.meta ? ((cs != 0 && (size_t)hdr + cs < n64 - 1) ? (size_t)hdr + cs : 0) : cs;
+            }
+            on = false;
         }
-        if (lane == 0) {
-            const size_t cs = wv_serial(lds0, ttb, src, n, dst, cap, tl);
-            a.results[b] = a.meta ? ((cs != 0 && (size_t)hdr + cs < n64 - 1) ? (size_t)hdr + cs : 0) : cs;
-        }
-        return;
     }
     u32 tail = 0;
-    if (mine) {
+    if (on && mine) {
         WvSink k;
         const u32 lead = (u32)((uintptr_t)dst & (WV_RING - 1));
         const u32 off0 = lead + (excl >> 3);                                // my first byte, as an offset from dstAl
-        k.dstAl = dst - lead; k.ring = ringBase + lane * (WV_RING / 4);
+        k.dstAl = dst - lead; k.ring = ringBase + hl * (WV_RING / 4);
         k.woff = off0 & ~3u; k.done = off0; k.acc = 0; k.nacc = 8u * (off0 & 3u) + (excl & 7u);
         xa = start & 0xFFFFu; xb = start >> 16;
-        wv_emit(lds0, ttb, src, n, j0, j1, xa, xb, k);
-        if (lane == lastLane) {
+        wv_emit<TT4>(ttb, src, n, j0, j1, xa, xb, k);
+        if (hl == lastLane) {
             // fse_compress.c:608-609 : CState2 then CState1.  n even -> CState2 is the even-distance chain (:577-580), n odd -> CState1 (:572-576)
             const u32 fa = fin & 0xFFFFu, fb = fin >> 16;
             const u32 c2 = (n & 1u) ? fb : fa, c1 = (n & 1u) ? fa : fb;
@@ -320,23 +367,27 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
         tail = (u32)(k.acc >> (k.nacc & ~7u));                              // < 8 bits, belong to the next lane's first byte
     }
     const u32 prevTail = (u32)__shfl_up((int)tail, 1, WAVE);
-    if (mine && lane > 0 && (excl & 7u)) {
+    if (on && mine && hl > 0 && (excl & 7u)) {
         u8* const p = dst + (excl >> 3);
         const uintptr_t ad = (uintptr_t)p;
         atomicOr((u32*)(ad & ~(uintptr_t)3), prevTail << (8u * (u32)(ad & 3u)));
     }
-    ETIMING(T4 = __builtin_readcyclecounter(); if (lane == 0 && b < 4096) { unsigned long long* t = g_encTiming + 8 * b; t[0] = T1 - T0; t[1] = T2 - T1; t[2] = T3 - T2; t[3] = T4 - T3; t[4] = rounds; t[5] = nBad0; t[6] = firstBad; })
-    if (lane == 0) a.results[b] = result;
+    ETIMING(T4 = __builtin_readcyclecounter(); if (hl == 0 && b < 4096) { unsigned long long* t = g_encTiming + 8 * b; t[0] = T1 - T0; t[1] = T2 - T1; t[2] = T3 - T2; t[3] = T4 - T3; t[4] = rounds; t[5] = nBad0; t[6] = firstBad; })
+    if (on && hl == 0) a.results[b] = result;
 }
 
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const u32 tableWords = (2 + (1u << (a.maxTableLog - 1)) + 512 + 2 + 31) & ~31u;    // rings start 128-byte aligned
-    const u32 slotWords = tableWords + 64 * (WV_RING / 4);
-    const size_t ldsBytes = 4 * (size_t)slotWords * FSE_WV_WAVES;
+    const bool tt4 = a.maxTableLog <= 11;                                   // states fit 12 bits: 4-byte symbolTT entries
+    const u32 tableWords = (2 + (1u << (a.maxTableLog - 1)) + (tt4 ? 256 : 512) + 2 + 31) & ~31u;    // rings start 128-byte aligned
+    const u32 slotWords = tableWords + WV_LANES * (WV_RING / 4);
+    const size_t ldsBytes = 4 * (size_t)slotWords * WV_BPW * FSE_WV_WAVES;
+    const size_t perGroup = (size_t)WV_BPW * FSE_WV_WAVES;
     probe_before(PK_FSE_ENCODE_WAVE, s);
-    hipLaunchKernelGGL(k_fse_encode_wave, dim3((unsigned)((a.nBlocks + FSE_WV_WAVES - 1) / FSE_WV_WAVES)), dim3(64 * FSE_WV_WAVES), ldsBytes, s, a, slotWords, tableWords);
+    const dim3 grid((unsigned)((a.nBlocks + perGroup - 1) / perGroup));
+    if (tt4) hipLaunchKernelGGL(k_fse_encode_wave<true>, grid, dim3(64 * FSE_WV_WAVES), ldsBytes, s, a, slotWords, tableWords);
+    else     hipLaunchKernelGGL(k_fse_encode_wave<false>, grid, dim3(64 * FSE_WV_WAVES), ldsBytes, s, a, slotWords, tableWords);
     probe_after(PK_FSE_ENCODE_WAVE, s);
     return hipGetLastError();
 }

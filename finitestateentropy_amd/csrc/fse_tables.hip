@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
     const FseMeta m = a.meta[b];
     if (m.state == 0) return;                                              // uniform
     const WaveBuildLds w = wave_build_carve(wbLds, capTs);
-    u32* const img = (u32*)(wbLds + 512 + 520 + 256 + 3 * (size_t)capTs + 16384 + 8192);   // CTable image: 1 + capTs/2 + 512 words
+    u32* const img = (u32*)(wbLds + ((wave_build_lds_bytes(capTs) + 15) & ~(size_t)15));     // CTable image: 1 + capTs/2 + 512 words
     u16* const cumAll = (u16*)(img + 1 + capTs / 2 + 512);                                  // [256] first stateTable slot of every symbol
     *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
     __syncthreads();
@@ -146,25 +146,23 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
         const u32 ns = (next << nb) - ts;
         // bit-reversed format (see fse_decode.hip): nbBits | rev_tl(newState) << (16 - maxLog); the cell of state u goes
         // to position rev_tl(u), which the copy-out below takes care of
-        if (rev) w.cell[u] = (u16)(nb | ((__brev(ns) >> (32u - tl)) << (16u - a.maxLog)));
-        else     w.cell[u] = (u16)((ns & 0xFFFu) | (nb << 12));
+        if (rev) w.cell[wb_ci(u)] = (u16)(nb | ((__brev(ns) >> (32u - tl)) << (16u - a.maxLog)));
+        else     w.cell[wb_ci(u)] = (u16)((ns & 0xFFFu) | (nb << 12));
     });
     u32* const A32 = (u32*)(a.atab + b * capTs);
     u32* const S32 = (u32*)(a.symtab + b * capTs);
     if (rev) {
         const u32 rs = 32u - tl;                                           // tl >= FSE_MIN_TABLELOG = 5
         for (u32 i = lane; i < ts / 2; i += 64)
-            A32[i] = (u32)w.cell[__brev(2u * i) >> rs] | ((u32)w.cell[__brev(2u * i + 1u) >> rs] << 16);
+            A32[i] = (u32)w.cell[wb_ci(__brev(2u * i) >> rs)] | ((u32)w.cell[wb_ci(__brev(2u * i + 1u) >> rs)] << 16);
         for (u32 i = lane; i < ts / 4; i += 64) {
             u32 y = 0;
-            for (u32 k = 0; k < 4; ++k) y |= (u32)w.symTab[__brev(4u * i + k) >> rs] << (8u * k);
+            for (u32 k = 0; k < 4; ++k) y |= (u32)w.symTab[wb_si(__brev(4u * i + k) >> rs)] << (8u * k);
             S32[i] = y;
         }
     } else {
-        const u32* const c32 = (const u32*)w.cell;
-        for (u32 i = lane; i < ts / 2; i += 64) A32[i] = c32[i];
-        const u32* const y32 = (const u32*)w.symTab;
-        for (u32 i = lane; i < ts / 4; i += 64) S32[i] = y32[i];
+        for (u32 i = lane; i < ts / 2; i += 64) A32[i] = *(const u32*)(w.cell + wb_ci(2u * i));
+        for (u32 i = lane; i < ts / 4; i += 64) S32[i] = *(const u32*)(w.symTab + wb_si(4u * i));
     }
     if (lane == 0) a.meta[b].state = 1u | (fast ? 2u : 0u);
 }
@@ -176,7 +174,7 @@ hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     const u32 capTs = 1u << a.maxTl;
-    const size_t ldsBytes = 512 + 520 + 256 + 3 * (size_t)capTs + 16384 + 8192 + 4 * (1 + (size_t)capTs / 2 + 512) + 512;
+    const size_t ldsBytes = ((wave_build_lds_bytes(capTs) + 15) & ~(size_t)15) + 4 * (1 + (size_t)capTs / 2 + 512) + 512;
     probe_before(PK_FSE_CPREP, s);
     hipLaunchKernelGGL(k_fse_cnorm, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_fse_cbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
@@ -187,7 +185,7 @@ hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     const u32 capTs = 1u << a.maxLog;
-    const size_t ldsBytes = 512 + 520 + 256 + 3 * (size_t)capTs + 16384 + 8192;
+    const size_t ldsBytes = wave_build_lds_bytes(capTs);
     probe_before(PK_FSE_DPREP, s);
     hipLaunchKernelGGL(k_fse_dparse, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);

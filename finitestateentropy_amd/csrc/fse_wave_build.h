@@ -33,19 +33,24 @@ struct WaveBuildLds {        // LDS scratch of one wave, tableSize = 1 << tl <= 
     s16* nrm;                // [256] normalized counters, zero beyond maxSV (input)
     u16* cumP;               // [257] (unused by the core; callers may use it)
     u8*  symP;               // [256] symbols in use (counter != 0), ascending
-    u8*  symTab;             // [capTs] symbol of every cell (output of the spread)
-    u16* cell;               // [capTs] rank inside the lane range; the emitter may overwrite cell[u] with its result
+    u8*  symTab;             // [wb_si(capTs)] symbol of every cell (output of the spread), index through wb_si()
+    u16* cell;               // [wb_ci(capTs)] rank inside the lane range, index through wb_ci(); the emitter may overwrite cell[wb_ci(u)] with its result
     u32* cnt;                // [256 * 16] byte matrix cnt[symbol][lane]
     u16* coarse;             // [256 * 16] per symbol: cells before lane group j (4 lanes per group)
 };
-DEV size_t wave_build_lds_bytes(u32 capTs) { return 512 + 520 + 256 + (size_t)capTs + 2 * (size_t)capTs + 16384 + 8192; }
+// cell[] / symTab[] are indexed through wb_ci() / wb_si(): every row of 32 cells is followed by 4 bytes of padding.  Lane l
+// works on cells [l*C, (l+1)*C) (C = 32 at tableLog 11), so without the padding the 64 lanes of one LDS instruction
+// would sit 64 (or 32) bytes apart -- on 2 (4) of the 32 banks; with it they are 17 (9) dwords apart: conflict-free.
+__host__ __device__ inline u32 wb_ci(u32 u) { return u + ((u >> 5) << 1); }     // u16 arrays (cell, marks)
+__host__ __device__ inline u32 wb_si(u32 u) { return u + ((u >> 5) << 2); }     // u8 array (symTab)
+__host__ __device__ inline size_t wave_build_lds_bytes(u32 capTs) { return 16384 + 8192 + 2 * (size_t)wb_ci(capTs) + wb_si(capTs) + 512 + 520 + 256; }
 DEV WaveBuildLds wave_build_carve(u8* base, u32 capTs)
 {
     WaveBuildLds w;
     w.cnt = (u32*)base; base += 16384;                   // 16-byte aligned parts first
     w.coarse = (u16*)base; base += 8192;
-    w.cell = (u16*)base; base += 2 * (size_t)capTs;
-    w.symTab = base; base += capTs;
+    w.cell = (u16*)base; base += 2 * (size_t)wb_ci(capTs);
+    w.symTab = base; base += wb_si(capTs);
     w.nrm = (s16*)base; base += 512;
     w.cumP = (u16*)base; base += 520;
     w.symP = base;
@@ -95,7 +100,7 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
     const u32 nLow = (totals >> 13) & 0x1FFu, nAny = totals >> 22;
     const int high = (int)ts - 1 - (int)nLow;                             // highThreshold (-1: every cell is a low-probability one)
     // clear the spread marks and the count matrix rows in use
-    if (act) { if (C >= 8) for (u32 i = 0; i < C; i += 8) *(uint4*)(marks + m0 + i) = make_uint4(0, 0, 0, 0); else for (u32 i = 0; i < C; ++i) marks[m0 + i] = 0; }
+    if (act) { if (C >= 2) for (u32 i = 0; i < C; i += 2) *(u32*)(marks + wb_ci(m0 + i)) = 0; else marks[wb_ci(m0)] = 0; }
     {   const u32 rows16 = (maxSV + 1) * 16;                              // dwords
         for (u32 i = 4 * lane; i < rows16; i += 256) *(uint4*)(w.cnt + i) = make_uint4(0, 0, 0, 0);
     }
@@ -106,8 +111,8 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (n[i] != 0) w.symP[anyBase++] = (u8)(4 * lane + i);
-        if (n[i] > 0) { marks[posBase] = (u16)(4 * lane + i + 1); posBase += (u32)n[i]; }
-        else if (n[i] == -1) { w.symTab[ts - 1 - lowBase] = (u8)(4 * lane + i); ++lowBase; }
+        if (n[i] > 0) { marks[wb_ci(posBase)] = (u16)(4 * lane + i + 1); posBase += (u32)n[i]; }
+        else if (n[i] == -1) { w.symTab[wb_si(ts - 1 - lowBase)] = (u8)(4 * lane + i); ++lowBase; }
     }
     // ---- spread: lane l visits m in [l*C, (l+1)*C); the k-th kept visit belongs to the symbol of the last mark at or
     //      before k, i.e. a running maximum over the marks (symbols ascend with k)
@@ -122,7 +127,7 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
     for (u32 i = 0; i < nv; i += 8) {
         u32 v[8];
 #pragma unroll
-        for (u32 j = 0; j < 8; ++j) { const u32 idx = k0 + i + j; v[j] = marks[idx < ts ? idx : ts - 1]; }
+        for (u32 j = 0; j < 8; ++j) { const u32 idx = k0 + i + j; v[j] = marks[wb_ci(idx < ts ? idx : ts - 1)]; }
 #pragma unroll
         for (u32 j = 0; j < 8; ++j) if (i + j < nv) localMax = v[j] > localMax ? v[j] : localMax;
     }
@@ -139,14 +144,14 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
 #pragma unroll
             for (u32 j = 0; j < 8; ++j) {
                 uu[j] = u; keep[j] = (int)u <= high;
-                v[j] = marks[k < ts ? k : ts - 1];
+                v[j] = marks[wb_ci(k < ts ? k : ts - 1)];
                 k += keep[j]; u = (u + step) & mask;
             }
 #pragma unroll
-            for (u32 j = 0; j < 8; ++j) if (keep[j]) { run = v[j] > run ? v[j] : run; w.symTab[uu[j]] = (u8)(run - 1u); }
+            for (u32 j = 0; j < 8; ++j) if (keep[j]) { run = v[j] > run ? v[j] : run; w.symTab[wb_si(uu[j])] = (u8)(run - 1u); }
         }
         for (; i < C; ++i) {
-            if ((int)u <= high) { const u32 v = marks[k++]; run = v > run ? v : run; w.symTab[u] = (u8)(run - 1u); }
+            if ((int)u <= high) { const u32 v = marks[wb_ci(k)]; ++k; run = v > run ? v : run; w.symTab[wb_si(u)] = (u8)(run - 1u); }
             u = (u + step) & mask;
         }
     }
@@ -159,7 +164,8 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
     if (act) {
         u32 i = 0;
         for (; i + 8 <= C; i += 8) {
-            const uint2 sy = *(const uint2*)(w.symTab + m0 + i);
+            const u32* const syp = (const u32*)(w.symTab + wb_si(m0 + i));    // 8 cells of one row: two aligned dwords
+            const uint2 sy = make_uint2(syp[0], syp[1]);
             u32 old[8];
 #pragma unroll
             for (u32 j = 0; j < 8; ++j) {
@@ -170,13 +176,14 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
 #pragma unroll
             for (u32 j = 0; j < 8; ++j) old[j] = (old[j] >> sh8) & 0xFFu;
             pk.x = old[0] | (old[1] << 16); pk.y = old[2] | (old[3] << 16); pk.z = old[4] | (old[5] << 16); pk.w = old[6] | (old[7] << 16);
-            *(uint4*)(w.cell + m0 + i) = pk;
+            u32* const cp = (u32*)(w.cell + wb_ci(m0 + i));
+            cp[0] = pk.x; cp[1] = pk.y; cp[2] = pk.z; cp[3] = pk.w;
         }
         for (; i < C; ++i) {
             const u32 u = m0 + i;
-            const u32 s = w.symTab[u];
+            const u32 s = w.symTab[wb_si(u)];
             const u32 old = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
-            w.cell[u] = (u16)((old >> sh8) & 0xFFu);
+            w.cell[wb_ci(u)] = (u16)((old >> sh8) & 0xFFu);
         }
     }
     __syncthreads();
@@ -203,8 +210,10 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
         const u32 belowMask = (1u << sh8) - 1u;
         u32 i = 0;
         for (; i + 8 <= C; i += 8) {
-            const uint2 sy = *(const uint2*)(w.symTab + m0 + i);
-            const uint4 lr = *(const uint4*)(w.cell + m0 + i);
+            const u32* const syp = (const u32*)(w.symTab + wb_si(m0 + i));
+            const uint2 sy = make_uint2(syp[0], syp[1]);
+            const u32* const cp = (const u32*)(w.cell + wb_ci(m0 + i));
+            const uint4 lr = make_uint4(cp[0], cp[1], cp[2], cp[3]);
             u32 s[8], co[8], cn[8], pl[8];
 #pragma unroll
             for (u32 j = 0; j < 8; ++j) {
@@ -220,8 +229,8 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
         }
         for (; i < C; ++i) {
             const u32 u = m0 + i;
-            const u32 s = w.symTab[u];
-            const u32 r = (u32)w.cell[u] + (u32)w.coarse[s * 16 + grp] + wb_bytesum(w.cnt[s * 16 + grp] & belowMask);
+            const u32 s = w.symTab[wb_si(u)];
+            const u32 r = (u32)w.cell[wb_ci(u)] + (u32)w.coarse[s * 16 + grp] + wb_bytesum(w.cnt[s * 16 + grp] & belowMask);
             emit(u, s, r, payload(s));
         }
     }
