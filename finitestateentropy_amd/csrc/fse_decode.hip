@@ -186,6 +186,8 @@ struct DecCtl {
 
 DEV u32 ctl_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV u32 ctl_peek(const u32* p) { const u32 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __asm__ volatile("" ::: "memory"); return v; }
+DEV int ctl_peek(const int* p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __asm__ volatile("" ::: "memory"); return v; }
 DEV void ctl_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -492,15 +494,20 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
     const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
     TIMING(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
+    // The service's progress words are read one round ahead: the loads issued here are consumed at the top of the next
+    // round, so their LDS round trip hides under this round's phase.  Stale values are conservative (srvFlushed only grows,
+    // srvValidLo only falls); LDS operations of one wave execute in order, so the ring reads of a phase cannot overtake
+    // the progress loads they depend on (the compiler is held back by the barrier in ctl_peek).
+    u32 flNext = ctl_peek(&ctl->srvFlushed);
+    int vloNext = ctl_peek(&ctl->srvValidLo);
     while (__any(can)) {
-        bool ready = false;
-        if (can) {
-            const u32 fl = ctl_load(&ctl->srvFlushed);
-            const int vlo = ctl_load(&ctl->srvValidLo);
-            // room for 16 more records, and the lowest byte this phase can read (p - 6*16 - 16) is in the ring
-            // (bit-reversed loop: 16 iterations of at most 44 bits, three window dwords below the last one -> 92 bytes below q + 8)
-            ready = (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - (FAST ? 84 : 6 * FSE_CHECK_EVERY + 8) >= vlo);
-        }
+        const u32 fl = flNext;
+        const int vlo = vloNext;
+        flNext = ctl_peek(&ctl->srvFlushed);
+        vloNext = ctl_peek(&ctl->srvValidLo);
+        // room for 16 more records, and the lowest byte this phase can read (p - 6*16 - 16) is in the ring
+        // (bit-reversed loop: 16 iterations of at most 44 bits, three window dwords below the last one -> 92 bytes below q + 8)
+        const bool ready = can && (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - (FAST ? 84 : 6 * FSE_CHECK_EVERY + 8) >= vlo);
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
             if (FAST) {
