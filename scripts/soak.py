@@ -1,0 +1,56 @@
+"""development aid: extended randomized differential run against the CPU oracle (more seeds / sizes / table logs than the
+test suite affords): python scripts/soak.py [seconds]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from finitestateentropy_amd.api import FseHip
+from oracle.oracle import Oracle
+from test_gpu_fse import _random_blocks, s64, is_error
+
+hip = FseHip()
+oracle = Oracle()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+t0 = time.time()
+seed = 0
+nblocks = 0
+while time.time() - t0 < budget:
+    seed += 1
+    rng = np.random.default_rng(77000 + seed)
+    size = int(rng.choice([int(rng.integers(2048, 5000)), int(rng.integers(5000, 70000)), 32768, 4096, 2048, 131072]))
+    tl = int(rng.choice([5, 6, 7, 8, 9, 10, 11, 11, 11, 12]))
+    blocks = _random_blocks(rng, 48, size)
+    src = torch.from_numpy(blocks).cuda()
+    dst, res = hip.fse_compress_batch(src, table_log=tl)
+    dst, res = dst.cpu().numpy(), res.cpu().numpy()
+    _, ores, odst = oracle.compress_batch(0, blocks, table_log=tl)
+    for b in range(len(blocks)):
+        r = int(ores[b])
+        assert res[b] == s64(r), ("fse size", seed, size, tl, b, res[b], r)
+        if not is_error(r) and r > 1:
+            assert (dst[b][:r] == odst[b][:r]).all(), ("fse bytes", seed, size, tl, b)
+    ok = np.array([(not is_error(int(r))) and int(r) > 1 for r in ores])
+    if ok.any():
+        d_c = torch.from_numpy(odst[ok]).cuda(); d_sz = torch.from_numpy(ores[ok].astype(np.int64)).cuda()
+        for ml in ([11, 12] if tl <= 11 else [12]):
+            out, dres = hip.fse_decompress_batch(d_c, d_sz, size, max_log=ml)
+            assert (dres.cpu().numpy() == size).all(), ("fse dsize", seed, size, tl, ml)
+            assert (out.cpu().numpy()[:, :size] == blocks[ok]).all(), ("fse dbytes", seed, size, tl, ml)
+    # Huff0 on the same blocks
+    htl = int(rng.choice([11, 11, 8, 6]))
+    hdst, hres = hip.huf_compress_batch(src, table_log=htl)
+    hdst, hres = hdst.cpu().numpy(), hres.cpu().numpy()
+    _, ohres, ohdst = oracle.compress_batch(1, blocks, table_log=htl)
+    for b in range(len(blocks)):
+        r = int(ohres[b])
+        assert hres[b] == s64(r), ("huf size", seed, size, htl, b, hres[b], r)
+        if not is_error(r) and r > 1:
+            assert (hdst[b][:r] == ohdst[b][:r]).all(), ("huf bytes", seed, size, htl, b)
+    okh = np.array([(not is_error(int(r))) and int(r) > 1 and int(r) < size for r in ohres])
+    if okh.any():
+        d_c = torch.from_numpy(ohdst[okh]).cuda(); d_sz = torch.from_numpy(ohres[okh].astype(np.int64)).cuda()
+        out, dres = hip.huf_decompress_batch(d_c, d_sz, size)
+        assert (dres.cpu().numpy() == size).all(), ("huf dsize", seed, size, htl)
+        assert (out.cpu().numpy()[:, :size] == blocks[okh]).all(), ("huf dbytes", seed, size, htl)
+    nblocks += len(blocks)
+print("soak ok: %d rounds, %d blocks, %.0f s" % (seed, nblocks, time.time() - t0))
