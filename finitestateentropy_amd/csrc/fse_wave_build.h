@@ -21,6 +21,9 @@
 #include "dev_common.h"
 
 #define WB_MAXSYM 256
+// The rank matrix covers a window of WB_WIN symbols at a time (alphabets up to 128 symbols: one pass; the LDS footprint
+// decides how many table builds a CU runs at once, and these builds are latency-bound).
+#define WB_WIN 128u
 #define WB_TSTEP(ts) (((ts) >> 1) + ((ts) >> 3) + 3)     // lib/fse.h:683
 
 #ifdef FSE_WB_TIMING         // development aid: phase cycle accounting of the last table build of each workgroup
@@ -35,20 +38,20 @@ struct WaveBuildLds {        // LDS scratch of one wave, tableSize = 1 << tl <= 
     u8*  symP;               // [256] symbols in use (counter != 0), ascending
     u8*  symTab;             // [wb_si(capTs)] symbol of every cell (output of the spread), index through wb_si()
     u16* cell;               // [wb_ci(capTs)] rank inside the lane range, index through wb_ci(); the emitter may overwrite cell[wb_ci(u)] with its result
-    u32* cnt;                // [256 * 16] byte matrix cnt[symbol][lane]
-    u16* coarse;             // [256 * 16] per symbol: cells before lane group j (4 lanes per group)
+    u32* cnt;                // [WB_WIN * 16] byte matrix cnt[symbol - window base][lane]
+    u16* coarse;             // [WB_WIN * 16] per symbol of the window: cells before lane group j (4 lanes per group)
 };
 // cell[] / symTab[] are indexed through wb_ci() / wb_si(): every row of 32 cells is followed by 4 bytes of padding.  Lane l
 // works on cells [l*C, (l+1)*C) (C = 32 at tableLog 11), so without the padding the 64 lanes of one LDS instruction
 // would sit 64 (or 32) bytes apart -- on 2 (4) of the 32 banks; with it they are 17 (9) dwords apart: conflict-free.
 __host__ __device__ inline u32 wb_ci(u32 u) { return u + ((u >> 5) << 1); }     // u16 arrays (cell, marks)
 __host__ __device__ inline u32 wb_si(u32 u) { return u + ((u >> 5) << 2); }     // u8 array (symTab)
-__host__ __device__ inline size_t wave_build_lds_bytes(u32 capTs) { return 16384 + 8192 + 2 * (size_t)wb_ci(capTs) + wb_si(capTs) + 512 + 520 + 256; }
+__host__ __device__ inline size_t wave_build_lds_bytes(u32 capTs) { return WB_WIN * 64 + WB_WIN * 32 + 2 * (size_t)wb_ci(capTs) + wb_si(capTs) + 512 + 520 + 256; }
 DEV WaveBuildLds wave_build_carve(u8* base, u32 capTs)
 {
     WaveBuildLds w;
-    w.cnt = (u32*)base; base += 16384;                   // 16-byte aligned parts first
-    w.coarse = (u16*)base; base += 8192;
+    w.cnt = (u32*)base; base += WB_WIN * 64;             // 16-byte aligned parts first
+    w.coarse = (u16*)base; base += WB_WIN * 32;
     w.cell = (u16*)base; base += 2 * (size_t)wb_ci(capTs);
     w.symTab = base; base += wb_si(capTs);
     w.nrm = (s16*)base; base += 512;
@@ -101,9 +104,6 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
     const int high = (int)ts - 1 - (int)nLow;                             // highThreshold (-1: every cell is a low-probability one)
     // clear the spread marks and the count matrix rows in use
     if (act) { if (C >= 2) for (u32 i = 0; i < C; i += 2) *(u32*)(marks + wb_ci(m0 + i)) = 0; else marks[wb_ci(m0)] = 0; }
-    {   const u32 rows16 = (maxSV + 1) * 16;                              // dwords
-        for (u32 i = 4 * lane; i < rows16; i += 256) *(uint4*)(w.cnt + i) = make_uint4(0, 0, 0, 0);
-    }
     __syncthreads();
     WBT(1)
     // symbols in use (for the per-symbol pass below); low-probability symbols take the top cells; every symbol with a
@@ -158,83 +158,107 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
     __syncthreads();
     WBT(3)
 
-    // ---- rank inside the lane range: LDS atomics return the previous count, in program order.  Eight cells at a time so
-    //      that the LDS round trips overlap (the symbols of a lane's cells are contiguous bytes).
+    // ---- per window of WB_WIN symbols: rank inside the lane range, running sums over the lane groups, emit.
+    //      (The emitter may overwrite cell[wb_ci(u)] of the cells it is called for; the other cells still hold their
+    //      local rank, which later windows read.)
     const u32 sh8 = 8 * (lane & 3u), grp = lane >> 2;
-    if (act) {
-        u32 i = 0;
-        for (; i + 8 <= C; i += 8) {
-            const u32* const syp = (const u32*)(w.symTab + wb_si(m0 + i));    // 8 cells of one row: two aligned dwords
-            const uint2 sy = make_uint2(syp[0], syp[1]);
-            u32 old[8];
+    const u32 belowMask = (1u << sh8) - 1u;
+    const bool single = maxSV < WB_WIN;                                   // uniform: one window, nothing to predicate
+    for (u32 base = 0; base <= maxSV; base += WB_WIN) {
+        {   const u32 rows = (maxSV + 1 - base) < WB_WIN ? (maxSV + 1 - base) : WB_WIN;
+            for (u32 i = 4 * lane; i < rows * 16; i += 256) *(uint4*)(w.cnt + i) = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        // rank inside the lane range: LDS atomics return the previous count, in program order.  Eight cells at a time so
+        // that the LDS round trips overlap (the symbols of a lane's cells are contiguous bytes).
+        if (act) {
+            u32 i = 0;
+            for (; i + 8 <= C; i += 8) {
+                const u32* const syp = (const u32*)(w.symTab + wb_si(m0 + i));    // 8 cells of one row: two aligned dwords
+                const uint2 sy = make_uint2(syp[0], syp[1]);
+                u32* const cp = (u32*)(w.cell + wb_ci(m0 + i));
+                uint4 prev = make_uint4(0, 0, 0, 0);
+                if (!single) prev = make_uint4(cp[0], cp[1], cp[2], cp[3]);        // local ranks written by earlier windows
+                u32 old[8]; bool in[8];
 #pragma unroll
-            for (u32 j = 0; j < 8; ++j) {
-                const u32 s = ((j < 4 ? sy.x : sy.y) >> (8 * (j & 3))) & 0xFFu;
-                old[j] = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
+                for (u32 j = 0; j < 8; ++j) {
+                    const u32 s = (((j < 4 ? sy.x : sy.y) >> (8 * (j & 3))) & 0xFFu) - base;
+                    in[j] = single || s < WB_WIN;
+                    old[j] = 0;
+                    if (in[j]) old[j] = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
+                }
+#pragma unroll
+                for (u32 j = 0; j < 8; ++j) {
+                    const u32 pw = j < 2 ? prev.x : j < 4 ? prev.y : j < 6 ? prev.z : prev.w;
+                    old[j] = in[j] ? (old[j] >> sh8) & 0xFFu : (pw >> (16 * (j & 1))) & 0xFFFFu;
+                }
+                cp[0] = old[0] | (old[1] << 16); cp[1] = old[2] | (old[3] << 16); cp[2] = old[4] | (old[5] << 16); cp[3] = old[6] | (old[7] << 16);
             }
-            uint4 pk;
-#pragma unroll
-            for (u32 j = 0; j < 8; ++j) old[j] = (old[j] >> sh8) & 0xFFu;
-            pk.x = old[0] | (old[1] << 16); pk.y = old[2] | (old[3] << 16); pk.z = old[4] | (old[5] << 16); pk.w = old[6] | (old[7] << 16);
-            u32* const cp = (u32*)(w.cell + wb_ci(m0 + i));
-            cp[0] = pk.x; cp[1] = pk.y; cp[2] = pk.z; cp[3] = pk.w;
+            for (; i < C; ++i) {
+                const u32 u = m0 + i;
+                const u32 s = (u32)w.symTab[wb_si(u)] - base;
+                if (single || s < WB_WIN) {
+                    const u32 old = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
+                    w.cell[wb_ci(u)] = (u16)((old >> sh8) & 0xFFu);
+                }
+            }
         }
-        for (; i < C; ++i) {
-            const u32 u = m0 + i;
-            const u32 s = w.symTab[wb_si(u)];
-            const u32 old = atomicAdd(&w.cnt[s * 16 + grp], 1u << sh8);
-            w.cell[wb_ci(u)] = (u16)((old >> sh8) & 0xFFu);
-        }
-    }
-    __syncthreads();
-    WBT(4)
-    // ---- per symbol in use (lane l: the l-th, l+64-th, ... of them): running sum over the 16 lane groups
-    for (u32 j = lane; j < nAny; j += 64) {
-        const u32 s = w.symP[j];
-        const uint4* const row = (const uint4*)(w.cnt + s * 16);
-        const uint4 c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
-        u32 r[16];
-        u32 acc = 0;
+        __syncthreads();
+        WBT(4)
+        // per symbol in use (lane l: the l-th, l+64-th, ... of them): running sum over the 16 lane groups
+        for (u32 j = lane; j < nAny; j += 64) {
+            const u32 s = (u32)w.symP[j] - base;
+            if (!single && s >= WB_WIN) continue;
+            const uint4* const row = (const uint4*)(w.cnt + s * 16);
+            const uint4 c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
+            u32 r[16];
+            u32 acc = 0;
 #define WB_ACC(k, v) r[k] = acc; acc += wb_bytesum(v);
-        WB_ACC(0, c0.x) WB_ACC(1, c0.y) WB_ACC(2, c0.z) WB_ACC(3, c0.w) WB_ACC(4, c1.x) WB_ACC(5, c1.y) WB_ACC(6, c1.z) WB_ACC(7, c1.w)
-        WB_ACC(8, c2.x) WB_ACC(9, c2.y) WB_ACC(10, c2.z) WB_ACC(11, c2.w) WB_ACC(12, c3.x) WB_ACC(13, c3.y) WB_ACC(14, c3.z) WB_ACC(15, c3.w)
+            WB_ACC(0, c0.x) WB_ACC(1, c0.y) WB_ACC(2, c0.z) WB_ACC(3, c0.w) WB_ACC(4, c1.x) WB_ACC(5, c1.y) WB_ACC(6, c1.z) WB_ACC(7, c1.w)
+            WB_ACC(8, c2.x) WB_ACC(9, c2.y) WB_ACC(10, c2.z) WB_ACC(11, c2.w) WB_ACC(12, c3.x) WB_ACC(13, c3.y) WB_ACC(14, c3.z) WB_ACC(15, c3.w)
 #undef WB_ACC
-        uint4* const out = (uint4*)(w.coarse + s * 16);
-        out[0] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
-        out[1] = make_uint4(r[8] | (r[9] << 16), r[10] | (r[11] << 16), r[12] | (r[13] << 16), r[14] | (r[15] << 16));
-    }
-    __syncthreads();
-    WBT(5)
-    // ---- emit: everything a cell needs is gathered for eight cells before the first one is emitted
-    if (act) {
-        const u32 belowMask = (1u << sh8) - 1u;
-        u32 i = 0;
-        for (; i + 8 <= C; i += 8) {
-            const u32* const syp = (const u32*)(w.symTab + wb_si(m0 + i));
-            const uint2 sy = make_uint2(syp[0], syp[1]);
-            const u32* const cp = (const u32*)(w.cell + wb_ci(m0 + i));
-            const uint4 lr = make_uint4(cp[0], cp[1], cp[2], cp[3]);
-            u32 s[8], co[8], cn[8], pl[8];
+            uint4* const out = (uint4*)(w.coarse + s * 16);
+            out[0] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+            out[1] = make_uint4(r[8] | (r[9] << 16), r[10] | (r[11] << 16), r[12] | (r[13] << 16), r[14] | (r[15] << 16));
+        }
+        __syncthreads();
+        WBT(5)
+        // emit: everything a cell needs is gathered for eight cells before the first one is emitted
+        if (act) {
+            u32 i = 0;
+            for (; i + 8 <= C; i += 8) {
+                const u32* const syp = (const u32*)(w.symTab + wb_si(m0 + i));
+                const uint2 sy = make_uint2(syp[0], syp[1]);
+                const u32* const cp = (const u32*)(w.cell + wb_ci(m0 + i));
+                const uint4 lr = make_uint4(cp[0], cp[1], cp[2], cp[3]);
+                u32 sf[8], co[8], cn[8], pl[8]; bool in[8];
 #pragma unroll
-            for (u32 j = 0; j < 8; ++j) {
-                s[j] = ((j < 4 ? sy.x : sy.y) >> (8 * (j & 3))) & 0xFFu;
-                co[j] = w.coarse[s[j] * 16 + grp]; cn[j] = w.cnt[s[j] * 16 + grp]; pl[j] = payload(s[j]);
+                for (u32 j = 0; j < 8; ++j) {
+                    sf[j] = ((j < 4 ? sy.x : sy.y) >> (8 * (j & 3))) & 0xFFu;
+                    const u32 sw = sf[j] - base;
+                    in[j] = single || sw < WB_WIN;
+                    const u32 row = in[j] ? sw : 0u;
+                    co[j] = w.coarse[row * 16 + grp]; cn[j] = w.cnt[row * 16 + grp]; pl[j] = payload(sf[j]);
+                }
+#pragma unroll
+                for (u32 j = 0; j < 8; ++j) {
+                    const u32 lrw = j < 2 ? lr.x : j < 4 ? lr.y : j < 6 ? lr.z : lr.w;
+                    const u32 local = (lrw >> (16 * (j & 1))) & 0xFFFFu;
+                    if (in[j]) emit(m0 + i + j, sf[j], local + co[j] + wb_bytesum(cn[j] & belowMask), pl[j]);
+                }
             }
-#pragma unroll
-            for (u32 j = 0; j < 8; ++j) {
-                const u32 lrw = j < 2 ? lr.x : j < 4 ? lr.y : j < 6 ? lr.z : lr.w;
-                const u32 local = (lrw >> (16 * (j & 1))) & 0xFFFFu;
-                emit(m0 + i + j, s[j], local + co[j] + wb_bytesum(cn[j] & belowMask), pl[j]);
+            for (; i < C; ++i) {
+                const u32 u = m0 + i;
+                const u32 sfull = w.symTab[wb_si(u)];
+                const u32 sw = sfull - base;
+                if (single || sw < WB_WIN) {
+                    const u32 r = (u32)w.cell[wb_ci(u)] + (u32)w.coarse[sw * 16 + grp] + wb_bytesum(w.cnt[sw * 16 + grp] & belowMask);
+                    emit(u, sfull, r, payload(sfull));
+                }
             }
         }
-        for (; i < C; ++i) {
-            const u32 u = m0 + i;
-            const u32 s = w.symTab[wb_si(u)];
-            const u32 r = (u32)w.cell[wb_ci(u)] + (u32)w.coarse[s * 16 + grp] + wb_bytesum(w.cnt[s * 16 + grp] & belowMask);
-            emit(u, s, r, payload(s));
-        }
+        __syncthreads();
     }
-    __syncthreads();
     WBT(6)
 #ifdef FSE_WB_TIMING
     if (lane == 0 && blockIdx.x < 4096) for (int q = 0; q < 6; ++q) g_wbTiming[8 * blockIdx.x + q] = TT[q + 1] - TT[q];
