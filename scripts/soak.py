@@ -32,7 +32,7 @@ while time.time() - t0 < budget:
     ok = np.array([(not is_error(int(r))) and int(r) > 1 for r in ores])
     if ok.any():
         d_c = torch.from_numpy(odst[ok]).cuda(); d_sz = torch.from_numpy(ores[ok].astype(np.int64)).cuda()
-        for ml in ([11, 12] if tl <= 11 else [12]):
+        for ml in sorted({tl, max(tl, 11), 12}):
             out, dres = hip.fse_decompress_batch(d_c, d_sz, size, max_log=ml)
             assert (dres.cpu().numpy() == size).all(), ("fse dsize", seed, size, tl, ml)
             assert (out.cpu().numpy()[:, :size] == blocks[ok]).all(), ("fse dbytes", seed, size, tl, ml)
