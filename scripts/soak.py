@@ -34,8 +34,13 @@ while time.time() - t0 < budget:
         d_c = torch.from_numpy(odst[ok]).cuda(); d_sz = torch.from_numpy(ores[ok].astype(np.int64)).cuda()
         for ml in sorted({tl, max(tl, 11), 12}):
             out, dres = hip.fse_decompress_batch(d_c, d_sz, size, max_log=ml)
-            assert (dres.cpu().numpy() == size).all(), ("fse dsize", seed, size, tl, ml)
-            assert (out.cpu().numpy()[:, :size] == blocks[ok]).all(), ("fse dbytes", seed, size, tl, ml)
+            # the stream's own tableLog (low 4 bits of its first byte + 5) may exceed the compressor's request
+            # (FSE_optimalTableLog raises it to what the alphabet needs): fse_decompress.c:266 -> tableLog_tooLarge (code 5)
+            stl = (odst[ok][:, 0] & 15).astype(np.int64) + 5
+            want = np.where(stl <= ml, size, -5)
+            assert (dres.cpu().numpy() == want).all(), ("fse dsize", seed, size, tl, ml)
+            good = stl <= ml
+            assert (out.cpu().numpy()[:, :size][good] == blocks[ok][good]).all(), ("fse dbytes", seed, size, tl, ml)
     # Huff0 on the same blocks
     htl = int(rng.choice([11, 11, 8, 6]))
     hdst, hres = hip.huf_compress_batch(src, table_log=htl)
