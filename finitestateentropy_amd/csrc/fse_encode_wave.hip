@@ -1,12 +1,12 @@
-// fse_encode_wave.hip -- a2: FSE_compress_usingCTable, one wave per block
+// fse_encode_wave.hip -- a2: FSE_compress_usingCTable, 32 lanes per block (two blocks per wave)
 // (reference: lib/fse_compress.c:554-623, lib/fse.h:503-527, lib/bitstream.h:183-260; format SURVEY A.1/A.3).
 //
 // tANS encoding is a loop-carried chain (two interleaved chains per block), but the encoder state is only
 // tableLog bits wide and every step replaces part of it by a function of the symbol alone, so a chain "forgets"
 // where it came from.  That makes the block splittable without changing a single output bit:
 //
-//   One 64-lane wave per block; only the CTable lives in LDS, so many blocks are resident per CU.  In emission
-//   order (last source byte first) lane t owns a contiguous range of symbols.
+//   WV_LANES (32) lanes per block, two blocks per 64-lane wave; only the packed CTable lives in LDS, so many blocks are
+//   resident per CU.  In emission order (last source byte first) lane t of a block owns a contiguous range of symbols.
 //   Pass 1: the lane warms both chains up over `warm` symbols in front of its range starting from an
 //   arbitrary state, remembers the states it arrives with (its speculated start), then runs its range counting
 //   bits and remembers the states it ends with.  Verification: lane t's speculated start must equal lane t-1's
@@ -16,11 +16,11 @@
 //   the output is bit-exact by construction.
 //   Pass 2: a wave prefix sum of the bit counts gives every lane its bit offset (and the exact compressed size /
 //   the BIT_closeCStream verdict before a single bit is written); each lane re-runs its range from its verified
-//   start and writes its bits straight to global memory: whole 32-bit words as they fill up, the last whole
-//   bytes at the end.  The byte shared by two neighbouring ranges is stored by the upper lane with the lower
+//   start and emits its bits through a small per-lane LDS ring, written out in aligned 32-byte pieces, the last
+//   whole bytes at the end.  The byte shared by two neighbouring ranges is stored by the upper lane with the lower
 //   lane's bits OR-ed in afterwards (one global atomic per lane).  CState2, CState1 and the end mark are appended
 //   by the lane that owns the final states (lib/fse_compress.c:608-610).
-//   Source bytes are streamed per lane, 16 per (unaligned) load, one load ahead.
+//   Source bytes are streamed per lane in 64-byte aligned segments (four 16-byte loads), one segment ahead.
 #include "internal.h"
 
 // Warm-up symbols (half per chain) in front of every range.  Two states fed the same symbols merge with probability

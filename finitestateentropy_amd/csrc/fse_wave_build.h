@@ -15,6 +15,7 @@
 //   2. rank(u) = number of cells u' < u with the same symbol.  Lane l owns the contiguous cells [l*C, (l+1)*C);
 //      a byte matrix cnt[symbol][lane] counts the symbols per lane range (LDS atomic add with return = the rank inside
 //      the range), a per-symbol running sum over groups of 4 lanes gives the ranks of everything before the range.
+//      The matrix holds WB_WIN symbols; larger alphabets take one rank / sum / emit pass per window of symbols.
 // The result is handed to `emit(u, symbol, rank, payload(symbol))` once per cell, lane l emitting its own range in
 // ascending u; `payload` is a per-symbol LDS lookup of the caller's that is gathered together with the core's own.
 #pragma once
