@@ -3,13 +3,14 @@
 //
 // A prefix code has no loop-carried state, so the encoder is fully parallel inside a block:
 //   one workgroup per block, one 64-lane wavefront per stream (4 waves for the 4-stream layout).
-//   pass 1: every lane sums the code lengths of a strided share of its stream  -> exact stream sizes,
-//           hence the 6-byte jump table, every stream's start offset and the return value (0 when any
-//           stream fails BIT_closeCStream's capacity rule, lib/bitstream.h:254-260) before a bit is written;
-//   pass 2: the stream is walked in emission order (last symbol first) in rows of 256 symbols; lane L owns
-//           4 consecutive symbols, packs their codes LSB-first into one <=48-bit chunk, a wave prefix sum of
-//           the chunk lengths gives its bit position and the chunk is OR-ed into an LDS image of the block's
-//           output (ds_or_b32); source bytes are read with coalesced loads.
+//   the stream is read in emission order (last symbol first) with 16-byte loads, a whole 8 KiB stream at once, and
+//   kept in registers for both passes;
+//   pass 1: every lane sums the code lengths of its symbols  -> exact stream sizes, hence the 6-byte jump table,
+//           every stream's start offset and the return value (0 when any stream fails BIT_closeCStream's capacity
+//           rule, lib/bitstream.h:254-260) before a bit is written;
+//   pass 2: rows of 1024 symbols; lane L owns 16 consecutive symbols, packs their codes LSB-first into four
+//           <=48-bit chunks, a wave prefix sum of the lane totals gives its bit position and the chunks are OR-ed
+//           into an LDS image of the block's output (ds_or_b32).
 //   The image is then copied to global memory with coalesced stores.  Outputs too large for the LDS image
 //   (only possible for blocks > 32 KB) take the same path with global atomics on a pre-zeroed destination.
 #include "internal.h"
@@ -44,26 +45,74 @@ DEV void or_bits(u32* img, u64 P, u64 bits, u32 nb)
     if (hi) atomicOr(&img[w + 2], hi);
 }
 
-template <bool GLOBAL>
-DEV void emit_stream(u32* img, u64 bitBase, const u8* seg, u32 len, const u32* ct, u32 lane)
+// A stream is walked in emission order (j = 0 is the LAST symbol of the segment, huf_compress.c:474-499 net effect) in
+// tiles of HE_TILE symbols: a tile is HE_ROWS rows of 1024 symbols, lane L of the wave owning the 16 consecutive symbols
+// j = row*1024 + 16*L .. +15 of every row = one (unaligned) 16-byte load whose bytes are taken from the top down.
+// All loads of a tile are issued before the first one is used, and a stream of up to HE_TILE symbols (the 8 KiB streams
+// of a 32 KiB block) is loaded once for both passes.
+#define HE_ROWS 4u
+#define HE_TILE (HE_ROWS * 1024u)
+struct HeTile { uint4 v[HE_ROWS]; };
+DEV uint4 he_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+DEV void he_load_tile(HeTile& t, const u8* seg, u32 len, u32 j0, u32 lane)
 {
-    // emission order: j = 0 is the LAST symbol of the segment (huf_compress.c:474-499 net effect)
-    u64 rowBase = bitBase;
-    for (u32 j0 = 0; j0 < len; j0 += 256) {
-        const u32 j = j0 + 4 * lane;
-        u64 bits = 0; u32 nb = 0;
 #pragma unroll
-        for (u32 k = 0; k < 4; ++k) {
-            if (j + k < len) {
-                const u32 e = ct[seg[len - 1 - (j + k)]];
-                bits |= (u64)(e & 0xFFFFu) << nb;
-                nb += (e >> 16) & 0xFFu;
-            }
+    for (u32 r = 0; r < HE_ROWS; ++r) {
+        const u32 j = j0 + r * 1024u + 16u * lane;          // my first symbol of this row
+        t.v[r] = make_uint4(0, 0, 0, 0);
+        if (j + 16 <= len) t.v[r] = he_load16(seg + (len - j - 16));
+        else if (j < len) {                                  // the row that reaches the start of the segment: bytewise
+            u32 w[4] = { 0, 0, 0, 0 };
+            for (u32 k = 0; k < len - j; ++k) { const u32 pos = 15u - k; w[pos >> 2] |= (u32)seg[len - 1 - (j + k)] << (8u * (pos & 3u)); }
+            t.v[r] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        const u32 incl = wave_incl_scan_u32(nb, lane);
-        or_bits<GLOBAL>(img, rowBase + (incl - nb), bits, nb);
+    }
+}
+// symbol k (0..15, emission order) of a row register: byte 15 - k
+DEV u32 he_sym(const uint4& v, u32 k) { const u32 w = k < 4 ? v.w : k < 8 ? v.z : k < 12 ? v.y : v.x; return (w >> (8u * (3u - (k & 3u)))) & 0xFFu; }
+
+// pass 1 over one tile: code bits of my symbols
+DEV u32 he_count_tile(const HeTile& t, u32 len, u32 j0, const u32* ct, u32 lane)
+{
+    u32 bits = 0;
+#pragma unroll
+    for (u32 r = 0; r < HE_ROWS; ++r) {
+        const u32 j = j0 + r * 1024u + 16u * lane;
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) if (j + k < len) bits += (ct[he_sym(t.v[r], k)] >> 16) & 0xFFu;
+    }
+    return bits;
+}
+// pass 2 over one tile: every lane packs its 16 symbols of a row into four <= 48-bit chunks; one wave prefix sum per row
+// gives the lane's bit position; the chunks are OR-ed into the image.  Returns the bit position behind the tile.
+template <bool GLOBAL>
+DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, const u32* ct, u32 lane)
+{
+#pragma unroll
+    for (u32 r = 0; r < HE_ROWS; ++r) {
+        const u32 j = j0 + r * 1024u + 16u * lane;
+        if (j0 + r * 1024u >= len) break;                    // uniform
+        u64 cb[4]; u32 cn[4]; u32 tot = 0;
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c) {
+            u64 bits = 0; u32 nb = 0;
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                if (j + 4 * c + k < len) {
+                    const u32 e = ct[he_sym(t.v[r], 4 * c + k)];
+                    bits |= (u64)(e & 0xFFFFu) << nb;
+                    nb += (e >> 16) & 0xFFu;
+                }
+            }
+            cb[c] = bits; cn[c] = nb; tot += nb;
+        }
+        const u32 incl = wave_incl_scan_u32(tot, lane);
+        u64 pos = rowBase + (incl - tot);
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c) { or_bits<GLOBAL>(img, pos, cb[c], cn[c]); pos += cn[c]; }
         rowBase += (u32)__shfl((int)incl, 63, WAVE);
     }
+    return rowBase;
 }
 
 __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u32 imgBytes)
@@ -98,10 +147,16 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     const u32 myStart = wave * segSize;
     const u32 myLen = (int)wave < streams ? (streams == 4 && wave == 3 ? n - 3 * segSize : segSize) : 0;
 
-    // ---- pass 1: code bits of my stream
-    {   u32 bits = 0;
-        const u8* seg = src + myStart;
-        for (u32 i = lane; i < myLen; i += 64) bits += (ct[seg[i]] >> 16) & 0xFFu;
+    // ---- pass 1: code bits of my stream (the first tile stays in registers for pass 2)
+    const u8* const seg = src + myStart;
+    HeTile tile0;
+    he_load_tile(tile0, seg, myLen, 0, lane);
+    {   u32 bits = he_count_tile(tile0, myLen, 0, ct, lane);
+        for (u32 j0 = HE_TILE; j0 < myLen; j0 += HE_TILE) {
+            HeTile t;
+            he_load_tile(t, seg, myLen, j0, lane);
+            bits += he_count_tile(t, myLen, j0, ct, lane);
+        }
         bits = wave_sum_u32(bits);
         if (lane == 0 && (int)wave < streams) sh[wave] = bits;
     }
@@ -137,14 +192,24 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     if ((int)wave < streams) {
         const u64 base = 8 * ((u64)lead + start[wave]);
         if (inLds) {                                     // separate call sites keep the LDS / global address spaces visible
-            emit_stream<false>(img, base, src + myStart, myLen, ct, lane);
+            u64 pos = he_emit_tile<false>(img, base, tile0, myLen, 0, ct, lane);
+            for (u32 j0 = HE_TILE; j0 < myLen; j0 += HE_TILE) {
+                HeTile t;
+                he_load_tile(t, seg, myLen, j0, lane);
+                pos = he_emit_tile<false>(img, pos, t, myLen, j0, ct, lane);
+            }
             if (lane == 0) {                             // end mark, then the jump table entry of this stream
                 or_bits<false>(img, base + sh[wave], 1, 1);
                 if (streams == 4 && wave < 3) or_bits<false>(img, 8 * ((u64)lead + 2 * wave), ssize[wave], 16);
             }
         } else {
             u32* const g = (u32*)dstAl;
-            emit_stream<true>(g, base, src + myStart, myLen, ct, lane);
+            u64 pos = he_emit_tile<true>(g, base, tile0, myLen, 0, ct, lane);
+            for (u32 j0 = HE_TILE; j0 < myLen; j0 += HE_TILE) {
+                HeTile t;
+                he_load_tile(t, seg, myLen, j0, lane);
+                pos = he_emit_tile<true>(g, pos, t, myLen, j0, ct, lane);
+            }
             if (lane == 0) {
                 or_bits<true>(g, base + sh[wave], 1, 1);
                 if (streams == 4 && wave < 3) or_bits<true>(g, 8 * ((u64)lead + 2 * wave), ssize[wave], 16);
