@@ -6,7 +6,7 @@
 // fse_decode.hip:
 //   * a workgroup = 1 decoder wave + HD_SRV_WAVES service waves over G blocks (lane 4g+k of the decoder wave walks
 //     stream k of block g); 2 workgroups per CU;
-//   * the decoder lane touches registers and LDS only: the X1 table (2-byte cells, staged as {byte, 32 - nbBits}), a
+//   * the decoder lane touches registers and LDS only: the X1 table (2-byte cells, staged bit-reversed as {nbBits, byte}), a
 //     256-byte ring of compressed input and a ring of 4-symbol output words per stream;
 //   * the service waves own all global-memory traffic of the bulk loop, coalesced: 128-byte input refills, 256-byte
 //     output rows; the two sides talk through per-stream control words in LDS (acquire/release, workgroup scope).
@@ -34,6 +34,13 @@
 #define HD_THREADS (64 * (1 + HD_SRV_WAVES))
 #define HD_SLOT_LOG 11u          // tables up to this tableLog live in LDS; larger ones are decoded by the literal path
 
+#ifdef HD_TIMING             // development aid: decoder-wave cycle accounting (phases run / polls waited)
+__device__ unsigned long long g_hdTiming[4096 * 4];
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hdTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hdTiming), sizeof(g_hdTiming)); }
+#define HDT(x) x
+#else
+#define HDT(x)
+#endif
 struct HdCtl {             // per stream, in LDS
     u32 pubIters;          // decoder -> service: bulk iterations completed (output words produced)
     u32 pubPofs;           // decoder -> service: byte offset of the topmost dword still read; bit 31 = bulk finished
@@ -59,49 +66,63 @@ DEV u32 hufx1_step(BitReader& r, const u16* cells, u32 dtLog)                // 
     return c & 0xFFu;
 }
 
-struct HdBulk { u32 q, bq; };      // q = byte offset of the lowest of the 3 window dwords, bq = unread bits of the topmost
-
-// One phase = HD_PHASE iterations of 4 symbols for one lane, registers + LDS only.  cell = byte | (32 - nbBits) << 8.
-DEV void hd_bulk_phase(HdBulk& b, const u16* T, u32 idxShift, const u8* myIn, u32* ring)
+// Bulk loop, laid out like fse_decode.hip's bit-reversed loop: a lone wave is bound by its dependent chain and by the
+// number of instructions it issues, so both are kept minimal -- per symbol one v_and_or (table address), the LDS read and
+// one v_alignbit on the chain, a shift and a byte permute beside it.
+//   * The service waves write the input ring in CONSUMPTION order (ring dword m = bit-reversed stream dword
+//     Stop/4 - 1 - m), so bits are taken from the low end of the window and the cell's nbBits (its low 5 bits) is used
+//     as shift amount as it comes.  The cursor is Q = (consumed bits) - 1, so that the window's bit 1 is the next
+//     unread bit and "2 * index" is a mask of the window: cell address = tableBase | (window & (tableMask << 1)).
+//   * Low-end-first bits are the code bit-reversed, so the table is staged bit-reversed: cell rev(i) = nbBits | byte << 8.
+//   * Window = three ring dwords {w2:w1:w0} in registers (Q's dword and the two after it); it slides by selects and the
+//     two dwords behind it are prefetched at the top of every iteration, all off the dependent chain: the first lookup
+//     of an iteration takes its index from the window register carried over from the previous one (its low 20+ bits
+//     are valid), the fresh {hi:lo} pair is formed while that lookup is in flight.
+// One iteration = 4 symbols = at most 44 bits.
+typedef const __attribute__((address_space(3))) u16* hd_lds_u16;
+typedef const __attribute__((address_space(3))) u32* hd_lds_u32;
+DEV u32 hd_cell(u32 win, u32 mask2, u32 tabOff) { return *(hd_lds_u16)(uintptr_t)((win & mask2) | tabOff); }
+DEV void hd_bulk_phase(u32& Qref, u32 tabOff, u32 mask2, u32 myIn, u32* ring)
 {
-    u32 q = b.q, bq = b.bq;
-    // window {w2:w1:w0} = stream dwords at q+8, q+4, q in registers; the two dwords below it are read at the top of every
-    // iteration (off the dependent chain) and the window slides down by 0, 1 or 2 dwords through selects
+    u32 q4 = (Qref >> 5) << 2, bq = Qref & 31u;                  // byte offset of Q's dword in the consumption-order stream, Q's bit in it
     u32 w0, w1, w2;
-    {   const u32* const wp = (const u32*)(myIn + (q & (HD_IN_RING - 4)));
+    {   const hd_lds_u32 wp = (hd_lds_u32)(uintptr_t)(myIn + (q4 & (HD_IN_RING - 4)));
         w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; }
+    u32 lo = __builtin_amdgcn_alignbit(w1, w0, bq);
 #pragma unroll 8
     for (int it = 0; it < HD_PHASE; ++it) {
-        const u32* const np = (const u32*)(myIn + ((q - 8u) & (HD_IN_RING - 4)));
-        const u32 n0 = np[0], n1 = np[1];                        // stream dwords at q-8, q-4
-        u32 thi = __builtin_amdgcn_alignbit(w2, w1, bq), tlo = __builtin_amdgcn_alignbit(w1, w0, bq);   // next 64 unread bits
-        u32 word = 0, msum = 0;
-#define HD_SYM(SEL)                                                                        \
-        {   const u32 c = T[thi >> idxShift];                                              \
-            const u32 m = c >> 8;                                                          \
-            thi = __builtin_amdgcn_alignbit(thi, tlo, m); tlo <<= (32u - m);               \
-            msum += m;                                                                     \
-            word = __builtin_amdgcn_perm(c, word, SEL); }
-        HD_SYM(0x03020104u)                                      // byte 0 <- cell byte
-        HD_SYM(0x03020400u)
-        HD_SYM(0x03040100u)
-        HD_SYM(0x04020100u)
-#undef HD_SYM
-        const int left = (int)bq - (int)(128u - msum);           // unread bits of the topmost dword after this iteration (>= -48)
-        const bool k1 = left < 0, k2 = left < -32;
-        w2 = k2 ? w0 : (k1 ? w1 : w2);
-        w1 = k2 ? n1 : (k1 ? w0 : w1);
-        w0 = k2 ? n0 : (k1 ? n1 : w0);
-        q += (u32)((left >> 5) << 2);
-        bq = (u32)left & 31u;
+        const hd_lds_u32 np = (hd_lds_u32)(uintptr_t)(myIn + ((q4 + 12u) & (HD_IN_RING - 4)));
+        const u32 n0 = np[0], n1 = np[1];                        // the two dwords behind the window
+        const u32 c1 = hd_cell(lo, mask2, tabOff);
+        u32 l = __builtin_amdgcn_alignbit(w1, w0, bq), h = __builtin_amdgcn_alignbit(w2, w1, bq);   // 64 bits from Q
+        l = __builtin_amdgcn_alignbit(h, l, c1); h >>= (c1 & 31u);
+        const u32 c2 = hd_cell(l, mask2, tabOff);
+        l = __builtin_amdgcn_alignbit(h, l, c2); h >>= (c2 & 31u);
+        const u32 c3 = hd_cell(l, mask2, tabOff);
+        l = __builtin_amdgcn_alignbit(h, l, c3); h >>= (c3 & 31u);
+        const u32 c4 = hd_cell(l, mask2, tabOff);
+        lo = __builtin_amdgcn_alignbit(h, l, c4);                // at least 20 valid bits: the next iteration's first index
+        u32 word = __builtin_amdgcn_perm(c1, 0u, 0x03020105u);   // byte 0 <- symbol of c1 (its byte 1)
+        word = __builtin_amdgcn_perm(c2, word, 0x03020500u);
+        word = __builtin_amdgcn_perm(c3, word, 0x03050100u);
+        word = __builtin_amdgcn_perm(c4, word, 0x05020100u);
+        const u32 bqn = bq + ((c1 + c2 + c3 + c4) & 0xFFu);      // low bytes = nbBits (<= 11 each): no carry into the symbols
+        const bool k1 = bqn >= 32u, k2 = bqn >= 64u;             // the window slides up by one / two dwords
+        w0 = k2 ? w2 : (k1 ? w1 : w0);
+        w1 = k2 ? n0 : (k1 ? w2 : w1);
+        w2 = k2 ? n1 : (k1 ? n0 : w2);
+        q4 += (bqn >> 5) << 2;
+        bq = bqn & 31u;
         ring[it] = word;
     }
-    b.q = q; b.bq = bq;
+    Qref = (q4 << 3) + bq;
 }
 
-DEV void hd_ring_put(u32* rg, int off, u32 w)
+// stream dword at byte offset `off` (S = stream size) -> ring, bit-reversed, at the consumption-order position
+DEV void hd_ring_put(u32* rg, int S, int off, u32 w)
 {
-    const u32 j = (u32)off & (HD_IN_RING - 1);
+    const u32 j = (u32)(((S + 3) & ~3) - 4 - off) & (HD_IN_RING - 1);
+    w = __brev(w);
     rg[j >> 2] = w;
     if (j < HD_IN_MIRROR) rg[(HD_IN_RING + j) >> 2] = w;
 }
@@ -128,11 +149,11 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
             const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
             u32* const rg = (u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX);
             const int off = vlo + 4 * lane;                  // 64 lanes x 4 bytes = the whole ring
-            if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); hd_ring_put(rg, off, w); }
+            if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); hd_ring_put(rg, Sg, off, w); }
             else if (off >= 0 && off < Sg) {
                 u32 w = 0;
                 for (int i = 0; i < 3; ++i) if (off + i < Sg) w |= (u32)ig[off + i] << (8 * i);
-                hd_ring_put(rg, off, w);
+                hd_ring_put(rg, Sg, off, w);
             }
         }
         if (live) hd_store(&ctl->srvValidLo, validLo);
@@ -188,7 +209,8 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
             const int l = 2 * p + half;
             const bool on = (rm >> l) & 1ull;
             const int nlo = __shfl(validLo, l, WAVE) - HD_IN_CHUNK;
-            if (on) hd_ring_put((u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX), nlo + 4 * l32, pend[p]);
+            const int Sg = __shfl(S32, l, WAVE);
+            if (on) hd_ring_put((u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX), Sg, nlo + 4 * l32, pend[p]);
         }
         if (wantFill) { validLo -= HD_IN_CHUNK; hd_store(&ctl->srvValidLo, validLo); }
         // (4) the output words are in registers: hand the slots back, then store them (256-byte rows)
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     u8* const aux = (u8*)ctlAll + 4 * HD_MAXG * sizeof(HdCtl);
     const int nStreams = 4 * a.G;
 
-    // ---- stage the X1 tables: reference cells {byte, nbBits} -> {byte, 32 - nbBits} (uniform control flow, all waves).
+    // ---- stage the X1 tables: reference cells {byte, nbBits} -> bit-reversed order, {nbBits, byte} (uniform control flow, all waves).
     //      Tables that do not fit the slot (tableLog 12) stay in global memory and are decoded by the literal path.
     for (int g = 0; g < a.G; ++g) {
         const size_t b = first + g;
@@ -227,10 +249,12 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         const u32 tl = (desc >> 16) & 0xFFu;
         if (tl > a.maxTableLog || tl > HD_SLOT_LOG || tl < 1 || ((desc >> 8) & 0xFFu) != 0) continue;
         const u32 words = 1u << (tl - 1);                        // two cells per word
-        u32* s = (u32*)(lds8 + (size_t)g * tabStride);
+        u16* s = (u16*)(lds8 + (size_t)g * tabStride);
         for (u32 i = tid; i < words; i += HD_THREADS) {
-            const u32 w = t[1 + i];                              // cells: byte | nbBits << 8, twice
-            s[i] = (w & 0x00FF00FFu) | ((0x20002000u - (w & 0xFF00FF00u)) & 0xFF00FF00u);
+            const u32 w = t[1 + i];                              // cells 2i, 2i+1: byte | nbBits << 8 each
+            const u32 r0 = __brev(2u * i) >> (32u - tl);         // cell 2i+1 goes to r0 | tableSize/2
+            s[r0] = (u16)(((w >> 8) & 0xFFu) | ((w & 0xFFu) << 8));
+            s[r0 | (1u << (tl - 1))] = (u16)(((w >> 24) & 0xFFu) | (((w >> 16) & 0xFFu) << 8));
         }
     }
     __syncthreads();
@@ -283,13 +307,15 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     const bool inLds = dtLog >= 1 && dtLog <= HD_SLOT_LOG;
     bool can = streamOk && inLds && r.at >= 24 + 6 * HD_PHASE + 8 && cnt / 4 >= HD_PHASE && r.size < (1ull << 31)
                && oStart + (size_t)cnt <= dstSize;      // (degenerate tiny blocks whose segments overhang go bytewise)
-    HdBulk bs; bs.q = 0; bs.bq = 0;
+    struct { u32 q, bq; } bs; bs.q = 0; bs.bq = 0;      // the reference-order view of the cursor: q = 4*(unread bits >> 5) - 8, bq = unread bits & 31
+    const u32 R8 = 8u * (((u32)r.size + 3u) & ~3u);            // consumption-order cursor Q = R8 - unread bits - 1
+    u32 Q = 0;
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;
     if (can) {
         const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the stream
-        bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
+        bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u; Q = R8 - B - 1u;
         groups = cnt >> 2;
         validLo = ((int)bs.q + 8 - 124) & ~127;                  // P - validLo in [124, 252): ring reaches up to P + 4 and down to P - 16 - 6*HD_PHASE
     }
@@ -305,10 +331,13 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     if (wave >= 1) { hd_service(nStreams, aux, ctlAll, lane, (wave - 1) * HD_SRV_S); return; }
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
-    const u16* const T = (const u16*)(lds8 + (size_t)((int)g < a.G ? g : 0) * tabStride);
-    const u8* const myIn = aux + (size_t)lane * HD_STREAM_AUX;
+    const u32 ldsBase = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds8;
+    if (ldsBase & (tabStride - 1)) __builtin_trap();             // the table address is formed with an OR (dynamic LDS starts at 0: no static LDS here)
+    const u32 tabOff = ldsBase + (u32)((int)g < a.G ? g : 0) * tabStride;
+    const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(aux + (size_t)lane * HD_STREAM_AUX);
     u32* const myOut = (u32*)(aux + (size_t)lane * HD_STREAM_AUX + HD_IN_RING + HD_IN_MIRROR);
-    const u32 idxShift = 32u - dtLog;
+    const u32 mask2 = ((1u << dtLog) - 1u) << 1;
+    HDT(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
     while (__any(can)) {
         bool ready = false;
         if (can) {
@@ -317,14 +346,17 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
             ready = (iters + HD_PHASE - fl <= HD_OUT_RING) && ((int)bs.q - 6 * HD_PHASE - 8 >= vlo);
         }
         if (ready) {
-            hd_bulk_phase(bs, T, idxShift, myIn, myOut + (iters & (HD_OUT_RING - 1)));
+            hd_bulk_phase(Q, tabOff, mask2, myIn, myOut + (iters & (HD_OUT_RING - 1)));
+            {   const u32 B = R8 - Q - 1u; bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u; }
             iters += HD_PHASE; groups -= HD_PHASE;
             can = bs.q >= 24u + 6u * HD_PHASE && groups >= HD_PHASE;
             hd_store(&ctl->pubIters, iters);
             hd_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
         }
+        HDT({ const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB; })
         if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
     }
+    HDT(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* t = g_hdTiming + 4 * blockIdx.x; t[0] = tRun; t[1] = tWait; t[2] = nRun; t[3] = nWait; })
     int endBad = 0;                                  // my stream did not end exactly
     if (streamOk) {
         long p = 4 * (long)iters;
