@@ -56,9 +56,19 @@ __global__ __launch_bounds__(64) void k_hist(HistArgs a)
         const uint4* v = (const uint4*)(q + head);
         const size_t nvec = (len - head) >> 4;
         size_t i = lane;
-        for (; i + 192 < nvec; i += 256) {                  // 4 x 1 KiB coalesced loads in flight per wave
-            const uint4 x0 = v[i], x1 = v[i + 64], x2 = v[i + 128], x3 = v[i + 192];
-            hist_add16(cnt, col, x0); hist_add16(cnt, col, x1); hist_add16(cnt, col, x2); hist_add16(cnt, col, x3);
+        if (i + 192 < nvec) {                               // 4 x 1 KiB coalesced loads per group, one group ahead of its use
+            uint4 x0 = v[i], x1 = v[i + 64], x2 = v[i + 128], x3 = v[i + 192];
+            for (;;) {
+                const size_t j = i + 256;
+                const bool more = j + 192 < nvec;           // (per lane; lanes that stop early finish in the loop below)
+                uint4 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
+                if (more) { y0 = v[j]; y1 = v[j + 64]; y2 = v[j + 128]; y3 = v[j + 192]; }
+                __asm__ volatile("" ::: "memory");          // keep the next group's loads above this group's LDS updates
+                hist_add16(cnt, col, x0); hist_add16(cnt, col, x1); hist_add16(cnt, col, x2); hist_add16(cnt, col, x3);
+                i = j;
+                if (!more) break;
+                x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            }
         }
         for (; i < nvec; i += 64) { const uint4 x = v[i]; hist_add16(cnt, col, x); }
         const size_t done = head + (nvec << 4);
