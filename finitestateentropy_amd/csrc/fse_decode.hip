@@ -377,18 +377,26 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     if (tid < 2) flagsSh[tid] = 0;
     __syncthreads();
     {   u32 badBits = 0; bool anyNb0 = false;
-        for (int g = 0; g < a.G; ++g) {
+        if (a.atab) {
+            // k_fse_dbuild output: already in the LDS format, one slot of tabStride bytes per block both in global memory and
+            // in LDS, so the tables of this workgroup are one contiguous copy.  Every load is issued before the first store
+            // (a lone copy loop would pay the memory latency once per table).
+            const size_t nTab = a.nBlocks - first < (size_t)a.G ? a.nBlocks - first : (size_t)a.G;
+            const uint4* const srcv = (const uint4*)(a.atab + (first << a.maxTableLog));
+            uint4* const dstv = (uint4*)lds8;
+            const u32 nvec = (u32)nTab * (tabStride / 16u);
+            constexpr u32 MAXV = (80u * 1024u / 16u + FSE_DEC_THREADS - 1) / FSE_DEC_THREADS;
+            uint4 buf[MAXV];
+#pragma unroll
+            for (u32 k = 0; k < MAXV; ++k) { const u32 idx = tid + k * FSE_DEC_THREADS; if (idx < nvec) buf[k] = srcv[idx]; }
+#pragma unroll
+            for (u32 k = 0; k < MAXV; ++k) { const u32 idx = tid + k * FSE_DEC_THREADS; if (idx < nvec) dstv[idx] = buf[k]; }
+            for (size_t g = 0; g < nTab; ++g) { const u32 st = a.meta[first + g].state; anyNb0 |= st != 0 && !(st & 2u); }   // a cell with nbBits == 0 needs a counter > tableSize/2
+        }
+        else for (int g = 0; g < a.G; ++g) {
             const size_t b = first + g;
             if (b >= a.nBlocks) break;
             if (a.meta && a.meta[b].state == 0) continue;
-            if (a.atab) {                                        // k_fse_dbuild output: already in the LDS format
-                const u32 ts = 1u << a.meta[b].tableLog;
-                const u32* const t32 = (const u32*)(a.atab + (b << a.maxTableLog));
-                u32* const A32 = (u32*)(lds8 + (size_t)g * tabStride);
-                for (u32 i = tid; i < ts / 2; i += FSE_DEC_THREADS) A32[i] = t32[i];
-                anyNb0 |= !(a.meta[b].state & 2u);               // a cell with nbBits == 0 needs a counter > tableSize/2
-                continue;
-            }
             if (FAST) __builtin_trap();                          // the bit-reversed loop takes k_fse_dbuild tables only (launch_fse_decode)
             const u32* t = a.dtables + b * a.dtStrideU32;
             const u32 tl = t[0] & 0xFFFFu;
