@@ -63,8 +63,10 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
     const FseMeta m = a.meta[b];
     if (m.state == 0) return;                                              // uniform
     const WaveBuildLds w = wave_build_carve(wbLds, capTs);
-    u32* const img = (u32*)(wbLds + ((wave_build_lds_bytes(capTs) + 15) & ~(size_t)15));     // CTable image: 1 + capTs/2 + 512 words
-    u16* const cumAll = (u16*)(img + 1 + capTs / 2 + 512);                                  // [256] first stateTable slot of every symbol
+    // The CTable is written straight to global memory: symbolTT entries coalesced, stateTable entries as scattered 2-byte
+    // stores inside the block's 4 KiB (the L2 merges them) -- an LDS image would cost 6 KiB per build, i.e. occupancy.
+    u32* const img = a.ctables + b * a.ctStrideU32;
+    u16* const cumAll = w.cumP;                                            // [256] first stateTable slot of every symbol (the core leaves cumP to its caller)
     *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
     __syncthreads();
     const u32 tl = m.tableLog, ts = 1u << tl, maxSV = m.maxSV;
@@ -96,9 +98,6 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
     __syncthreads();
     wave_spread_rank(w, maxSV, tl, lane, [&](u32 s) { return (u32)cumAll[s]; },
                      [&](u32 u, u32 s, u32 r, u32 first) { (void)s; stateTable[first + r] = (u16)(ts + u); });   // :125-133
-    u32* const out = a.ctables + b * a.ctStrideU32;
-    const u32 words = 1 + (ts >> 1) + 2 * (maxSV + 1);
-    for (u32 i = lane; i < words; i += 64) out[i] = img[i];
 }
 
 // Decompress side, two kernels:
@@ -174,7 +173,7 @@ hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     const u32 capTs = 1u << a.maxTl;
-    const size_t ldsBytes = ((wave_build_lds_bytes(capTs) + 15) & ~(size_t)15) + 4 * (1 + (size_t)capTs / 2 + 512) + 512;
+    const size_t ldsBytes = wave_build_lds_bytes(capTs);
     probe_before(PK_FSE_CPREP, s);
     hipLaunchKernelGGL(k_fse_cnorm, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_fse_cbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
