@@ -338,10 +338,11 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
     for (;;) {                                                   // remaining iterations of fse_decompress.c:201-218
         const int st = r.reload();
         if (!((st == BR_UNFINISHED) & (op < omax - 3))) break;
-        out[op + 0] = (u8)fse_tail_step(t, s1, r, fast);
-        out[op + 1] = (u8)fse_tail_step(t, s2, r, fast);
-        out[op + 2] = (u8)fse_tail_step(t, s1, r, fast);
-        out[op + 3] = (u8)fse_tail_step(t, s2, r, fast);
+        u32 w = fse_tail_step(t, s1, r, fast);                     // four symbols, one store
+        w |= fse_tail_step(t, s2, r, fast) << 8;
+        w |= fse_tail_step(t, s1, r, fast) << 16;
+        w |= fse_tail_step(t, s2, r, fast) << 24;
+        __builtin_memcpy(out + op, &w, 4);
         op += 4;
     }
     for (;;) {                                                   // :222-235
@@ -474,25 +475,30 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     BulkState bs; bs.q = 0; bs.bq = 0;
     {   const u32 st = half ? s2 : s1;                                           // my state as a cell address
         bs.s = tabOff + 2u * (FAST ? __brev(st) >> (32u - (tl ? tl : 1u)) : st); }
-    const u32 R8 = 8u * (((u32)S + 3u) & ~3u);                                   // bit-reversed loop: cursor P = R8 - unread bits
+    // Ring coordinates count bytes from the 4-byte aligned address at or below the payload (inA bytes lower), so that the
+    // service's refills are aligned dwords and its 64-byte chunks whole 64-byte sectors of memory: every byte of the stream
+    // is fetched exactly once.  "Unread bits" B below therefore includes those 8*inA bits.
+    const u32 inA = (u32)((uintptr_t)in & 3u);
+    const u32 R8 = 8u * (((u32)S + inA + 3u) & ~3u);                             // bit-reversed loop: cursor P = R8 - unread bits
     u32 P = 0;
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + FSE_IN_RING)
     if (can) {
-        const u32 B = 8u * ((u32)r.at + 8u) - r.used;            // unread bits = bits [0, B) of the payload
+        const u32 B = 8u * ((u32)r.at + 8u + inA) - r.used;      // unread bits = bits [0, B) counted from the aligned base
         bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u; P = R8 - B;
         groups = (omax - 3 - op + 3) >> 2;
         // P = q + 8 = byte offset of dword dp.  The ring must reach up to P + 4 and down to the lowest byte a phase can
-        // read, P - 8 - 6*16 = P - 104
-        validLo = ((int)bs.q + 8 - 112) & ~(FSE_IN_CHUNK - 1);          // the ring then reaches from below q - 104 up to above q + 12
+        // read, P - 8 - 6*16 = P - 104.  Chunk boundaries sit on 64-byte aligned addresses (offset c0 in ring coordinates).
+        const int c0 = (int)((0 - ((uintptr_t)in - inA)) & (FSE_IN_CHUNK - 1));
+        validLo = (((int)bs.q + 8 - 112 - c0) & ~(FSE_IN_CHUNK - 1)) + c0;   // the ring then reaches from below q - 104 up to above q + 12
     }
     DecCtl* const ctl = ctlAll + (gsl < FSE_MAXG ? gsl : 0);
     if (wave == 0 && gsl < FSE_MAXG && half == 0) {
         ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
-        ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S : 0);
-        const unsigned long long ib = (unsigned long long)(uintptr_t)in, ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)syms;
+        ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S + inA : 0);
+        const unsigned long long ib = (unsigned long long)(uintptr_t)(in - inA), ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)syms;
         ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
     }
     __syncthreads();
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             else          fse_bulk_phase<false>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
             iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
             // the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
-            can = bs.q >= 24u + 6u * FSE_CHECK_EVERY && groups >= FSE_CHECK_EVERY;
+            can = bs.q >= 24u + 6u * FSE_CHECK_EVERY + 4u && groups >= FSE_CHECK_EVERY;     // (+4: q counts from the aligned base)
             if (half == 0) {
                 ctl_store(&ctl->pubIters, iters);
                 ctl_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     if (!owner || half) return;
     op = 4 * (long)iters;
     if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container) after a reload
-        const u32 B = 8u * (bs.q + 8u) + bs.bq;
+        const u32 B = 8u * (bs.q + 8u) + bs.bq - 8u * inA;      // back to bits of the payload proper
         r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s - tabOff) >> 1; s2 = (sOther - tabOff) >> 1;
         if (FAST) { s1 = __brev(s1) >> (32u - tl); s2 = __brev(s2) >> (32u - tl); }
     }
