@@ -8,7 +8,7 @@
 //     stream k of block g); 2 workgroups per CU;
 //   * the decoder lane touches registers and LDS only: the X1 table (2-byte cells, staged bit-reversed as {nbBits, byte}), a
 //     256-byte ring of compressed input and a ring of 4-symbol output words per stream;
-//   * the service waves own all global-memory traffic of the bulk loop, coalesced: 128-byte input refills, 256-byte
+//   * the service waves own all global-memory traffic of the bulk loop, coalesced: 128-byte input refills, 64..128-byte
 //     output rows; the two sides talk through per-stream control words in LDS (acquire/release, workgroup scope).
 //
 // Per stream the kernel reproduces the reference's reader state (64-bit window at byte offset `at`, consumed bits
@@ -24,10 +24,10 @@
 #include "bitreader.h"
 
 #define HD_PHASE 8               // bulk iterations per phase (4 symbols, <= 6 bytes each)
-#define HD_OUT_RING 64           // per-stream ring of output words (4 symbols each)
+#define HD_OUT_RING 32           // per-stream ring of output words (4 symbols each); flushed from 16 words on
 #define HD_IN_RING 256           // per-stream ring of compressed input, direct-mapped by offset mod 256
 #define HD_IN_CHUNK 128          // refill granule: 32 lanes x 4 bytes
-#define HD_IN_MIRROR 16          // the first bytes are mirrored behind the ring so reads of 3 dwords never wrap
+#define HD_IN_MIRROR 8           // the first bytes are mirrored behind the ring so reads of 3 dwords never wrap
 #define HD_MAXG 16               // blocks per workgroup (64 streams = the lanes of the decoder wave)
 #define HD_SRV_WAVES 4
 #define HD_SRV_S (4 * HD_MAXG / HD_SRV_WAVES)       // streams per service wave
@@ -49,8 +49,7 @@ struct HdCtl {             // per stream, in LDS
     int initValidLo;       // set-up constants for the service wave
     int S32;
     u32 inLo, inHi, outLo, outHi;
-    u32 pad[6];
-};
+};                         // 40 bytes: with 392 bytes of rings per stream 14 blocks (56 streams) fit a workgroup's 80 KiB
 #define HD_STREAM_AUX (HD_IN_RING + HD_IN_MIRROR + HD_OUT_RING * 4)     // rings of one stream, bytes
 
 DEV u32 hd_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -160,11 +159,9 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
     }
 
     u32 pend[HD_SRV_S / 2];
-    u32 outw[HD_SRV_S];
+    u32 outw[HD_SRV_S / 2];
 #pragma unroll
-    for (int l = 0; l < HD_SRV_S / 2; ++l) pend[l] = 0;
-#pragma unroll
-    for (int l = 0; l < HD_SRV_S; ++l) outw[l] = 0;
+    for (int l = 0; l < HD_SRV_S / 2; ++l) { pend[l] = 0; outw[l] = 0; }
     for (;;) {
         u32 pp = 0x80000000u, it = flushed;
         if (live) { pp = hd_load(&ctl->pubPofs); it = hd_load(&ctl->pubIters); }   // finished flag before the count it guards
@@ -194,13 +191,16 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
             if (on && off >= 0 && off + 4 <= Sg) __builtin_memcpy(&w, ig + off, 4);
             pend[p] = w;
         }
-        // (2) read the output words of every stream with enough of them
+        // (2) read the output words of every stream with enough of them: at most 32 words each, so streams 2p and 2p+1 of
+        //     this wave share one instruction (32 lanes each)
 #pragma unroll
-        for (int l = 0; l < HD_SRV_S; ++l) {
-            if (!((fm >> l) & 1ull)) continue;               // uniform
+        for (int p = 0; p < HD_SRV_S / 2; ++p) {
+            if (!((fm >> (2 * p)) & 3ull)) continue;         // uniform
+            const int l = 2 * p + half;
+            const bool on = (fm >> l) & 1ull;
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl = (u32)__shfl((int)flushed, l, WAVE);
             const u32* const og = (const u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX + HD_IN_RING + HD_IN_MIRROR);
-            if ((u32)lane < cnt) outw[l] = og[(fl + lane) & (HD_OUT_RING - 1)];
+            if (on && (u32)l32 < cnt) outw[p] = og[(fl + l32) & (HD_OUT_RING - 1)];
         }
         // (3) install the input chunks and publish them
 #pragma unroll
@@ -213,20 +213,22 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
             if (on) hd_ring_put((u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX), Sg, nlo + 4 * l32, pend[p]);
         }
         if (wantFill) { validLo -= HD_IN_CHUNK; hd_store(&ctl->srvValidLo, validLo); }
-        // (4) the output words are in registers: hand the slots back, then store them (256-byte rows)
+        // (4) the output words are in registers: hand the slots back, then store them (rows of 16..32 words)
         if (wantFlush) hd_store(&ctl->srvFlushed, it);
 #pragma unroll
-        for (int l = 0; l < HD_SRV_S; ++l) {
-            if (!((fm >> l) & 1ull)) continue;               // uniform
+        for (int p = 0; p < HD_SRV_S / 2; ++p) {
+            if (!((fm >> (2 * p)) & 3ull)) continue;         // uniform
+            const int l = 2 * p + half;
+            const bool on = (fm >> l) & 1ull;
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl = (u32)__shfl((int)flushed, l, WAVE);
             u8* const og = (u8*)(uintptr_t)__shfl(outBits, l, WAVE) + 4ull * fl;
-            if ((u32)lane < cnt) __builtin_memcpy(og + 4u * lane, &outw[l], 4);
+            if (on && (u32)l32 < cnt) __builtin_memcpy(og + 4u * l32, &outw[p], 4);
         }
         if (wantFlush) flushed = it;
     }
 }
 
-// LDS: G tables (2-byte cells, 1 << HD_SLOT_LOG of them) | HdCtl[4 * HD_MAXG] | per stream: input ring (256 + 16 B), output ring (64 x 4 B)
+// LDS: G tables (2-byte cells, 1 << HD_SLOT_LOG of them) | HdCtl[4 * HD_MAXG] | per stream: input ring (256 + 8 B), output ring (32 x 4 B)
 __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     u8* const lds8 = (u8*)lds;
     const u32 tabStride = 2u << HD_SLOT_LOG;
     HdCtl* const ctlAll = (HdCtl*)(lds8 + (size_t)a.G * tabStride);
-    u8* const aux = (u8*)ctlAll + 4 * HD_MAXG * sizeof(HdCtl);
+    u8* const aux = (u8*)ctlAll + (((size_t)4 * a.G * sizeof(HdCtl) + 15) & ~(size_t)15);
     const int nStreams = 4 * a.G;
 
     // ---- stage the X1 tables: reference cells {byte, nbBits} -> bit-reversed order, {nbBits, byte} (uniform control flow, all waves).
@@ -319,8 +321,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         groups = cnt >> 2;
         validLo = ((int)bs.q + 8 - 124) & ~127;                  // P - validLo in [124, 252): ring reaches up to P + 4 and down to P - 16 - 6*HD_PHASE
     }
-    HdCtl* const ctl = ctlAll + lane;
-    if (wave == 0) {
+    HdCtl* const ctl = ctlAll + (lane < nStreams ? lane : 0);        // (the array holds 4 * G entries)
+    if (wave == 0 && lane < nStreams) {
         ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(r.size < (1ull << 31) ? r.size : 0);
@@ -396,8 +398,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
 
 static int huf_decode_G(size_t ldsBytes)
 {
-    const size_t perBlock = (2u << HD_SLOT_LOG) + 4 * HD_STREAM_AUX;
-    int g = (int)((ldsBytes - 4 * HD_MAXG * sizeof(HdCtl)) / perBlock);
+    const size_t perBlock = (2u << HD_SLOT_LOG) + 4 * (HD_STREAM_AUX + sizeof(HdCtl));
+    int g = (int)((ldsBytes - 16) / perBlock);
     return g > HD_MAXG ? HD_MAXG : g;
 }
 
