@@ -151,11 +151,15 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     const u8* const seg = src + myStart;
     HeTile tile0;
     he_load_tile(tile0, seg, myLen, 0, lane);
-    {   u32 bits = he_count_tile(tile0, myLen, 0, ct, lane);
-        for (u32 j0 = HE_TILE; j0 < myLen; j0 += HE_TILE) {
-            HeTile t;
-            he_load_tile(t, seg, myLen, j0, lane);
-            bits += he_count_tile(t, myLen, j0, ct, lane);
+    {   // every tile is loaded while the one before it is being processed
+        u32 bits = 0;
+        HeTile cur = tile0;
+        for (u32 j0 = 0; j0 < myLen; j0 += HE_TILE) {
+            HeTile nxt = cur;
+            if (j0 + HE_TILE < myLen) he_load_tile(nxt, seg, myLen, j0 + HE_TILE, lane);
+            __asm__ volatile("" ::: "memory");               // keep the loads above the LDS lookups of the current tile
+            bits += he_count_tile(cur, myLen, j0, ct, lane);
+            cur = nxt;
         }
         bits = wave_sum_u32(bits);
         if (lane == 0 && (int)wave < streams) sh[wave] = bits;
@@ -192,11 +196,14 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     if ((int)wave < streams) {
         const u64 base = 8 * ((u64)lead + start[wave]);
         if (inLds) {                                     // separate call sites keep the LDS / global address spaces visible
-            u64 pos = he_emit_tile<false>(img, base, tile0, myLen, 0, ct, lane);
-            for (u32 j0 = HE_TILE; j0 < myLen; j0 += HE_TILE) {
-                HeTile t;
-                he_load_tile(t, seg, myLen, j0, lane);
-                pos = he_emit_tile<false>(img, pos, t, myLen, j0, ct, lane);
+            u64 pos = base;
+            HeTile cur = tile0;
+            for (u32 j0 = 0; j0 < myLen; j0 += HE_TILE) {
+                HeTile nxt = cur;
+                if (j0 + HE_TILE < myLen) he_load_tile(nxt, seg, myLen, j0 + HE_TILE, lane);
+                __asm__ volatile("" ::: "memory");
+                pos = he_emit_tile<false>(img, pos, cur, myLen, j0, ct, lane);
+                cur = nxt;
             }
             if (lane == 0) {                             // end mark, then the jump table entry of this stream
                 or_bits<false>(img, base + sh[wave], 1, 1);
@@ -204,11 +211,14 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
             }
         } else {
             u32* const g = (u32*)dstAl;
-            u64 pos = he_emit_tile<true>(g, base, tile0, myLen, 0, ct, lane);
-            for (u32 j0 = HE_TILE; j0 < myLen; j0 += HE_TILE) {
-                HeTile t;
-                he_load_tile(t, seg, myLen, j0, lane);
-                pos = he_emit_tile<true>(g, pos, t, myLen, j0, ct, lane);
+            u64 pos = base;
+            HeTile cur = tile0;
+            for (u32 j0 = 0; j0 < myLen; j0 += HE_TILE) {
+                HeTile nxt = cur;
+                if (j0 + HE_TILE < myLen) he_load_tile(nxt, seg, myLen, j0 + HE_TILE, lane);
+                __asm__ volatile("" ::: "memory");
+                pos = he_emit_tile<true>(g, pos, cur, myLen, j0, ct, lane);
+                cur = nxt;
             }
             if (lane == 0) {
                 or_bits<true>(g, base + sh[wave], 1, 1);
