@@ -14,6 +14,7 @@
 #define HUF_DEF_TL FSEHIP_HUF_TABLELOG_DEFAULT
 #define HUF_MAX_SV 255
 
+#define HUF_BIG_ALPHABET 96u     // alphabets from this size on are sorted by the LDS network of k_huf_presort
 struct hnode_t { u32 count; u16 parent; u8 byte; u8 nbBits; };        // lib/huf_compress.c:201-206
 
 // Node array of one lane inside the workgroup's scratch: element i of lane l sits at (i * 64 + l), so that the 64 lanes
@@ -132,19 +133,49 @@ __device__ void huf_sort_nodes_merge(NodeArr node0, const unsigned* count, u32 m
     for (u32 i = n + 1; i < 512; i++) node0[i] = z;
 }
 
+// The same order once more, for large alphabets by a kernel of its own (k_huf_presort): every lane sorts its
+// own column keys[i * 64 + lane] of 256 keys with a bitonic network.  key = count << 9 | 1 << 8 | (255 - symbol) is unique,
+// so "descending key" = count descending, ties in symbol order; the unused tail of the column holds zeros.  The network
+// has no data-dependent control flow and its compare-exchanges within a stage are independent, so the LDS round trips
+// overlap (the merge sort above is a chain of dependent global-memory accesses: 1.5 ms of the 4 ms this kernel took on
+// 256-symbol alphabets).
+__device__ void huf_sort_nodes_lds(NodeArr node0, const unsigned* count, u32 maxSV, u32* keys)
+{
+    const u32 n = maxSV + 1;
+    for (u32 i = 0; i < 256; i++) keys[i * 64] = i < n ? (count[i] << 9) | (1u << 8) | (255u - i) : 0u;
+    for (u32 k = 2; k <= 256; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll 8
+            for (u32 t = 0; t < 128; t++) {
+                const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // the t-th index with bit j clear
+                const u32 l = i | j;
+                const u32 a = keys[i * 64], b = keys[l * 64];
+                const bool up = (i & k) != 0;                            // descending overall: ascending runs where bit k is set
+                const bool swap = up ? a > b : a < b;
+                keys[i * 64] = swap ? b : a;
+                keys[l * 64] = swap ? a : b;
+            }
+        }
+    }
+    hnode_t z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0;
+    node0[0] = z;
+    for (u32 i = 0; i < n; i++) { const u32 key = keys[i * 64]; hnode_t h; h.count = key >> 9; h.parent = 0; h.byte = (u8)(255u - (key & 0xFFu)); h.nbBits = 0; node0[1 + i] = h; }
+    for (u32 i = n + 1; i < 512; i++) node0[i] = z;
+}
+
 // HUF_buildCTable_wksp (lib/huf_compress.c:338-410).  celt[s] = val | nbBits << 16 (struct HUF_CElt_s, :106-109).
 // node0: scratch of 2*256 entries (global memory, interleaved across the lanes of the wave).
-__device__ size_t huf_build_ctable(u32* celt, const unsigned* count, u32 maxSV, u32 maxNbBits, NodeArr node0)
+__device__ size_t huf_build_ctable(u32* celt, const unsigned* count, u32 maxSV, u32 maxNbBits, NodeArr node0, bool presorted)
 {
     const int START = HUF_MAX_SV + 1;
     const NodeArr node = node0 + 1;
     int last, lowS, lowN, nodeNb = START, root, n;
     if (maxNbBits == 0) maxNbBits = HUF_DEF_TL;
     if (maxSV > HUF_MAX_SV) return FERR(maxSymbolValue_tooLarge);
-    if (maxSV < 96) {                                      // small alphabets: the reference's bucket + insertion sort is cheapest
+    if (maxSV < HUF_BIG_ALPHABET) {                        // small alphabets: the reference's bucket + insertion sort is cheapest
         hnode_t z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; for (u32 i = 0; i < 512; i++) node0[i] = z;
         huf_sort_nodes(node, count, maxSV);
-    } else huf_sort_nodes_merge(node0, count, maxSV);
+    } else if (!presorted) huf_sort_nodes_merge(node0, count, maxSV);      // (k_huf_presort has left the sorted nodes in node0)
     last = (int)maxSV;
     while (node[last].count == 0) last--;
     lowS = last; root = nodeNb + lowS - 1; lowN = nodeNb;
@@ -368,6 +399,20 @@ __device__ size_t huf_read_dtable_x1(u32* dtable, u32 maxTableLogField, const u8
 // ---------------------------------------------------------------------------------------------------
 //  prepare kernels (one lane per block)
 // ---------------------------------------------------------------------------------------------------
+// Large alphabets are sorted by a kernel of their own: it needs 64 KiB of LDS per wave for the lanes' sort columns, which
+// would cost the rest of the (latency-bound, lane-per-block) prepare work two thirds of its occupancy.  It leaves the
+// sorted nodes in the node scratch of the same (workgroup, lane) that k_huf_cprep then uses.
+__global__ __launch_bounds__(64) void k_huf_presort(HufCPrepArgs a, hnode_t* nodeScratch)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 sortLds[];
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.nBlocks) return;
+    if (is_err(a.histResults[b])) return;
+    const u32 maxSV = a.maxSVs[b];
+    if (maxSV < HUF_BIG_ALPHABET || maxSV > HUF_MAX_SV) return;
+    huf_sort_nodes_lds(NodeArr{nodeScratch + (size_t)blockIdx.x * 64 * 512 + threadIdx.x}, a.counts + b * 256, maxSV, sortLds + threadIdx.x);
+}
+
 __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a, hnode_t* nodeScratch)
 {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -387,7 +432,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a, hnode_t* nodeS
         const u32 maxSV = a.maxSVs[b];
         u32 huffLog = fse_optimal_tablelog(a.huffLogReq ? a.huffLogReq : HUF_DEF_TL, n, maxSV, 1);   // :691, :48-51
         u32* const celt = a.ctables + b * a.ctStrideU32;
-        {   const size_t mb = huf_build_ctable(celt, a.counts + b * 256, maxSV, huffLog, NodeArr{nodeScratch + (size_t)blockIdx.x * 64 * 512 + threadIdx.x});
+        {   const size_t mb = huf_build_ctable(celt, a.counts + b * 256, maxSV, huffLog, NodeArr{nodeScratch + (size_t)blockIdx.x * 64 * 512 + threadIdx.x}, true);
             if (is_err(mb)) { result = mb; break; }
             huffLog = (u32)mb;
         }
@@ -430,6 +475,13 @@ hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* nodeScra
 {
     if (a.nBlocks == 0) return hipSuccess;
     probe_before(PK_HUF_CPREP, s);
+    static bool attrSet = false;
+    if (!attrSet) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_huf_presort, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    hipLaunchKernelGGL(k_huf_presort, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 64 * 1024, s, a, (hnode_t*)nodeScratch);
     hipLaunchKernelGGL(k_huf_cprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a, (hnode_t*)nodeScratch);
     probe_after(PK_HUF_CPREP, s);
     return hipGetLastError();
