@@ -107,10 +107,18 @@ struct WvSink {
 // Run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even).  Returns the
 // number of bits they emit; with EMIT the bits also go to the sink.  The source is streamed downwards: 64 bytes (four
 // 16-byte loads of one 64-byte segment, so the segment is fetched from memory once) one segment ahead of its use.
-template <bool EMIT, bool TT4>
-DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink* k)
+// Checkpoints (counting passes only): after every ck->every 64-symbol groups of the range the pass records its state pair
+// and bit count (WV_CK_RECORD), or -- when a range is re-run from a corrected start state (WV_CK_MERGE) -- compares
+// them with what the previous run recorded there: once the states agree the rest of the range repeats the previous
+// run (same states, same symbols), so the new total is known and the pass stops.
+enum { WV_CK_NONE = 0, WV_CK_RECORD = 1, WV_CK_MERGE = 2 };
+#define WV_CK_MAX 8u
+struct WvCk { uint2* slot; u32 every; u32 oldBits; bool merged; };
+template <bool EMIT, bool TT4, int CK = WV_CK_NONE>
+DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink* k, WvCk* ck = nullptr)
 {
     u32 bits = 0, j = ja;
+    u32 ckLeft = CK != WV_CK_NONE ? ck->every : 0u, ckIdx = 0;
     u32 na, nbb, ba, bb;
 #define WV_PAIR(w, hiA, hiB)                                                                         \
     {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u);     \
@@ -130,6 +138,22 @@ DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, 
             __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one segment ahead of its use
             WV_QUAD(c3) WV_QUAD(c2) WV_QUAD(c1) WV_QUAD(c0)
             c0 = n0; c1 = n1; c2 = n2; c3 = n3; j = nj;
+            if (CK != WV_CK_NONE && --ckLeft == 0) {
+                ckLeft = ck->every;
+                const u32 st = xa | (xb << 16);
+                if (CK == WV_CK_MERGE) {
+                    const uint2 o = ck->slot[ckIdx];
+                    if (o.x == st) {
+                        // keep the later records consistent with the new run: their bit counts shift by what the prefix changed by
+                        const u32 nck = ((jb - ja) / 64u) / ck->every, d = bits - o.y;
+                        for (u32 i = ckIdx; i < nck && i < WV_CK_MAX; ++i) ck->slot[i].y += d;
+                        ck->merged = true;
+                        return bits + (ck->oldBits - o.y);
+                    }
+                }
+                if (ckIdx < WV_CK_MAX) ck->slot[ckIdx] = make_uint2(st, bits);
+                ++ckIdx;
+            }
         }
     }
     while (j + 16 <= jb) {
@@ -282,7 +306,9 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     const bool mine = on && j0 < n;                                         // non-empty range
     const u32 lastLane = m ? ((m + delta - 1) / C < WV_LANES - 1u ? (m + delta - 1) / C : WV_LANES - 1u) : 0u;   // owner of the final states
 
-    // ---- pass 1: speculated start, bit count, end states
+    // ---- pass 1: speculated start, bit count, end states.  The output rings are idle until pass 2: they hold the checkpoints
+    WvCk ck; ck.slot = (uint2*)(ringBase + hl * (WV_RING / 4)); ck.oldBits = 0; ck.merged = false;
+    ck.every = (C / 64u + WV_CK_MAX - 1u) / WV_CK_MAX; ck.every = ck.every ? ck.every : 1u;      // at most WV_CK_MAX checkpoints per range
     u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
     if (mine) {
         if (j0 <= 2 + warm) {                                        // the warm-up would reach the block end: be exact
@@ -294,7 +320,7 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
             wv_count<TT4>(ttb, src, n, j0 - warm, j0, xa, xb);
         }
         start = xa | (xb << 16);
-        bits = wv_count<TT4>(ttb, src, n, j0, j1, xa, xb);
+        bits = wv_run<false, TT4, WV_CK_RECORD>(ttb, src, n, j0, j1, xa, xb, nullptr, &ck);
         end = xa | (xb << 16);
     }
     ETIMING(T2 = __builtin_readcyclecounter();)
@@ -307,8 +333,9 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
         if (bad) {
             start = prevEnd;
             xa = start & 0xFFFFu; xb = start >> 16;
-            bits = wv_count<TT4>(ttb, src, n, j0, j1, xa, xb);
-            end = xa | (xb << 16);
+            ck.oldBits = bits; ck.merged = false;
+            bits = wv_run<false, TT4, WV_CK_MERGE>(ttb, src, n, j0, j1, xa, xb, nullptr, &ck);
+            if (!ck.merged) end = xa | (xb << 16);                        // merged: the rest of the range, and its end states, repeat the previous run
         }
         ETIMING(++rounds;)
     }
