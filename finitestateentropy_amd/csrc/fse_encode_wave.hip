@@ -11,7 +11,8 @@
 //   arbitrary state, remembers the states it arrives with (its speculated start), then runs its range counting
 //   bits and remembers the states it ends with.  Verification: lane t's speculated start must equal lane t-1's
 //   end; lane 0 starts from the exact FSE_initCState2 states, so if every link matches, every start is exact by
-//   induction.  A lane whose link does not match re-runs its range from its predecessor's end, and the check is
+//   induction.  A lane whose link does not match re-runs its range from its predecessor's end -- only as far as the
+//   first checkpoint at which it has merged with the trajectory its previous run recorded -- and the check is
 //   repeated until no link changes (worst case this degenerates into the serial algorithm).  Nothing is assumed:
 //   the output is bit-exact by construction.
 //   Pass 2: a wave prefix sum of the bit counts gives every lane its bit offset (and the exact compressed size /
@@ -25,7 +26,7 @@
 
 // Warm-up symbols (half per chain) in front of every range.  Two states fed the same symbols merge with probability
 // ~ present/tableSize per step (sum_s p_s / norm_s), so the warm-up is sized as a multiple of tableSize/present.
-#define FSE_WV_WARM_FACTOR 4u
+#define FSE_WV_WARM_FACTOR 2u
 #define FSE_WV_WARM_MIN 64u
 #define FSE_WV_WARM_MAX 4096u
 
