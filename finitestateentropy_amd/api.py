@@ -6,6 +6,7 @@ pointers on torch's current stream.  ``results`` tensors are ``torch.int64`` vie
 Single-block functions take numpy arrays (host pointers) and have the reference's exact signatures.
 """
 import ctypes as C
+import numbers
 
 import numpy as np
 import torch
@@ -40,12 +41,25 @@ def _ptr(t):
     return VP(t.data_ptr()) if t is not None else VP(0)
 
 
-def _sizes_arg(sizes):
-    """sizes: None | int | int64/uint64 cuda tensor -> (device pointer or NULL, uniform, keepalive)"""
-    if sizes is None or isinstance(sizes, int):
+def _sizes_arg(sizes, like=None):
+    """sizes: None | integer (python or numpy) | integer cuda tensor -> (device pointer or NULL, uniform, keepalive)"""
+    if sizes is None or isinstance(sizes, numbers.Integral):
         return VP(0), SZ(int(sizes or 0)), None
+    if not isinstance(sizes, torch.Tensor) or not sizes.is_cuda:
+        raise TypeError("per-block sizes must be an integer or a CUDA integer tensor (the C ABI takes a device pointer)")
+    if like is not None and sizes.device != like.device:
+        raise ValueError("sizes live on %s, the blocks on %s" % (sizes.device, like.device))
     t = sizes.to(torch.int64).contiguous()
     return VP(t.data_ptr()), SZ(0), t
+
+
+def _blocks(t, what):
+    """a batch of byte blocks handed to the C ABI as (base pointer, row stride): uint8, on the GPU, rows contiguous"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 2:
+        raise TypeError("%s must be a 2-D CUDA uint8 tensor" % what)
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError("%s: bytes of a block must be contiguous (stride(1) == 1); call .contiguous()" % what)
+    return t
 
 
 class FseHip:
@@ -81,34 +95,46 @@ class FseHip:
         self.lib.FSEHIP_probagen_table(t.ctypes.data_as(VP), C.c_double(p))
         return t
 
-    def probagen_batch(self, p_percent, n_blocks, block_size=32768, first_seed=1, out=None, device="cuda"):
-        """block b = probagen(block_size, p, seed=first_seed+b)  (programs/probaGenerator.c)"""
+    def probagen_batch(self, p_percent, n_blocks, block_size=32768, first_seed=1, out=None, device="cuda", seed_step=1):
+        """block b = probagen(block_size, p, seed=first_seed + b*seed_step)  (programs/probaGenerator.c)"""
         table = self.probagen_table(p_percent / 100.0)
         if out is None:
             out = torch.empty((n_blocks, block_size), dtype=torch.uint8, device=device)
-        _check(self.lib.FSEHIP_probagen_batch(_ptr(out), SZ(out.stride(0)), SZ(block_size), SZ(n_blocks),
-                                              table.ctypes.data_as(VP), C.c_uint32(first_seed), _stream()), "probagen_batch")
+        _check(self.lib.FSEHIP_probagen_batch_ex(_ptr(out), SZ(out.stride(0)), SZ(block_size), SZ(n_blocks),
+                                                 table.ctypes.data_as(VP), C.c_uint32(first_seed & 0xFFFFFFFF), C.c_uint32(seed_step), _stream()), "probagen_batch")
+        return out
+
+    def probagen_mixed(self, probas, n_blocks, block_size=32768, first_block=0, device="cuda"):
+        """BASELINE config 5 corpus: global block g (= first_block + row) is drawn from distribution probas[g mod len(probas)]
+        with seed g + 1 -- one strided generator call per distribution."""
+        out = torch.empty((n_blocks, block_size), dtype=torch.uint8, device=device)
+        k = len(probas)
+        for j in range(k):
+            r0 = (j - first_block) % k                       # first row whose global index is congruent to j
+            rows = out[r0::k]
+            if rows.shape[0]:
+                self.probagen_batch(probas[j], rows.shape[0], block_size, first_seed=first_block + r0 + 1, out=rows, seed_step=k)
         return out
 
     # ------------------------------------------------------------------ a1
     def hist_count_batch(self, src, sizes=None, max_symbol_values=None):
-        n = src.shape[0]
+        n = _blocks(src, "src").shape[0]
         counts = torch.zeros((n, 256), dtype=torch.int32, device=src.device)
         msv = (torch.full((n,), 255, dtype=torch.int32, device=src.device) if max_symbol_values is None
                else max_symbol_values.to(torch.int32).contiguous().clone())
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
-        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         _check(self.lib.FSEHIP_HIST_count_batch(_ptr(counts), _ptr(msv), _ptr(res), _ptr(src), SZ(src.stride(0)), ps, uni,
                                                 SZ(n), _stream()), "HIST_count_batch")
         return counts, msv, res
 
     # ------------------------------------------------------------------ a2 / a3
     def fse_compress_using_ctable_batch(self, src, ctables, max_table_log=12, sizes=None, dst_capacity=None, shared_table=False):
-        n = src.shape[0]
+        n = _blocks(src, "src").shape[0]
         cap = fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
         dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
-        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_FSE_compress_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
                                                               ps, uni, _ptr(ctables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()),
@@ -116,10 +142,10 @@ class FseHip:
         return dst, res
 
     def fse_decompress_using_dtable_batch(self, csrc, csizes, dtables, dst_capacity, max_table_log=12, shared_table=False):
-        n = csrc.shape[0]
+        n = _blocks(csrc, "csrc").shape[0]
         dst = torch.zeros((n, max(dst_capacity, 1)), dtype=torch.uint8, device=csrc.device)
         res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
-        ps, uni, keep = _sizes_arg(csizes)
+        ps, uni, keep = _sizes_arg(csizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)
         _check(self.lib.FSEHIP_FSE_decompress_usingDTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(res), _ptr(csrc),
                                                                 SZ(csrc.stride(0)), ps, uni, _ptr(dtables), SZ(stride),
@@ -134,7 +160,7 @@ class FseHip:
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
     def fse_compress_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
-        n = src.shape[0]
+        n = _blocks(src, "src").shape[0]
         cap = (fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity)
         if dst is None:
             dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
@@ -142,21 +168,21 @@ class FseHip:
             results = torch.empty(n, dtype=torch.int64, device=src.device)
         if workspace is None:
             workspace = self.fse_workspace(n, table_log, False, src.device)
-        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         _check(self.lib.FSEHIP_FSE_compress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(src.stride(0)), ps, uni,
                                                   C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace),
                                                   SZ(workspace.numel()), _stream()), "FSE_compress_batch")
         return dst, results
 
     def fse_decompress_batch(self, csrc, csizes, dst_capacity, max_log=12, dst=None, results=None, workspace=None):
-        n = csrc.shape[0]
+        n = _blocks(csrc, "csrc").shape[0]
         if dst is None:
             dst = torch.empty((n, max(dst_capacity, 1)), dtype=torch.uint8, device=csrc.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=csrc.device)
         if workspace is None:
             workspace = self.fse_workspace(n, max_log, True, csrc.device)
-        ps, uni, keep = _sizes_arg(csizes)
+        ps, uni, keep = _sizes_arg(csizes, csrc)
         _check(self.lib.FSEHIP_FSE_decompress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(results), _ptr(csrc), SZ(csrc.stride(0)),
                                                     ps, uni, C.c_uint(max_log), SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()),
                "FSE_decompress_batch")
@@ -202,7 +228,7 @@ def _huf_methods():
         return torch.empty(int(fn(SZ(n_blocks))), dtype=torch.uint8, device=device)
 
     def huf_compress_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
-        n = src.shape[0]
+        n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
         if dst is None:
             dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
@@ -210,34 +236,34 @@ def _huf_methods():
             results = torch.empty(n, dtype=torch.int64, device=src.device)
         if workspace is None:
             workspace = self.huf_workspace(n, False, src.device)
-        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         _check(self.lib.FSEHIP_HUF_compress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(src.stride(0)), ps, uni,
                                                   C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace),
                                                   SZ(workspace.numel()), _stream()), "HUF_compress_batch")
         return dst, results
 
     def huf_decompress_batch(self, csrc, csizes, dst_sizes, dst=None, results=None, workspace=None):
-        n = csrc.shape[0]
-        width = dst_sizes if isinstance(dst_sizes, int) else int(dst_sizes.max().item())
+        n = _blocks(csrc, "csrc").shape[0]
+        width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
         if dst is None:
             dst = torch.empty((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=csrc.device)
         if workspace is None:
             workspace = self.huf_workspace(n, True, csrc.device)
-        pc, unic, keepc = _sizes_arg(csizes)
-        pd, unid, keepd = _sizes_arg(dst_sizes)
+        pc, unic, keepc = _sizes_arg(csizes, csrc)
+        pd, unid, keepd = _sizes_arg(dst_sizes, csrc)
         _check(self.lib.FSEHIP_HUF_decompress_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(results), _ptr(csrc), SZ(csrc.stride(0)), pc, unic,
                                                     SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()), "HUF_decompress_batch")
         return dst, results
 
     def huf_compress4x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
         """ctables: (n, 256) int32/uint32 HUF_CElt entries (val | nbBits << 16)"""
-        n = src.shape[0]
+        n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
         dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
-        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_HUF_compress4X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
                                                                 ps, uni, _ptr(ctables), SZ(stride), SZ(n), _stream()),
@@ -245,12 +271,12 @@ def _huf_methods():
         return dst, res
 
     def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
-        n = csrc.shape[0]
-        width = dst_sizes if isinstance(dst_sizes, int) else int(dst_sizes.max().item())
+        n = _blocks(csrc, "csrc").shape[0]
+        width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
         dst = torch.zeros((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
         res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
-        pc, unic, keepc = _sizes_arg(csizes)
-        pd, unid, keepd = _sizes_arg(dst_sizes)
+        pc, unic, keepc = _sizes_arg(csizes, csrc)
+        pd, unid, keepd = _sizes_arg(dst_sizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)
         _check(self.lib.FSEHIP_HUF_decompress4X1_usingDTable_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(res), _ptr(csrc), SZ(csrc.stride(0)),
                                                                    pc, unic, _ptr(dtables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()),

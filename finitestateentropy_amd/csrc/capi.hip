@@ -28,19 +28,44 @@ extern "C" const char* FSEHIP_getErrorName(size_t code)   // lib/error_private.h
 
 extern "C" const char* FSEHIP_versionString(void) { return "fsehip 0.1 (gfx950)"; }
 
+// Per-device caches (a process may drive several devices: the attribute and the CU count belong to the current one),
+// guarded for concurrent host threads.
+#include <mutex>
+#include <vector>
+#include <utility>
+namespace {
+std::mutex g_devMutex;
+const int MAX_DEVS = 64;
+DevProps g_props[MAX_DEVS];
+std::vector<std::pair<int, const void*>> g_ldsAttrDone;      // (device, kernel) pairs already configured
+}
 const DevProps& dev_props()
 {
-    static DevProps p = { 0, 0, false };
+    static const DevProps none = { 0, 0, false };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVS) return none;
+    std::lock_guard<std::mutex> lock(g_devMutex);
+    DevProps& p = g_props[dev];
     if (!p.ok) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             p.cus = prop.multiProcessorCount;
             p.ldsPerCU = (int)prop.maxSharedMemoryPerMultiProcessor;
             p.ok = true;
         }
     }
     return p;
+}
+hipError_t ensure_dyn_lds(const void* kernel, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_devMutex);
+    for (auto& d : g_ldsAttrDone) if (d.first == dev && d.second == kernel) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) g_ldsAttrDone.emplace_back(dev, kernel);
+    return e;
 }
 
 extern "C" int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info)
@@ -59,8 +84,8 @@ extern "C" int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info)
 }
 
 // ---- kernel timing probe ------------------------------------------------------------------------------
-#include <vector>
 namespace {
+std::mutex g_probeMutex;
 struct Probe {
     bool on = false;
     std::vector<hipEvent_t> pool;            // reusable events
@@ -78,6 +103,7 @@ struct Probe {
 void probe_before(int id, hipStream_t s)
 {
     if (!g_probe.on) return;
+    std::lock_guard<std::mutex> lock(g_probeMutex);
     hipEvent_t e = g_probe.get();
     g_probe.pending[id] = e;
     if (e) (void)hipEventRecord(e, s);
@@ -85,17 +111,20 @@ void probe_before(int id, hipStream_t s)
 void probe_after(int id, hipStream_t s)
 {
     if (!g_probe.on) return;
+    std::lock_guard<std::mutex> lock(g_probeMutex);
     hipEvent_t e = g_probe.get();
     if (e && g_probe.pending[id]) { (void)hipEventRecord(e, s); g_probe.recs.push_back({ id, g_probe.pending[id], e }); }
 }
 extern "C" int FSEHIP_probe_begin(void)
 {
+    std::lock_guard<std::mutex> lock(g_probeMutex);
     g_probe.on = true; g_probe.used = 0; g_probe.recs.clear();
     return 0;
 }
 extern "C" int FSEHIP_probe_collect(double* totalMs, unsigned* launches)
 {
     for (int i = 0; i < 16; ++i) { totalMs[i] = 0; launches[i] = 0; }
+    std::lock_guard<std::mutex> lock(g_probeMutex);
     g_probe.on = false;
     for (auto& r : g_probe.recs) {
         CK(hipEventSynchronize(r.b));
@@ -132,14 +161,42 @@ extern "C" void FSEHIP_probagen_table(uint8_t table[4096], double p)   // progra
 extern "C" int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
                                      const uint8_t h_table[4096], uint32_t firstSeed, void* stream)
 {
+    return FSEHIP_probagen_batch_ex(d_dst, dstStride, blockSize, nBlocks, h_table, firstSeed, 1, stream);
+}
+extern "C" int FSEHIP_probagen_batch_ex(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
+                                        const uint8_t h_table[4096], uint32_t firstSeed, uint32_t seedStep, void* stream)
+{
     hipStream_t s = (hipStream_t)stream;
     u8* d_table = nullptr;
     CK(hipMalloc(&d_table, 4096));
     hipError_t e = hipMemcpyAsync(d_table, h_table, 4096, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = launch_probagen((u8*)d_dst, dstStride, blockSize, nBlocks, d_table, firstSeed, s);
+    if (e == hipSuccess) e = launch_probagen((u8*)d_dst, dstStride, blockSize, nBlocks, d_table, firstSeed, seedStep, s);
     hipError_t e2 = hipStreamSynchronize(s);   // the table must outlive the kernel
     (void)hipFree(d_table);
     return (int)(e != hipSuccess ? e : e2);
+}
+
+// Argument errors of the one-shot calls are per-block results, like everything else the reference call would return for
+// block b (include/fsehip.h): the batch call itself still succeeds.
+//   mode 0 (FSE_compress2, lib/fse_compress.c:691): every block gets `code`;
+//   mode 1 (HUF_compress_internal, lib/huf_compress.c:654-660): srcSize 0 or dstCapacity 0 -> 0, srcSize > HUF_BLOCKSIZE_MAX ->
+//          srcSize_wrong come first, then `code`.
+__global__ void k_batch_arg_error(size_t* results, const size_t* sizes, size_t uniform, size_t dstCapacity, size_t nBlocks, size_t code, int mode)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    size_t r = code;
+    if (mode == 1) {
+        const size_t n = sizes ? sizes[b] : uniform;
+        if (n == 0 || dstCapacity == 0) r = 0;
+        else if (n > FSEHIP_HUF_BLOCKSIZE_MAX) r = FERR(srcSize_wrong);
+    }
+    results[b] = r;
+}
+static int batch_arg_error(size_t* d_results, const size_t* d_sizes, size_t uniform, size_t dstCapacity, size_t nBlocks, size_t code, int mode, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_batch_arg_error, dim3((unsigned)((nBlocks + 255) / 256)), dim3(256), 0, s, d_results, d_sizes, uniform, dstCapacity, nBlocks, code, mode);
+    return (int)hipGetLastError();
 }
 
 // =====================================================================================================
@@ -226,7 +283,8 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
 {
     hipStream_t s = (hipStream_t)stream;
     if (nBlocks == 0) return 0;
-    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return (int)hipErrorInvalidValue;   // FSE_compress2 -> tableLog_tooLarge (fse_compress.c:691); see single-block wrapper
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG)                                       // FSE_compress2 -> tableLog_tooLarge for every block (fse_compress.c:691)
+        return batch_arg_error(d_results, nullptr, 0, dstCapacity, nBlocks, FSEHIP_ERROR(tableLog_tooLarge), 0, s);
     const FseCWs w = fse_cws(tableLog);
     if (workspaceBytes < w.perBlock + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / w.perBlock;
@@ -348,8 +406,8 @@ extern "C" size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity,
 {
     const u16* h = (const u16*)ct;
     const unsigned tl = h[0], msv = h[1];
-    if (tl > FSEHIP_FSE_MAX_TABLELOG || msv > 255) return FSEHIP_ERROR(tableLog_tooLarge);
-    const size_t words = 1 + (tl ? ((size_t)1 << (tl - 1)) : 1) + 2 * ((size_t)msv + 1);
+    if (tl > FSEHIP_FSE_MAX_TABLELOG) return FSEHIP_ERROR(tableLog_tooLarge);
+    const size_t words = 1 + (tl ? ((size_t)1 << (tl - 1)) : 1) + 2 * ((size_t)(msv > 255 ? 255 : msv) + 1);   // byte symbols: larger entries are unreachable
     DevBuf dsrc, ddst, dct, dres;
     HK(dsrc.alloc(srcSize)); HK(ddst.alloc(dstCapacity)); HK(dct.alloc(words * 4)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
@@ -462,7 +520,9 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
 {
     hipStream_t s = (hipStream_t)stream;
     if (nBlocks == 0) return 0;
-    if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255) return (int)hipErrorInvalidValue;   // huf_compress.c:659-660 (see single-block wrapper)
+    if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255)               // huf_compress.c:656-660, in the reference's order, per block
+        return batch_arg_error(d_results, d_sizes, uniformSize, dstCapacity, nBlocks,
+                               tableLog > FSEHIP_HUF_TABLELOG_MAX ? FSEHIP_ERROR(tableLog_tooLarge) : FSEHIP_ERROR(maxSymbolValue_tooLarge), 1, s);
     if (workspaceBytes < HUF_CWS_PER_BLOCK + HUF_CWS_NODE_PAD + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK - HUF_CWS_NODE_PAD) / HUF_CWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;

@@ -64,7 +64,11 @@ u32 xxh32(const u8* p, size_t len, u32 seed)
     h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
     return h;
 }
-void Checksum::start(const u8* p, size_t n) { th = std::thread([this, p, n] { value = (xxh32(p, n, 0) >> 5) & ((1u << 22) - 1); }); }
+void Checksum::start(const u8* p, size_t n)
+{
+    if (n < ((size_t)1 << 20)) { value = (xxh32(p, n, 0) >> 5) & ((1u << 22) - 1); return; }     // small inputs: not worth a thread
+    th = std::thread([this, p, n] { value = (xxh32(p, n, 0) >> 5) & ((1u << 22) - 1); });
+}
 inline size_t block_size(unsigned id) { return (size_t)1024 << id; }   // fileio.c:219
 inline size_t cbound(size_t n) { return FSEHIP_FSE_COMPRESSBOUND(n); }
 
@@ -84,7 +88,7 @@ extern "C" size_t FSEHIP_frame_compressBound(size_t srcSize, unsigned blockSizeI
     return 5 + srcSize + 5 * ((srcSize + bs - 1) / bs) + 3;
 }
 
-extern "C" size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec)
+static size_t frame_compress_impl(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec)
 {
     if (blockSizeId > MAX_BSID || (codec != 0 && codec != 1)) return FSEHIP_ERROR(GENERIC);
     if (dstCapacity < FSEHIP_frame_compressBound(srcSize, blockSizeId)) return FSEHIP_ERROR(dstSize_tooSmall);
@@ -134,7 +138,7 @@ extern "C" size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const voi
     return o;
 }
 
-extern "C" size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+static size_t frame_decompress_impl(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
     u8* const out = (u8*)dst;
     const u8* const in = (const u8*)src;
@@ -166,6 +170,9 @@ extern "C" size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const v
         if (k.bt == BT_COMPRESSED) { if (ip + 2 > srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; } k.cSize = ((size_t)in[ip] << 8) + in[ip + 1]; ip += 2; }
         else k.cSize = k.bt == BT_RAW ? k.rSize : 1;
         if (ip + k.cSize > srcSize) { frameErr = FSEHIP_ERROR(srcSize_wrong); break; }
+        // the reference tool's buffers hold blockSize bytes (fileio.c:509-510): a larger announced size is outside its contract and
+        // would overrun the bs-byte device slots below -- rejected here (the oracle does the same)
+        if (k.rSize > bs) { frameErr = FSEHIP_ERROR(corruption_detected); break; }
         k.at = ip; ip += k.cSize;
         blocks.push_back(k);
     }
@@ -241,4 +248,17 @@ extern "C" size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const v
     const u32 calc = (xxh32(out, o, 0) >> 5) & ((1u << 22) - 1);                  // :604-607
     if (calc != savedCrc) return FSEHIP_ERROR(corruption_detected);
     return o;
+}
+
+// The C ABI never lets a C++ exception through (std::bad_alloc from the block vectors, whose sizes come from an untrusted
+// frame, or std::system_error from the checksum thread): it becomes the generic error code.
+extern "C" size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec)
+{
+    try { return frame_compress_impl(dst, dstCapacity, src, srcSize, blockSizeId, codec); }
+    catch (...) { return FSEHIP_ERROR(GENERIC); }
+}
+extern "C" size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    try { return frame_decompress_impl(dst, dstCapacity, src, srcSize); }
+    catch (...) { return FSEHIP_ERROR(GENERIC); }
 }

@@ -579,13 +579,10 @@ size_t fse_decode_blocks_per_round(unsigned maxTableLog)
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    static bool attrSet = false;
     const size_t ldsBytes = FSE_DEC_LDS;
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_fse_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fse_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true>, (int)ldsBytes);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false>, (int)ldsBytes);
         if (e != hipSuccess) return e;
-        attrSet = true;
     }
     fse_decode_geometry(a.maxTableLog, ldsBytes, &a.slotU32, &a.G);
     if (a.G < 1) return hipErrorInvalidValue;

@@ -38,8 +38,10 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
         if (a.meta && fse_enc_skip(a.meta[b].state, a.onlyState)) continue;
         const u32* t = a.ctables + b * a.ctStrideU32;
         const u32 h = t[0];
-        const u32 tl = h & 0xFFFFu, msv = h >> 16;
-        if (tl > a.maxTableLog || msv > 255u) continue;
+        // symbols are bytes: entries above 255 of a table with a larger maxSymbolValue (FSE_buildCTable_raw with nbBits > 8,
+        // lib/fse_compress.c:498-528) can never be addressed and are not staged
+        const u32 tl = h & 0xFFFFu, msv = (h >> 16) > 255u ? 255u : (h >> 16);
+        if (tl > a.maxTableLog) continue;
         const u32 ttStart = 1 + (tl ? (1u << (tl - 1)) : 1u);
         const u32 words = ttStart + 2 * (msv + 1);
         u32* s = lds + (size_t)g * a.slotU32;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
 
     const u32 h0 = a.ctables[b * a.ctStrideU32];
     const u32 tl = h0 & 0xFFFFu;
-    if (tl > a.maxTableLog || (h0 >> 16) > 255u) {                   // table does not fit the slot the caller configured
+    if (tl > a.maxTableLog) {                                        // table does not fit the slot the caller configured
         a.results[b] = FERR(tableLog_tooLarge);
         return;
     }
@@ -169,13 +171,8 @@ size_t fse_encode_blocks_per_round(unsigned maxTableLog)
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    static bool attrSet = false;
     const size_t ldsBytes = FSE_ENC_LDS;
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_fse_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
+    {   const hipError_t e = ensure_dyn_lds((const void*)k_fse_encode, (int)ldsBytes); if (e != hipSuccess) return e; }
     fse_encode_geometry(a.maxTableLog, &a.slotU32, &a.G);
     // 32-bit lane offsets inside a group
     if (a.nBlocks > 1 && ((a.src.stride > 0x3FFFFFFu) || (a.dstStride > 0x3FFFFFFu))) return hipErrorInvalidValue;

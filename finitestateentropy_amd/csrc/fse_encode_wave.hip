@@ -253,8 +253,8 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     u32 tl = 0, msv = 0;
     if (on) {
         const u32 h0 = gct[0];
-        tl = h0 & 0xFFFFu; msv = h0 >> 16;
-        if (tl > a.maxTableLog || msv > 255u) { if (hl == 0) a.results[b] = FERR(tableLog_tooLarge); on = false; }
+        tl = h0 & 0xFFFFu; msv = (h0 >> 16) > 255u ? 255u : (h0 >> 16);      // symbols are bytes: larger entries are unreachable (raw tables, fse_compress.c:498-528)
+        if (tl > a.maxTableLog) { if (hl == 0) a.results[b] = FERR(tableLog_tooLarge); on = false; }
     }
     const u8* const src = on ? view_ptr(a.src, b) : nullptr;
     const size_t n64 = on ? view_size(a.src, b) : 0;
@@ -263,6 +263,13 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     if (on && n64 >= ((size_t)1 << 31)) { if (hl == 0) a.results[b] = FERR(srcSize_wrong); on = false; }
     const u32 n = (u32)n64;
     if (on && (n <= 2 || cap <= 8)) { if (hl == 0) a.results[b] = 0; on = false; }    // fse_compress.c:566-568
+    // tableLog 0 = the fake table of FSE_buildCTable_rle (fse_compress.c:531-551): its one symbol costs no bits and the state
+    // stays 0, so the stream is the end mark alone (two 0-bit states, then BIT_closeCStream: one byte).  The packed entry
+    // format below cannot express minStatePlus == 0, so the block is finished here.
+    if (on && tl == 0) {
+        if (hl == 0) { dst[0] = 1; a.results[b] = a.meta ? (((size_t)hdr + 1 < n64 - 1) ? (size_t)hdr + 1 : 0) : 1; }
+        on = false;
+    }
 
     // ---- stage the CTable (coalesced): word 0 header, stateTable at byte 4, symbolTT rebased to LDS byte addresses
     const u32 ttStart = 1 + (tl ? (1u << (tl - 1)) : 1u);

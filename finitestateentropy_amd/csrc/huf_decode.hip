@@ -406,13 +406,8 @@ static int huf_decode_G(size_t ldsBytes)
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    static bool attrSet = false;
     const size_t ldsBytes = 80 * 1024;               // two workgroups per CU
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_huf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
+    {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_decode, (int)ldsBytes); if (e != hipSuccess) return e; }
     a.G = huf_decode_G(ldsBytes);
     a.slotU32 = 0;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;

@@ -242,13 +242,8 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
 hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    static bool attrSet = false;
     const size_t maxLds = 64 * 1024;
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_huf_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
+    {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_encode, (int)maxLds); if (e != hipSuccess) return e; }
     size_t img = a.dstCapacity + 16;
     if (img > maxLds - 1100) img = maxLds - 1100;
     img = (img + 15) & ~(size_t)15;

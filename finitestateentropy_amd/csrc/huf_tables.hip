@@ -475,12 +475,7 @@ hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* nodeScra
 {
     if (a.nBlocks == 0) return hipSuccess;
     probe_before(PK_HUF_CPREP, s);
-    static bool attrSet = false;
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_huf_presort, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
+    {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_presort, 64 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_huf_presort, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 64 * 1024, s, a, (hnode_t*)nodeScratch);
     hipLaunchKernelGGL(k_huf_cprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a, (hnode_t*)nodeScratch);
     probe_after(PK_HUF_CPREP, s);

@@ -158,13 +158,15 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
 
 // ---- workload generator -----------------------------------------------------------------------------
-hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, hipStream_t s);
+hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, u32 seedStep, hipStream_t s);
 
 // ---- kernel timing probe (HIP events on the launch stream; used by bench.py for the live roofline figure) ----
 enum { PK_HIST = 0, PK_FSE_CPREP, PK_FSE_ENCODE, PK_FSE_DPREP, PK_FSE_DECODE, PK_HUF_CPREP, PK_HUF_ENCODE, PK_HUF_DPREP, PK_HUF_DECODE, PK_FSE_ENCODE_WAVE, PK_COUNT };
 void probe_before(int kernelId, hipStream_t s);
 void probe_after(int kernelId, hipStream_t s);
 
-// device properties cache
+// per-device caches (capi.hip): properties of the current device; "this kernel may use `bytes` of dynamic LDS" is set once
+// per (device, kernel)
 struct DevProps { int cus; int ldsPerCU; bool ok; };
 const DevProps& dev_props();
+hipError_t ensure_dyn_lds(const void* kernel, int bytes);

@@ -85,3 +85,26 @@ def sharded_roundtrip(blocks_root, n_blocks, block_bytes, rank, world, device, c
     g_slots, g_sizes = gather_blocks(slots, sizes, n_blocks, rank, world, root)
     g_back, g_res = gather_blocks(back, results, n_blocks, rank, world, root)
     return g_slots, g_sizes, g_back, g_res
+
+
+def sharded_codec_job(corpus_root, n_blocks, block_bytes, rank, world, device, codecs, root=0):
+    """BASELINE config 5 with the corpus on one rank (bench.py's with-comm variant): scatter the raw blocks, run every codec's
+    encode + decode on the rank's shard, gather every codec's compressed slots and sizes on the root.
+    `codecs`: objects with .src (set here), .encode(), .decode(), .dst (rows, stride), .res, .out, .dres.
+    Returns (my shard, [(slots, sizes) per codec on the root, (None, None) elsewhere])."""
+    mine = scatter_blocks(corpus_root, n_blocks, block_bytes, rank, world, device, root)
+    for cd in codecs:
+        cd.src = mine
+        cd.encode()
+        cd.decode()
+    gathered = [gather_blocks(cd.dst, cd.res, n_blocks, rank, world, root) for cd in codecs]
+    return mine, gathered
+
+
+def sharded_job_ok(mine, gathered, codecs, n_blocks, block_bytes, rank, world, root=0):
+    """round trip on this rank's shard, and (root) the gathered sizes of its own range equal its local results"""
+    ok = all(bool((cd.dres == block_bytes).all()) and torch.equal(cd.out, mine) for cd in codecs)
+    if rank == root:
+        lo, hi = shard_range(n_blocks, rank, world)
+        ok = ok and all(torch.equal(g[1][lo:hi], cd.res) for g, cd in zip(gathered, codecs))
+    return ok

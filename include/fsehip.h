@@ -172,6 +172,10 @@ FSEHIP_API int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
 FSEHIP_API void FSEHIP_probagen_table(uint8_t table4096[4096], double p);
 FSEHIP_API int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
                                      const uint8_t h_table4096[4096], uint32_t firstSeed, void* stream);
+/* same with seed = firstSeed + b * seedStep: lets a caller interleave several distributions in one corpus (BASELINE config 5:
+ * block g of the corpus = distribution g mod 3, seed g + 1 -> three calls with dstStride = 3 blocks and seedStep = 3) */
+FSEHIP_API int FSEHIP_probagen_batch_ex(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
+                                        const uint8_t h_table4096[4096], uint32_t firstSeed, uint32_t seedStep, void* stream);
 
 /* ---- .fse frames on HOST buffers: the container written / read by the reference's command-line tool
  * (programs/fileio.c:266-285 format, FIO_compressFilename :286-432, FIO_decompressFilename :462-626) around blocks of

@@ -1,0 +1,16 @@
+/* oracle/fse_on_mi355x.h -- TEST INFRASTRUCTURE: the 3-line shim of INTEGRATION.md section 1.
+ * Force-included (gcc -include) when compiling the reference's own programs/fuzzer.c and programs/fuzzerHuff0.c, AFTER
+ * which every hot-path call written in those programs (HIST_count, FSE_compress[2], FSE_decompress,
+ * FSE_compress_usingCTable, FSE_decompress_usingDTable, HUF_compress[2], HUF_decompress, HUF_compress1X/4X_usingCTable,
+ * HUF_decompress4X[1]_usingDTable) resolves to libfsehip.so; the reference's lib/ objects are compiled WITHOUT it and
+ * still provide the table builders the programs call (FSE_normalizeCount, FSE_readNCount, FSE_buildCTable_raw, ...). */
+#ifndef FSE_ON_MI355X_H
+#define FSE_ON_MI355X_H
+#define FSE_STATIC_LINKING_ONLY
+#define HUF_STATIC_LINKING_ONLY
+#include "fse.h"
+#include "huf.h"
+#include "hist.h"
+#define FSEHIP_DROPIN_NAMES
+#include "fsehip.h"
+#endif

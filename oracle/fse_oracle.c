@@ -1122,6 +1122,15 @@ double orc_decompress_batch(int codec, const u8* cSrc, size_t cStride, const u64
     return wall_s() - t0;
 }
 
+/* multi-core CPU baseline driver (bench.py cpu_baseline, kind "port") */
+#define now_s wall_s
+#define CPUB_NAME orc_bench_roundtrip
+#define CPUB_STREAM_NAME orc_stream_bandwidth
+#define CPUB_COMPRESS(codec, d, cap, s, n, msv, tl) ((codec) == 0 ? orc_fse_compress2(d, cap, s, n, msv, tl) : orc_huf_compress2(d, cap, s, n, msv, tl))
+#define CPUB_DECOMPRESS(codec, d, n, s, cs) ((codec) == 0 ? orc_fse_decompress(d, n, s, cs) : orc_huf_decompress(d, n, s, cs))
+#include "cpu_bench.h"
+#undef now_s
+
 /* ------------------------------------------------------------------------------------------
  *  XXH64 (public spec) -- only for the Appendix-B known-answer table
  * ---------------------------------------------------------------------------------------- */
@@ -1271,6 +1280,9 @@ size_t orc_frame_decompress(void* dst, size_t dstCapacity, const void* src, size
         if (bt == FBT_COMPRESSED) { if (ip + 2 > srcSize) return ERR(srcSize_wrong); cSize = ((size_t)in[ip] << 8) + in[ip + 1]; ip += 2; }
         else if (bt == FBT_RAW) cSize = rSize; else cSize = 1;
         if (ip + cSize > srcSize) return ERR(srcSize_wrong);
+        /* the reference tool decodes into malloc(blockSize) buffers (:509-510): an announced size above the frame's block size is
+           outside its contract (it would overrun them); both this restatement and the device path reject such a frame here */
+        if (rSize > bs) return ERR(corruption_detected);
         if (bt == FBT_COMPRESSED) {
             if (o + rSize > dstCapacity) return ERR(dstSize_tooSmall);
             const size_t r = codec == 1 ? orc_huf_decompress(out + o, rSize, in + ip, cSize) : orc_fse_decompress(out + o, rSize, in + ip, cSize);   /* :570-573 */

@@ -218,6 +218,21 @@ class _Base:
         return int(r), out[:dst_size]
 
     # ---- batches (OpenMP) -----------------------------------------------------------------
+    def bench_roundtrip(self, codec, src2d, table_log=11, max_sv=255, nthreads=0, dynamic=False, min_seconds=1.0, reps=3):
+        """multi-core baseline loop (oracle/cpu_bench.h): returns dict(enc_s, dec_s per pass of the sample, threads, ...)"""
+        src2d = np.ascontiguousarray(src2d, dtype=np.uint8)
+        n, bs = src2d.shape
+        cap = fse_compress_bound(bs) if codec == 0 else huf_compress_bound(bs)
+        out = (C.c_double * 8)()
+        rc = self._call(self.N["bench_roundtrip"], C.c_int, C.c_int(codec), src2d.ctypes.data_as(self.vp), self.sz(n), self.sz(bs), self.sz(cap),
+                        C.c_uint(max_sv), C.c_uint(table_log), C.c_int(nthreads), C.c_int(1 if dynamic else 0), C.c_double(min_seconds), C.c_int(reps), out)
+        if rc != 0:
+            raise RuntimeError("bench_roundtrip failed: %d" % rc)
+        return {"enc_s": out[0], "dec_s": out[1], "threads": int(out[2]), "passes_enc": int(out[3]), "passes_dec": int(out[4]), "mean_csize": out[5]}
+
+    def stream_bandwidth(self, nbytes=1 << 30, nthreads=0, passes=5):
+        return float(self._call(self.N["stream_bandwidth"], C.c_double, self.sz(nbytes), C.c_int(nthreads), C.c_int(passes)))
+
     def compress_batch(self, codec, src2d, table_log=11, max_sv=255, nthreads=0, cap=None):
         """src2d: (nBlocks, blockSize) uint8.  Returns (seconds, results u64[n], dst (n, cap) u8)."""
         src2d = np.ascontiguousarray(src2d, dtype=np.uint8)
@@ -252,7 +267,8 @@ class Oracle(_Base):
          "huf_compress1x": "orc_huf_compress1x_using_ctable", "huf_compress4x": "orc_huf_compress4x_using_ctable",
          "huf_decompress4x1": "orc_huf_decompress4x1_using_dtable", "huf_decompress1x1": "orc_huf_decompress1x1_using_dtable",
          "huf_compress2": "orc_huf_compress2", "huf_decompress": "orc_huf_decompress",
-         "compress_batch": "orc_compress_batch", "decompress_batch": "orc_decompress_batch"}
+         "compress_batch": "orc_compress_batch", "decompress_batch": "orc_decompress_batch",
+         "bench_roundtrip": "orc_bench_roundtrip", "stream_bandwidth": "orc_stream_bandwidth"}
     kind = "port"
 
     def __init__(self):
@@ -314,7 +330,8 @@ class Ref(_Base):
          "huf_compress1x": "HUF_compress1X_usingCTable", "huf_compress4x": "HUF_compress4X_usingCTable",
          "huf_decompress4x1": "HUF_decompress4X1_usingDTable", "huf_decompress1x1": "HUF_decompress1X1_usingDTable",
          "huf_compress2": "HUF_compress2", "huf_decompress": "HUF_decompress", "huf_decompress4x1_oneshot": "HUF_decompress4X1",
-         "compress_batch": "ref_compress_batch", "decompress_batch": "ref_decompress_batch"}
+         "compress_batch": "ref_compress_batch", "decompress_batch": "ref_decompress_batch",
+         "bench_roundtrip": "ref_bench_roundtrip", "stream_bandwidth": "ref_stream_bandwidth"}
     kind = "reference"
 
     @staticmethod
@@ -331,3 +348,22 @@ class Ref(_Base):
     def max_threads(self):
         self.lib.ref_max_threads.restype = C.c_int
         return int(self.lib.ref_max_threads())
+
+
+class Checker(Oracle):
+    """What the `-m gpu` parity tests and bench.py compare the kernels with: the COMPILED REFERENCE itself whenever
+    oracle/_ref/libfse_ref.so is present (it travels to the GPU box with the snapshot), so kernel -> reference is one hop;
+    our restatement otherwise.  The workload generator, the .fse frame and the checksums exist only in the restatement
+    (the reference library has no such entry points; the frame restatement is pinned against the reference tool on the CPU)."""
+
+    def __init__(self):
+        super().__init__()
+        self.ref = Ref() if Ref.available() else None
+        if self.ref is not None:
+            self.N = Ref.N
+            self.kind = "reference"
+
+    def _f(self, name):
+        if self.ref is not None and not name.startswith("orc_"):
+            return getattr(self.ref.lib, name)
+        return getattr(self.lib, name)

@@ -116,3 +116,10 @@ size_t ref_sizeof_FSE_DTable_U32(unsigned tableLog) { return FSE_DTABLE_SIZE_U32
 size_t ref_FSE_compressBound(size_t n) { return FSE_COMPRESSBOUND(n); }
 size_t ref_FSE_blockBound(size_t n) { return FSE_BLOCKBOUND(n); }
 size_t ref_HUF_compressBound(size_t n) { return HUF_COMPRESSBOUND(n); }
+
+/* multi-core CPU baseline driver (bench.py cpu_baseline, kind "reference") */
+#define CPUB_NAME ref_bench_roundtrip
+#define CPUB_STREAM_NAME ref_stream_bandwidth
+#define CPUB_COMPRESS(codec, d, cap, s, n, msv, tl) ((codec) == 0 ? FSE_compress2(d, cap, s, n, msv, tl) : HUF_compress2(d, cap, s, n, msv, tl))
+#define CPUB_DECOMPRESS(codec, d, n, s, cs) ((codec) == 0 ? FSE_decompress(d, n, s, cs) : HUF_decompress(d, n, s, cs))
+#include "cpu_bench.h"

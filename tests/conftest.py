@@ -28,6 +28,13 @@ def ref():
 
 
 @pytest.fixture(scope="session")
+def checker():
+    """the GPU tests' checker: the compiled reference when oracle/_ref is present, the restatement otherwise"""
+    from oracle.oracle import Checker
+    return Checker()
+
+
+@pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
 

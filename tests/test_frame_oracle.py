@@ -67,6 +67,25 @@ def test_oracle_frame_other_block_sizes_and_errors(oracle):
     assert is_error(oracle.frame_decompress(out[:r], len(data) - 1)[0])        # destination too small
     assert is_error(oracle.frame_decompress(out[:r - 4], len(data))[0])        # truncated
     assert is_error(oracle.frame_compress(data, 7, 0)[0])                      # block size id out of range
+    for bad, cap in oversize_frames(oracle):                                   # announced size above the frame's block size
+        assert (1 << 64) - oracle.frame_decompress(bad, cap)[0] == 4           # corruption_detected
+
+
+def oversize_frames(oracle):
+    """frames with block-size id 0 (1 KiB) whose first block announces a regenerated size of 0xFFFF / 1025 bytes: the
+    reference tool would overrun its blockSize buffers (programs/fileio.c:509-510,570); we reject them"""
+    data = oracle.probagen_batch(14, 1, 5000, 21)[0]
+    out = []
+    for codec in (0, 1):
+        r, fr = oracle.frame_compress(data, 0, codec)
+        fr = fr[:r]
+        assert fr[5] == 0x20, "first block is a full compressed one"            # type 0, full-size flag
+        for announced in (0xFFFF, 1025):
+            bad = np.concatenate([fr[:5], np.array([0x00, announced >> 8, announced & 0xFF], np.uint8), fr[6:]])
+            out.append((bad, 70000))
+        raw = np.concatenate([fr[:5], np.array([0x40, 0x04, 0x01], np.uint8), data[:1025], fr[-3:]])   # raw block of 1025 bytes
+        out.append((raw, 70000))
+    return out
 
 
 def test_golden_frames(oracle, golden):

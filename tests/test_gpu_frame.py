@@ -4,10 +4,16 @@ import numpy as np
 import pytest
 
 from oracle.oracle import is_error
-from test_frame_oracle import _inputs
+from test_frame_oracle import _inputs, oversize_frames
 from test_gpu_fse import s64
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle(checker):
+    """in this module `oracle` is the one-hop checker: the compiled reference itself when oracle/_ref is present"""
+    return checker
 
 
 def test_frames_match_oracle(hip, oracle):
@@ -48,6 +54,7 @@ def test_frame_block_sizes_golden_and_errors(hip, oracle, golden):
     rng = np.random.default_rng(3)
     for _ in range(6):
         bad = frame.copy(); idx = rng.integers(5, r, 3); bad[idx] = rng.integers(0, 256, 3); cases.append((bad, len(data)))
+    cases += oversize_frames(oracle)                                        # announced size above the block size (bsid 0)
     for bad, cap in cases:
         ro, oo = oracle.frame_decompress(bad, cap)
         rg, og = hip.frame_decompress(bad, cap)

@@ -9,6 +9,12 @@ from test_gpu_fse import mixed_blocks, s64
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def oracle(checker):
+    """in this module `oracle` is the one-hop checker: the compiled reference itself when oracle/_ref is present"""
+    return checker
+
+
 def _huf_tables(oracle, blk, req):
     mx, msv, cnt = oracle.hist_count(blk)
     n = len(blk)

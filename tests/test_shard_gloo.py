@@ -39,6 +39,30 @@ def _worker(rank, world, port, n_blocks, block_bytes, q):
         _, res, out = orc.decompress_batch(0, slots.numpy(), sizes.numpy().astype(np.uint64), bs, nthreads=1)
         return torch.from_numpy(out), torch.from_numpy(res.astype(np.int64))
 
+    # bench.py's N>1 code path (config 5 with the corpus on rank 0): the very function bench.py calls, FSE and Huff0 codecs
+    class CpuCodec:
+        def __init__(self, codec):
+            self.codec = codec; self.src = None
+        def encode(self):
+            _, res, dst = orc.compress_batch(self.codec, self.src.numpy(), table_log=11, nthreads=1)
+            self.dst, self.res = torch.from_numpy(dst), torch.from_numpy(res.astype(np.int64))
+        def decode(self):
+            _, res, out = orc.decompress_batch(self.codec, self.dst.numpy(), self.res.numpy().astype(np.uint64), block_bytes, nthreads=1)
+            self.out, self.dres = torch.from_numpy(out), torch.from_numpy(res.astype(np.int64))
+    cds = [CpuCodec(0), CpuCodec(1)]
+    mine, gathered = shard.sharded_codec_job(blocks_root, n_blocks, block_bytes, rank, world, "cpu", cds)
+    job_ok = shard.sharded_job_ok(mine, gathered, cds, n_blocks, block_bytes, rank, world)
+    lo, hi = shard.shard_range(n_blocks, rank, world)
+    assert mine.shape[0] == hi - lo
+    if rank == 0:
+        for codec, (slots, sizes) in zip((0, 1), gathered):
+            _, sres, sdst = orc.compress_batch(codec, blocks_root.numpy(), table_log=11, nthreads=1)
+            job_ok = job_ok and bool((sizes.numpy() == sres.astype(np.int64)).all()) and all(
+                bool((slots[b, :int(sres[b])].numpy() == sdst[b][:int(sres[b])]).all()) for b in range(n_blocks))
+    else:
+        job_ok = job_ok and all(g == (None, None) for g in gathered)
+    assert job_ok
+
     g_slots, g_sizes, g_back, g_res = shard.sharded_roundtrip(blocks_root, n_blocks, block_bytes, rank, world, "cpu", comp, decomp)
     t = shard.max_over_ranks([float(rank + 1), 0.5], "cpu", world)
     assert t == [float(world), 0.5]
