@@ -327,8 +327,8 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     return 0;
 }
 
-// per block: meta, 256 counters, and the decoder-format table (2 + 1 bytes per cell)
-static size_t fse_dws_per_block(unsigned maxLog) { return sizeof(FseMeta) + 512 + 3 * ((size_t)1 << maxLog); }
+// per block: meta, 256 counters, the decoder-format table (2 + 1 bytes per cell) and one entry in each decoder-class list
+static size_t fse_dws_per_block(unsigned maxLog) { return sizeof(FseMeta) + 512 + 3 * ((size_t)1 << maxLog) + FSE_DCLS_COUNT * sizeof(u32); }
 static unsigned clamp_maxlog(unsigned maxLog) { return (maxLog == 0 || maxLog > FSEHIP_FSE_MAX_TABLELOG) ? FSEHIP_FSE_MAX_TABLELOG : maxLog; }
 
 extern "C" size_t FSEHIP_FSE_decompress_batch_workspaceSize(size_t nBlocks, unsigned maxLog)
@@ -355,18 +355,21 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
     s16* norms = (s16*)p; p += align_up(chunk * 512, 256);
     u16* atab = (u16*)p; p += align_up((chunk * 2) << maxLog, 256);
-    u8* symtab = p;
+    u8* symtab = p; p += align_up(chunk << maxLog, 256);
+    u32* lists = (u32*)p; p += align_up(chunk * FSE_DCLS_COUNT * sizeof(u32), 256);
+    u32* counts = (u32*)p;                                      // FSE_DCLS_COUNT words (WS_SLACK covers the padding and this)
     for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
         const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
         const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
         FseDPrepArgs d;
-        d.csrc = cs; d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.results = d_results + b0; d.nBlocks = nb;
+        d.csrc = cs; d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.lists = lists; d.counts = counts;
+        d.results = d_results + b0; d.nBlocks = nb;
         CK(launch_fse_dprep(d, s));
         FseDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
         e.csrc = cs; e.dtables = nullptr; e.dtStrideU32 = 0; e.atab = atab; e.symtab = symtab; e.meta = meta;
         e.maxTableLog = maxLog; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
-        CK(launch_fse_decode(e, s));
+        CK(launch_fse_decode_classes(e, lists, counts, s));
     }
     return 0;
 }
@@ -555,7 +558,7 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
     return 0;
 }
 
-static const size_t HUF_DWS_PER_BLOCK = sizeof(HufMeta) + 4 * (size_t)FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1);
+static const size_t HUF_DWS_PER_BLOCK = sizeof(HufMeta) + 4 * (size_t)FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1) + HUF_DCLS_COUNT * sizeof(u32);
 extern "C" size_t FSEHIP_HUF_decompress_batch_workspaceSize(size_t nBlocks)
 {
     size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
@@ -573,22 +576,24 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
     size_t chunk = (workspaceBytes - WS_SLACK) / HUF_DWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
     u8* p = (u8*)d_workspace;
-    HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
-    u32* dtables = (u32*)p;
     const size_t dtU32 = FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1);      // 2-byte cells: 2^tableLog cells = 2^(tableLog-1) words
+    HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
+    u32* dtables = (u32*)p; p += align_up(chunk * dtU32 * 4, 256);
+    u32* lists = (u32*)p; p += align_up(chunk * HUF_DCLS_COUNT * sizeof(u32), 256);
+    u32* counts = (u32*)p;
     for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
         const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
         const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
         const BlockView ds = mkview(nullptr, 0, d_dstSizes ? d_dstSizes + b0 : nullptr, uniformDstSize);
         HufDPrepArgs d;
         d.csrc = cs; d.dstSizes = ds; d.dst = (u8*)d_dst + b0 * dstStride; d.dstStride = dstStride;
-        d.dtables = dtables; d.dtStrideU32 = dtU32; d.meta = meta; d.results = d_results + b0; d.nBlocks = nb;
+        d.dtables = dtables; d.dtStrideU32 = dtU32; d.meta = meta; d.lists = lists; d.counts = counts; d.results = d_results + b0; d.nBlocks = nb;
         CK(launch_huf_dprep(d, s));
         HufDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstSizes = ds; e.results = d_results + b0;
         e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
         e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.nBlocks = nb;
-        CK(launch_huf_decode(e, s));
+        CK(launch_huf_decode_classes(e, lists, counts, s));
     }
     return 0;
 }

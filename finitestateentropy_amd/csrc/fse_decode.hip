@@ -25,7 +25,8 @@
 #include "bitreader.h"
 
 // Two bulk loops share the kernel:
-//   * fse_bulk_phase_rev (k_fse_decode<true>): tables from k_fse_dbuild with maxTableLog <= 11, bit-reversed layout --
+//   * fse_bulk_phase_rev (k_fse_decode<true>): tables from k_fse_dbuild in the bit-reversed layout (tableLog <= 11, or 12 when no
+//     cell has nbBits == 0: the classes of internal.h, each launched over its own list of blocks) --
 //     the one the one-shot decompressor uses; described at the function;
 //   * fse_bulk_phase (k_fse_decode<false>): caller-built reference-layout DTables (staged as A[x] = newState (12 bits) |
 //     nbBits << 12) and maxTableLog 12.  FSE_buildDTable makes the low nbBits of newState zero
@@ -122,7 +123,7 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
     sMine = s; qRef = q; bqRef = bq;
 }
 
-// ---- bit-reversed bulk loop (maxTableLog <= 11, tables from k_fse_dbuild) ----------------------------------------
+// ---- bit-reversed bulk loop (tables from k_fse_dbuild) -------------------------------------------------------------
 // A lone wave is bound by the number of instructions it issues (about one per 7 cycles), so this variant is laid out to
 // need as few as possible: 6 VALU per symbol and 11 per iteration for the bit cursor.
 //   * The input ring holds the stream in CONSUMPTION order: ring dword m = bit-reversed payload dword (Stop/4 - 1 - m)
@@ -131,9 +132,11 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
 //     low end -- v_bfe_u32(window, offset, nbBits) with the offset and width operands used as they come (the hardware
 //     reads their low 5 bits), no per-iteration select of window registers, no special case for nbBits == 0.
 //   * Taking bits low-end-first yields them bit-reversed, so the table is stored bit-reversed too: the cell of state x
-//     sits at index rev(x), and holds nbBits (low 5 bits) | rev(newState) << (16 - maxTableLog).  newState is a
+//     sits at index rev(x), and holds nbBits (low 5 bits) | rev(newState) << 5 (11 bits: rev(newState) < 2048 because tableLog <= 11,
+//     or tableLog is 12 and newState is even -- every nbBits >= 1 -- which is what the 8 KiB class requires).  newState is a
 //     multiple of 1 << nbBits (lib/fse_decompress.c:121-122), hence rev(newState + bits) = rev(newState) | rev_nb(bits) << (tableLog - nbBits):
-//     next address = tableBase | cell >> (15 - maxTableLog) | bits << (tableLog + 1 - nbBits)   (v_lshrrev, v_or, v_sub, v_lshl_or).
+//     next address = tableBase | cell >> 4 | bits << (tableLog + 1 - nbBits)   (v_lshrrev, v_or, v_sub, v_lshl_or; bit 0 of cell >> 4
+//     is bit 4 of nbBits = 0).
 //   * Lane B's bits follow lane A's: its offset is lane A's nbBits, fetched and masked by one v_and_b32_dpp
 //     (maskB = 31 in lane B, 0 in lane A); the pair's bit count is one v_add_u32_dpp.
 // One iteration = 2 symbols per lane = at most 44 bits out of the 64+ bits {d2:d1:d0} >> (P & 31) read at its top.
@@ -182,7 +185,6 @@ struct DecCtl {
     u32 pad[4];
 };
 #define FSE_DEC_THREADS (64 * (1 + FSE_SRV_WAVES))     // wave 0 decodes, the others serve
-#define FSE_CTL_BYTES (FSE_MAXG * (u32)sizeof(DecCtl))
 
 DEV u32 ctl_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -214,7 +216,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 {
     const u32 symShift = a.atab ? 0u : 2u;
     const int myG = g0 + (lane < FSE_SRV_G ? lane : 0);      // lane l of this wave keeps the books of block g0 + l
-    DecCtl* const ctl = ctlAll + myG;
+    DecCtl* const ctl = ctlAll + (myG < a.G ? myG : 0);        // (the control area holds G entries)
     // per-block constants live in the registers of lane l of this wave
     const unsigned long long inBits = ((unsigned long long)ctl->inHi << 32) | ctl->inLo;
     const unsigned long long outBits = ((unsigned long long)ctl->outHi << 32) | ctl->outLo;
@@ -289,9 +291,9 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
                 const u32 ri = (fl_g + lane) & (FSE_DEC_RING - 1);
                 const u32* const rw = (const u32*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff) + 4u * (ri >> 1) + (ri & 1u);
                 uint2 rec; rec.x = rw[0]; rec.y = rw[2];      // x: state 1 before symbols 0 / 2, y: state 2 before symbols 1 / 3
-                // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+maxTableLog)
-                const u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.maxTableLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.maxTableLog);
-                const u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.maxTableLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.maxTableLog);
+                // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+ldsLog)
+                const u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.ldsLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.ldsLog);
+                const u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.ldsLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.ldsLog);
                 yq[l][0] = tg[x0 << symShift]; yq[l][2] = tg[x1 << symShift]; yq[l][1] = tg[x2 << symShift]; yq[l][3] = tg[x3 << symShift];
             }
         }
@@ -321,7 +323,7 @@ struct FseCellsRef { const u32* cells;
     DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = cells[st]; ns = c & 0xFFFFu; sym = (c >> 16) & 0xFFu; nb = c >> 24; } };
 struct FseCellsCompact { const u16* A; const u8* syms;
     DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 c = A[st]; ns = c & 0xFFFu; nb = c >> 12; sym = syms[st]; } };
-struct FseCellsRev { const u16* A; const u8* syms; u32 tl, cellShift;       // bit-reversed tables (see fse_bulk_phase_rev): cell shift = 16 - maxTableLog
+struct FseCellsRev { const u16* A; const u8* syms; u32 tl, cellShift;       // bit-reversed tables (see fse_bulk_phase_rev): cell shift = 5
     DEV void get(u32 st, u32& ns, u32& nb, u32& sym) const { const u32 i = __brev(st) >> (32u - tl); const u32 c = A[i]; nb = c & 31u; ns = __brev(c >> cellShift) >> (32u - tl); sym = syms[i]; } };
 template <class Cells>
 DEV u32 fse_tail_step(const Cells& t, u32& state, BitReader& r, bool fast)          // FSE_decodeSymbol(Fast), fse.h:600-622
@@ -355,18 +357,21 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
     }
 }
 
-// LDS: G tables A[2^maxTableLog] (u16) on table-size aligned addresses | DecCtl[FSE_MAXG] | per block: state ring
+// LDS: G tables A[2^ldsLog] (u16) on table-size aligned addresses | DecCtl[G] | per block: state ring
 // (64 x 8 B), input ring (256 + 16 B)
 template <bool FAST>
 __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // slot g of this workgroup = entry first + g of the launch's block list (or simply block first + g)
     const size_t first = (size_t)blockIdx.x * a.G;
+    const size_t nTot = a.count ? (size_t)*a.count : a.nBlocks;
+    if (first >= nTot) return;                                   // uniform: the grid is sized for the worst case
     u8* const lds8 = (u8*)lds;
-    const u32 tabStride = 2u << a.maxTableLog;                   // bytes per table
+    const u32 tabStride = 2u << a.ldsLog;                        // bytes per LDS table slot
     DecCtl* const ctlAll = (DecCtl*)(lds8 + (size_t)a.G * tabStride);
-    u8* const ldsb = (u8*)ctlAll + FSE_CTL_BYTES;                // ring area: one slot of slotBytes per block
+    u8* const ldsb = (u8*)ctlAll + (size_t)a.G * sizeof(DecCtl); // ring area: one slot of slotBytes per block
     const u32 slotBytes = a.slotU32 * 4u;                        // multiple of 8
     const u32 ringOff = 0;                                       // state ring offset inside a slot
     const u32 inOff = FSE_DEC_RING * 8;                          // input ring offset inside a slot
@@ -379,29 +384,37 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     __syncthreads();
     {   u32 badBits = 0; bool anyNb0 = false;
         if (a.atab) {
-            // k_fse_dbuild output: already in the LDS format, one slot of tabStride bytes per block both in global memory and
-            // in LDS, so the tables of this workgroup are one contiguous copy.  Every load is issued before the first store
-            // (a lone copy loop would pay the memory latency once per table).
-            const size_t nTab = a.nBlocks - first < (size_t)a.G ? a.nBlocks - first : (size_t)a.G;
-            const uint4* const srcv = (const uint4*)(a.atab + (first << a.maxTableLog));
+            // k_fse_dbuild output: already in the LDS format; the first tabStride bytes of every block's global table slot are
+            // its LDS image.  Every load is issued before the first store (a lone copy loop would pay the memory latency once
+            // per table).
+            const size_t nTab = nTot - first < (size_t)a.G ? nTot - first : (size_t)a.G;
             uint4* const dstv = (uint4*)lds8;
-            const u32 nvec = (u32)nTab * (tabStride / 16u);
+            const u32 vptLog = a.ldsLog - 3u;                            // 16-byte vectors per table: tabStride / 16
+            const u32 nvec = (u32)nTab << vptLog;
             constexpr u32 MAXV = (80u * 1024u / 16u + FSE_DEC_THREADS - 1) / FSE_DEC_THREADS;
             uint4 buf[MAXV];
 #pragma unroll
-            for (u32 k = 0; k < MAXV; ++k) { const u32 idx = tid + k * FSE_DEC_THREADS; if (idx < nvec) buf[k] = srcv[idx]; }
+            for (u32 k = 0; k < MAXV; ++k) {
+                const u32 idx = tid + k * FSE_DEC_THREADS;
+                if (idx < nvec) {
+                    const size_t sl = first + (idx >> vptLog);
+                    const size_t bi = a.list ? (size_t)a.list[sl] : sl;
+                    buf[k] = ((const uint4*)(a.atab + (bi << a.maxTableLog)))[idx & ((1u << vptLog) - 1u)];
+                }
+            }
 #pragma unroll
             for (u32 k = 0; k < MAXV; ++k) { const u32 idx = tid + k * FSE_DEC_THREADS; if (idx < nvec) dstv[idx] = buf[k]; }
-            for (size_t g = 0; g < nTab; ++g) { const u32 st = a.meta[first + g].state; anyNb0 |= st != 0 && !(st & 2u); }   // a cell with nbBits == 0 needs a counter > tableSize/2
+            if (!FAST) for (size_t g = 0; g < nTab; ++g) {                 // a cell with nbBits == 0 needs a counter > tableSize/2
+                const u32 st = a.meta[a.list ? (size_t)a.list[first + g] : first + g].state; anyNb0 |= st != 0 && !(st & 2u); }
         }
         else for (int g = 0; g < a.G; ++g) {
-            const size_t b = first + g;
-            if (b >= a.nBlocks) break;
+            if (first + g >= nTot) break;
+            const size_t b = a.list ? (size_t)a.list[first + g] : first + g;
             if (a.meta && a.meta[b].state == 0) continue;
             if (FAST) __builtin_trap();                          // the bit-reversed loop takes k_fse_dbuild tables only (launch_fse_decode)
             const u32* t = a.dtables + b * a.dtStrideU32;
             const u32 tl = t[0] & 0xFFFFu;
-            if (tl > a.maxTableLog) continue;
+            if (tl > a.ldsLog) continue;
             const u32 ts = 1u << tl;
             u16* A = (u16*)(lds8 + (size_t)g * tabStride);
             bool bad = false;
@@ -425,8 +438,9 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     //      (identical values in both; only the even lane publishes, finishes the block and writes its result)
     const int gsl = lane >> 1;
     const u32 half = (u32)lane & 1u, maskB = half ? ~0u : 0u;
-    const size_t b = first + (size_t)gsl;
-    bool owner = wave == 0 && gsl < a.G && b < a.nBlocks;
+    const bool inRange = gsl < a.G && first + (size_t)gsl < nTot;
+    const size_t b = inRange ? (a.list ? (size_t)a.list[first + gsl] : first + (size_t)gsl) : 0;
+    bool owner = wave == 0 && inRange;
     u32 hdr = 0;
     if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
     u32 tl = 0; bool fast = false;
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     if (owner) {
         if (compact) { tl = a.meta[b].tableLog; fast = (a.meta[b].state & 2u) != 0; }
         else { const u32 h0 = gtab[0]; tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0; }
-        if (tl > a.maxTableLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; }
+        if (tl > a.ldsLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; }
     }
     const u32* const cells = compact ? nullptr : gtab + 1;      // literal path: reference cells, or the LDS cells + symbol table
     const u8* const syms = compact ? a.symtab + ((owner ? b : 0) << a.maxTableLog) : (const u8*)cells + 2;
@@ -493,8 +507,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         const int c0 = (int)((0 - ((uintptr_t)in - inA)) & (FSE_IN_CHUNK - 1));
         validLo = (((int)bs.q + 8 - 112 - c0) & ~(FSE_IN_CHUNK - 1)) + c0;   // the ring then reaches from below q - 104 up to above q + 12
     }
-    DecCtl* const ctl = ctlAll + (gsl < FSE_MAXG ? gsl : 0);
-    if (wave == 0 && gsl < FSE_MAXG && half == 0) {
+    DecCtl* const ctl = ctlAll + (gsl < a.G ? gsl : 0);
+    if (wave == 0 && gsl < a.G && half == 0) {
         ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S + inA : 0);
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         if (ready) {
             uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
             if (FAST) {
-                fse_bulk_phase_rev(bs.s, P, tl + 1u, 15u - a.maxTableLog, tabOff, myIn, maskB & 31u, ring);
+                fse_bulk_phase_rev(bs.s, P, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
                 const u32 B = R8 - P;
                 bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
             }
@@ -554,16 +568,16 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
     size_t result;
-    if (FAST)         result = fse_tail(FseCellsRev{A, syms, tl, 16u - a.maxTableLog}, s1, s2, r, out, op, omax, fast);
+    if (FAST)         result = fse_tail(FseCellsRev{A, syms, tl, 5u}, s1, s2, r, out, op, omax, fast);
     else if (compact) result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
     else         result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
 }
 
-static void fse_decode_geometry(unsigned maxTableLog, size_t ldsBytes, unsigned* slotU32, int* G)
+static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
     *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
-    int g = (int)((ldsBytes - FSE_CTL_BYTES) / ((2u << maxTableLog) + *slotU32 * 4));
+    int g = (int)(ldsBytes / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));
     if (g > FSE_MAXG) g = FSE_MAXG;
     *G = g;
 }
@@ -571,25 +585,50 @@ static void fse_decode_geometry(unsigned maxTableLog, size_t ldsBytes, unsigned*
 size_t fse_decode_blocks_per_round(unsigned maxTableLog)
 {
     unsigned slot; int G;
-    fse_decode_geometry(maxTableLog, FSE_DEC_LDS, &slot, &G);
+    fse_decode_geometry(maxTableLog < FSE_DEC_FAST_MAXLOG ? maxTableLog : FSE_DEC_FAST_MAXLOG, FSE_DEC_LDS, &slot, &G);   // the common class
     const int cus = dev_props().ok ? dev_props().cus : 256;
     return (size_t)G * 2 * cus;
 }
 
-hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
+static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
 {
-    if (a.nBlocks == 0) return hipSuccess;
     const size_t ldsBytes = FSE_DEC_LDS;
     {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true>, (int)ldsBytes);
         if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false>, (int)ldsBytes);
         if (e != hipSuccess) return e;
     }
-    fse_decode_geometry(a.maxTableLog, ldsBytes, &a.slotU32, &a.G);
+    fse_decode_geometry(a.ldsLog, ldsBytes, &a.slotU32, &a.G);
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
-    probe_before(PK_FSE_DECODE, s);
-    if (a.atab && a.maxTableLog <= FSE_DEC_FAST_MAXLOG) hipLaunchKernelGGL(k_fse_decode<true>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
-    else hipLaunchKernelGGL(k_fse_decode<false>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
-    probe_after(PK_FSE_DECODE, s);
+    if (rev) hipLaunchKernelGGL(k_fse_decode<true>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    else     hipLaunchKernelGGL(k_fse_decode<false>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     return hipGetLastError();
+}
+
+// caller-built reference-layout DTables (FSE_decompress_usingDTable over a batch): staged as plain cells
+hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    a.ldsLog = a.maxTableLog; a.list = nullptr; a.count = nullptr;
+    probe_before(PK_FSE_DECODE, s);
+    const hipError_t e = fse_decode_launch(a, false, s);
+    probe_after(PK_FSE_DECODE, s);
+    return e;
+}
+
+// one-shot path: the tables come from k_fse_dbuild in the decoder's own formats, one launch per class (internal.h); a class
+// nobody belongs to costs a launch of workgroups that return at once
+hipError_t launch_fse_decode_classes(FseDecArgs a, const u32* lists, const u32* counts, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    probe_before(PK_FSE_DECODE, s);
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < FSE_DCLS_COUNT && e == hipSuccess; ++c) {
+        if (c != FSE_DCLS_REV11 && a.maxTableLog <= FSE_DEC_FAST_MAXLOG) break;      // those classes need tableLog 12
+        a.list = lists + (size_t)c * a.nBlocks; a.count = counts + c;
+        a.ldsLog = c == FSE_DCLS_REV11 ? (a.maxTableLog < FSE_DEC_FAST_MAXLOG ? a.maxTableLog : FSE_DEC_FAST_MAXLOG) : a.maxTableLog;
+        e = fse_decode_launch(a, c != FSE_DCLS_PLAIN, s);
+    }
+    probe_after(PK_FSE_DECODE, s);
+    return e;
 }

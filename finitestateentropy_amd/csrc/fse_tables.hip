@@ -109,43 +109,73 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
 __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
 {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.nBlocks) return;
-    FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
-    const u8* const in = view_ptr(a.csrc, b);
-    const size_t cSize = view_size(a.csrc, b);
-    size_t result = 0;
-    do {
-        u32 tl = 0, maxSV = 255;
-        const size_t h = fse_read_ncount(a.norms + b * 256, &maxSV, &tl, in, cSize);    // fse_decompress.c:264
-        if (is_err(h)) { result = h; break; }
-        if (tl > a.maxLog) { result = FERR(tableLog_tooLarge); break; }    // :266
-        m.state = 1; m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
-    } while (0);
-    a.meta[b] = m;
-    if (m.state == 0) a.results[b] = result;
+    const u32 lane = threadIdx.x;
+    int cls = -1;                                                          // decoder class of my block (-1: none / finished here)
+    if (b < a.nBlocks) {
+        FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+        const u8* const in = view_ptr(a.csrc, b);
+        const size_t cSize = view_size(a.csrc, b);
+        size_t result = 0;
+        do {
+            u32 tl = 0, maxSV = 255;
+            s16* const norm = a.norms + b * 256;
+            const size_t h = fse_read_ncount(norm, &maxSV, &tl, in, cSize);    // fse_decompress.c:264
+            if (is_err(h)) { result = h; break; }
+            if (tl > a.maxLog) { result = FERR(tableLog_tooLarge); break; }    // :266
+            // class by the block's own tableLog (internal.h); a counter above half the table makes cells with nbBits == 0
+            cls = FSE_DCLS_REV11;
+            if (tl > FSE_DEC_FAST_MAXLOG) {
+                int top = 0;
+                for (u32 s = 0; s <= maxSV; ++s) top = norm[s] > top ? norm[s] : top;
+                cls = 2 * top > (1 << tl) ? FSE_DCLS_PLAIN : FSE_DCLS_REV12;
+            }
+            m.state = 1u | ((u32)cls << 2); m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
+        } while (0);
+        a.meta[b] = m;
+        if (m.state == 0) a.results[b] = result;
+    }
+    // append my block to its class list: one atomic per class and wave
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 0; c < FSE_DCLS_COUNT; ++c) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (!mask) continue;                                               // uniform
+        const int leader = __builtin_ctzll(mask);
+        u32 base = 0;
+        if ((int)lane == leader) base = atomicAdd(&a.counts[c], (u32)__builtin_popcountll(mask));
+        base = (u32)__shfl((int)base, leader, WAVE);
+        if (cls == c) a.lists[(size_t)c * a.nBlocks + base + (u32)__builtin_popcountll(mask & below)] = (u32)b;
+    }
 }
 
-__global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
+// Workgroup w builds the w-th block of the class lists [firstList, firstList + nLists) taken one after the other (the lists sit
+// `nBlocks` entries apart; their lengths are device-side, so the grid is sized for the worst case and the surplus exits).
+__global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs, int firstList, int nLists, u32 ldsCapTs)
 {
     extern __shared__ __attribute__((aligned(16))) u8 wbLds[];
-    const size_t b = blockIdx.x;
+    u32 idx = blockIdx.x;
+    int c = firstList;
+    for (; c < firstList + nLists; ++c) { const u32 n = a.counts[c]; if (idx < n) break; idx -= n; }
+    if (c == firstList + nLists) return;                                   // uniform: beyond the last list
+    const size_t b = a.lists[(size_t)c * a.nBlocks + idx];
     const u32 lane = threadIdx.x;
     const FseMeta m = a.meta[b];
     if (m.state == 0) return;                                              // uniform
-    const WaveBuildLds w = wave_build_carve(wbLds, capTs);
+    const WaveBuildLds w = wave_build_carve(wbLds, ldsCapTs);
     *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
     __syncthreads();
     const u32 tl = m.tableLog, ts = 1u << tl;
-    const bool rev = a.maxLog <= FSE_DEC_FAST_MAXLOG;                      // uniform
+    const bool rev = ((m.state >> 2) & 3u) != FSE_DCLS_PLAIN;              // uniform
     const bool fast = wave_spread_rank(w, m.maxSV, tl, lane, [&](u32 s) { return (u32)(int)w.nrm[s]; }, [&](u32 u, u32 s, u32 r, u32 nrm) {
         (void)s;
         const int n = (int)nrm;
         const u32 next = (n > 0 ? (u32)n : 1u) + r;                        // symbolNext[s]++, fse_decompress.c:117-122
         const u32 nb = tl - hibit32(next);
         const u32 ns = (next << nb) - ts;
-        // bit-reversed format (see fse_decode.hip): nbBits | rev_tl(newState) << (16 - maxLog); the cell of state u goes
-        // to position rev_tl(u), which the copy-out below takes care of
-        if (rev) w.cell[wb_ci(u)] = (u16)(nb | ((__brev(ns) >> (32u - tl)) << (16u - a.maxLog)));
+        // bit-reversed format (see fse_decode.hip): nbBits | rev_tl(newState) << 5 (rev_tl(newState) < 2048: tableLog <= 11, or
+        // tableLog 12 with nbBits >= 1, i.e. newState even); the cell of state u goes to position rev_tl(u), which the copy-out
+        // below takes care of
+        if (rev) w.cell[wb_ci(u)] = (u16)(nb | ((__brev(ns) >> (32u - tl)) << 5));
         else     w.cell[wb_ci(u)] = (u16)((ns & 0xFFFu) | (nb << 12));
     });
     u32* const A32 = (u32*)(a.atab + b * capTs);
@@ -163,7 +193,7 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs)
         for (u32 i = lane; i < ts / 2; i += 64) A32[i] = *(const u32*)(w.cell + wb_ci(2u * i));
         for (u32 i = lane; i < ts / 4; i += 64) S32[i] = *(const u32*)(w.symTab + wb_si(4u * i));
     }
-    if (lane == 0) a.meta[b].state = 1u | (fast ? 2u : 0u);
+    if (lane == 0) a.meta[b].state = m.state | (fast ? 2u : 0u);
 }
 
 #ifdef FSE_WB_TIMING
@@ -184,10 +214,16 @@ hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     const u32 capTs = 1u << a.maxLog;
-    const size_t ldsBytes = wave_build_lds_bytes(capTs);
+    hipError_t e = hipMemsetAsync(a.counts, 0, FSE_DCLS_COUNT * sizeof(u32), s);
+    if (e != hipSuccess) return e;
     probe_before(PK_FSE_DPREP, s);
     hipLaunchKernelGGL(k_fse_dparse, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
+    // the builds are latency-bound single-wave workgroups: their LDS footprint (sized by the largest table of the launch)
+    // decides how many run per CU, so the tableLog <= 11 class gets a launch of its own
+    const u32 capA = a.maxLog < FSE_DEC_FAST_MAXLOG ? capTs : (1u << FSE_DEC_FAST_MAXLOG);
+    hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capA), s, a, capTs, (int)FSE_DCLS_REV11, 1, capA);
+    if (a.maxLog > FSE_DEC_FAST_MAXLOG)
+        hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capTs), s, a, capTs, (int)FSE_DCLS_REV12, 2, capTs);
     probe_after(PK_FSE_DPREP, s);
     return hipGetLastError();
 }

@@ -32,7 +32,7 @@
 #define HD_SRV_WAVES 4
 #define HD_SRV_S (4 * HD_MAXG / HD_SRV_WAVES)       // streams per service wave
 #define HD_THREADS (64 * (1 + HD_SRV_WAVES))
-#define HD_SLOT_LOG 11u          // tables up to this tableLog live in LDS; larger ones are decoded by the literal path
+#define HD_SLOT_LOG 11u          // LDS table slots hold 1 << 11 cells (4 KiB) for the common class, 1 << 12 for tableLog-12 blocks
 
 #ifdef HD_TIMING             // development aid: decoder-wave cycle accounting (phases run / polls waited)
 __device__ unsigned long long g_hdTiming[4096 * 4];
@@ -228,14 +228,17 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
     }
 }
 
-// LDS: G tables (2-byte cells, 1 << HD_SLOT_LOG of them) | HdCtl[4 * HD_MAXG] | per stream: input ring (256 + 8 B), output ring (32 x 4 B)
+// LDS: G tables (2-byte cells, 1 << ldsLog of them) | HdCtl[4 * HD_MAXG] | per stream: input ring (256 + 8 B), output ring (32 x 4 B)
 __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // slot g of this workgroup = entry first + g of the launch's block list (or simply block first + g)
     const size_t first = (size_t)blockIdx.x * a.G;
+    const size_t nTot = a.count ? (size_t)*a.count : a.nBlocks;
+    if (first >= nTot) return;                                   // uniform: the grid is sized for the worst case
     u8* const lds8 = (u8*)lds;
-    const u32 tabStride = 2u << HD_SLOT_LOG;
+    const u32 tabStride = 2u << a.ldsLog;
     HdCtl* const ctlAll = (HdCtl*)(lds8 + (size_t)a.G * tabStride);
     u8* const aux = (u8*)ctlAll + (((size_t)4 * a.G * sizeof(HdCtl) + 15) & ~(size_t)15);
     const int nStreams = 4 * a.G;
@@ -243,13 +246,13 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     // ---- stage the X1 tables: reference cells {byte, nbBits} -> bit-reversed order, {nbBits, byte} (uniform control flow, all waves).
     //      Tables that do not fit the slot (tableLog 12) stay in global memory and are decoded by the literal path.
     for (int g = 0; g < a.G; ++g) {
-        const size_t b = first + g;
-        if (b >= a.nBlocks) break;
+        if (first + g >= nTot) break;
+        const size_t b = a.list ? (size_t)a.list[first + g] : first + g;
         if (a.meta && a.meta[b].state == 0) continue;
         const u32* t = a.dtables + b * a.dtStrideU32;
         const u32 desc = t[0];
         const u32 tl = (desc >> 16) & 0xFFu;
-        if (tl > a.maxTableLog || tl > HD_SLOT_LOG || tl < 1 || ((desc >> 8) & 0xFFu) != 0) continue;
+        if (tl > a.maxTableLog || tl > a.ldsLog || tl < 1 || ((desc >> 8) & 0xFFu) != 0) continue;
         const u32 words = 1u << (tl - 1);                        // two cells per word
         u16* s = (u16*)(lds8 + (size_t)g * tabStride);
         for (u32 i = tid; i < words; i += HD_THREADS) {
@@ -263,8 +266,9 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
 
     // ---- per-stream set-up by the decoder wave: lane 4g+k = stream k of block first+g
     const u32 g = (u32)lane >> 2, k = (u32)lane & 3u;
-    const size_t b = first + g;
-    const bool live = wave == 0 && (int)g < a.G && b < a.nBlocks && !(a.meta && a.meta[b].state == 0);
+    const bool inRange = (int)g < a.G && first + g < nTot;
+    const size_t b = inRange ? (a.list ? (size_t)a.list[first + g] : first + g) : 0;
+    const bool live = wave == 0 && inRange && !(a.meta && a.meta[b].state == 0);
 
     size_t ierr = 0;                                 // BIT_initDStream error of my stream (0 = none)
     size_t blockErr = 0;                             // errors detected before any stream is touched
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         }
     }
     // bulk: iterations whose reload is certainly the fast one; 4 symbols each, all inside the stream's output range
-    const bool inLds = dtLog >= 1 && dtLog <= HD_SLOT_LOG;
+    const bool inLds = dtLog >= 1 && dtLog <= a.ldsLog;
     bool can = streamOk && inLds && r.at >= 24 + 6 * HD_PHASE + 8 && cnt / 4 >= HD_PHASE && r.size < (1ull << 31)
                && oStart + (size_t)cnt <= dstSize;      // (degenerate tiny blocks whose segments overhang go bytewise)
     struct { u32 q, bq; } bs; bs.q = 0; bs.bq = 0;      // the reference-order view of the cursor: q = 4*(unread bits >> 5) - 8, bq = unread bits & 31
@@ -396,23 +400,48 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     }
 }
 
-static int huf_decode_G(size_t ldsBytes)
+static int huf_decode_G(size_t ldsBytes, unsigned ldsLog)
 {
-    const size_t perBlock = (2u << HD_SLOT_LOG) + 4 * (HD_STREAM_AUX + sizeof(HdCtl));
+    const size_t perBlock = (2u << ldsLog) + 4 * (HD_STREAM_AUX + sizeof(HdCtl));
     int g = (int)((ldsBytes - 16) / perBlock);
     return g > HD_MAXG ? HD_MAXG : g;
 }
 
+static hipError_t huf_decode_launch(HufDecArgs a, hipStream_t s)
+{
+    const size_t ldsBytes = 80 * 1024;               // two workgroups per CU
+    {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_decode, (int)ldsBytes); if (e != hipSuccess) return e; }
+    a.G = huf_decode_G(ldsBytes, a.ldsLog);
+    a.slotU32 = 0;
+    const size_t groups = (a.nBlocks + a.G - 1) / a.G;
+    hipLaunchKernelGGL(k_huf_decode, dim3((unsigned)groups), dim3(HD_THREADS), ldsBytes, s, a);
+    return hipGetLastError();
+}
+
+// caller-built tables (HUF_decompress4X1_usingDTable over a batch): one launch, slots sized by the caller's maxTableLog
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const size_t ldsBytes = 80 * 1024;               // two workgroups per CU
-    {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_decode, (int)ldsBytes); if (e != hipSuccess) return e; }
-    a.G = huf_decode_G(ldsBytes);
-    a.slotU32 = 0;
-    const size_t groups = (a.nBlocks + a.G - 1) / a.G;
+    a.list = nullptr; a.count = nullptr;
+    a.ldsLog = a.maxTableLog > HD_SLOT_LOG ? FSEHIP_HUF_TABLELOG_MAX : HD_SLOT_LOG;
     probe_before(PK_HUF_DECODE, s);
-    hipLaunchKernelGGL(k_huf_decode, dim3((unsigned)groups), dim3(HD_THREADS), ldsBytes, s, a);
+    const hipError_t e = huf_decode_launch(a, s);
     probe_after(PK_HUF_DECODE, s);
-    return hipGetLastError();
+    return e;
+}
+
+// one-shot path: k_huf_dprep has sorted the blocks into two lists by their tableLog (<= 11: 4 KiB table slots, 14 blocks per
+// workgroup; 12: 8 KiB slots, 8 blocks per workgroup); one launch per list
+hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    probe_before(PK_HUF_DECODE, s);
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < HUF_DCLS_COUNT && e == hipSuccess; ++c) {
+        a.list = lists + (size_t)c * a.nBlocks; a.count = counts + c;
+        a.ldsLog = c == 0 ? HD_SLOT_LOG : FSEHIP_HUF_TABLELOG_MAX;
+        e = huf_decode_launch(a, s);
+    }
+    probe_after(PK_HUF_DECODE, s);
+    return e;
 }

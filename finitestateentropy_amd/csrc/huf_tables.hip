@@ -449,7 +449,9 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a, hnode_t* nodeS
 __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
 {
     const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.nBlocks) return;
+    const u32 lane = threadIdx.x;
+    int cls = -1;                                                           // decoder class of my block (-1: none / finished here)
+    if (b < a.nBlocks) {
     HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
     const u8* const in = view_ptr(a.csrc, b);
     const size_t cSize = view_size(a.csrc, b);
@@ -466,9 +468,23 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
         if (is_err(h)) { result = h; break; }
         if (h >= cSize) { result = FERR(srcSize_wrong); break; }
         m.state = 1; m.hdrSize = (u32)h; m.tableLog = (dt[0] >> 16) & 0xFF;
+        cls = m.tableLog > 11u ? 1 : 0;
     } while (0);
     a.meta[b] = m;
     if (m.state == 0) a.results[b] = result;
+    }
+    // append my block to its class list: one atomic per class and wave
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 0; c < HUF_DCLS_COUNT; ++c) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (!mask) continue;                                                // uniform
+        const int leader = __builtin_ctzll(mask);
+        u32 base = 0;
+        if ((int)lane == leader) base = atomicAdd(&a.counts[c], (u32)__builtin_popcountll(mask));
+        base = (u32)__shfl((int)base, leader, WAVE);
+        if (cls == c) a.lists[(size_t)c * a.nBlocks + base + (u32)__builtin_popcountll(mask & below)] = (u32)b;
+    }
 }
 
 hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* nodeScratch)
@@ -484,6 +500,7 @@ hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* nodeScra
 hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    {   const hipError_t e = hipMemsetAsync(a.counts, 0, HUF_DCLS_COUNT * sizeof(u32), s); if (e != hipSuccess) return e; }
     probe_before(PK_HUF_DPREP, s);
     hipLaunchKernelGGL(k_huf_dprep, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
     probe_after(PK_HUF_DPREP, s);

@@ -72,14 +72,23 @@ inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
     return launch_fse_encode(a, s);
 }
 
+// Decoder classes, chosen per block by k_fse_dparse from the block's own tableLog (the caller's maxLog only bounds it):
+//   FSE_DCLS_REV11 : tableLog <= 11            -> bit-reversed cells, 4 KiB of LDS per table   (the fast loop, 16 blocks / workgroup)
+//   FSE_DCLS_REV12 : tableLog 12, nbBits >= 1  -> bit-reversed cells, 8 KiB of LDS per table   (the fast loop,  9 blocks / workgroup)
+//   FSE_DCLS_PLAIN : tableLog 12 with a symbol owning more than half the table (some nbBits == 0: rev(newState) then needs 12 bits)
+//                    -> cells newState | nbBits << 12, the register-window loop
+// Each class has its own list of block indices (dense workgroups) and its own launch; see fse_decode.hip.
+enum { FSE_DCLS_REV11 = 0, FSE_DCLS_REV12 = 1, FSE_DCLS_PLAIN = 2, FSE_DCLS_COUNT = 3 };
 struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
     BlockView csrc;
     unsigned maxLog;
     // outputs, `capTs` = 1 << maxLog cells per block: the decoder's own table format (fse_decode.hip)
-    u16* atab;                   // maxLog <= FSE_DEC_FAST_MAXLOG: cell rev(x) = nbBits | rev(newState) << (16 - maxLog) (fse_decode.hip); else cell x = newState | nbBits << 12
+    u16* atab;                   // bit-reversed classes: cell rev(x) = nbBits | rev(newState) << 5; plain class: cell x = newState | nbBits << 12
     u8* symtab;                  // symbol of the cell at the same index
     s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
-    FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1
+    FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1 | class << 2
+    u32* lists;                  // FSE_DCLS_COUNT lists of block indices, `nBlocks` entries apart
+    u32* counts;                 // their lengths (zeroed by the launcher)
     size_t* results;
     size_t nBlocks;
 };
@@ -92,13 +101,18 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     const u32* dtables; size_t dtStrideU32;   // reference-layout tables (usingDTable batch), or nullptr:
     const u16* atab; const u8* symtab;        // tables in the decoder's own format from k_fse_dbuild, 1 << maxTableLog cells per block
     const FseMeta* meta;         // nullptr for the plain usingDTable batch
-    unsigned maxTableLog;
+    unsigned maxTableLog;        // global table slots hold 1 << maxTableLog cells
+    unsigned ldsLog;             // LDS table slots hold 1 << ldsLog cells (set by the launcher from the class)
+    const u32* list;             // block indices of this launch's class and their number (device memory), or nullptr: all blocks
+    const u32* count;
     int G;
     unsigned slotU32;
     size_t nBlocks;
 };
-#define FSE_DEC_FAST_MAXLOG 11u   // up to this maxTableLog the decoder's cells hold 2*newState (see fse_decode.hip)
+#define FSE_DEC_FAST_MAXLOG 11u   // largest tableLog of the 4 KiB class
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s);
+// one-shot path: one launch per decoder class over the lists written by k_fse_dparse
+hipError_t launch_fse_decode_classes(FseDecArgs a, const u32* lists, const u32* counts, hipStream_t s);
 size_t fse_decode_blocks_per_round(unsigned maxTableLog);   // blocks that fill the device once (for chunk sizing)
 
 // ---- Huff0 ----------------------------------------------------------------------------------------
@@ -132,12 +146,15 @@ struct HufEncArgs {              // a4: HUF_compress4X_usingCTable (streams = 4)
 };
 hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s);
 
+enum { HUF_DCLS_COUNT = 2 };      // decoder classes by tableLog: 0 = up to 11 (4 KiB LDS table slots), 1 = 12 (8 KiB)
 struct HufDPrepArgs {            // glue g6: HUF_readStats + HUF_readDTableX1 (+ raw / RLE decisions of HUF_decompress)
     BlockView csrc;
     BlockView dstSizes;          // only sizes/uniform used
     u8* dst; size_t dstStride;
     u32* dtables; size_t dtStrideU32;
     HufMeta* meta;
+    u32* lists;                  // HUF_DCLS_COUNT lists of block indices, `nBlocks` entries apart, and their lengths (zeroed by the launcher)
+    u32* counts;
     size_t* results;
     size_t nBlocks;
 };
@@ -151,11 +168,15 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
     const u32* dtables; size_t dtStrideU32;
     const HufMeta* meta;
     unsigned maxTableLog;
+    unsigned ldsLog;             // LDS table slots hold 1 << ldsLog cells (set by the launcher)
+    const u32* list;             // block indices of this launch and their number (device memory), or nullptr: all blocks
+    const u32* count;
     int G; unsigned slotU32;
     int streams;                 // 4 (4X1) or 1 (1X1)
     size_t nBlocks;
 };
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
+hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, hipStream_t s);
 
 // ---- workload generator -----------------------------------------------------------------------------
 hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, u32 seedStep, hipStream_t s);
