@@ -298,8 +298,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     size_t* hres = (size_t*)carve(chunk * 8);
     FseMeta* meta = (FseMeta*)carve(chunk * sizeof(FseMeta));
     u32* ctables = (u32*)carve(chunk * 4 * w.ctU32);
-    s16* norms = (s16*)p;                                        // 512 bytes per block (w.ts >= 512)
-    if ((size_t)((u8*)norms + chunk * w.ts - (u8*)d_workspace) > workspaceBytes) {
+    if ((size_t)(p - (u8*)d_workspace) > workspaceBytes) {
         // alignment slack exhausted: shrink the chunk by one (WS_SLACK covers 5 x 256 of padding)
         return (int)hipErrorInvalidValue;
     }
@@ -315,7 +314,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
         c.counts = counts; c.maxSVs = maxSVs; c.histResults = hres; c.src = src;
         c.dst = (u8*)d_dst + b0 * dstStride; c.dstStride = dstStride; c.dstCapacity = dstCapacity;
         c.maxSVReq = msv; c.tableLogReq = tableLog;
-        c.ctables = ctables; c.ctStrideU32 = w.ctU32; c.maxTl = w.maxTl; c.norms = norms;
+        c.ctables = ctables; c.ctStrideU32 = w.ctU32; c.maxTl = w.maxTl;
         c.meta = meta; c.results = d_results + b0; c.nBlocks = nb;
         CK(launch_fse_cprep(c, s));
         FseEncArgs e;

@@ -7,75 +7,79 @@
 // reference's in-memory layout in global scratch; the hot-loop kernels stage them into LDS.
 #include "internal.h"
 
-#include "fse_glue.h"
+#include "wave_glue.h"
+#include "ncount_reader.h"
 #include "fse_wave_build.h"
 
 // ---------------------------------------------------------------------------------------------------
 //  prepare kernels
 // ---------------------------------------------------------------------------------------------------
-// Compress side, two kernels:
-//   k_fse_cnorm  : one lane per block -- the early outs of FSE_compress_wksp, FSE_optimalTableLog, FSE_normalizeCount
-//                  and FSE_writeNCount (serial by nature; lib/fse_compress.c:632-665); leaves the counters in scratch;
-//   k_fse_cbuild : one wave per block -- FSE_buildCTable_wksp (lib/fse_compress.c:66-169) with the wave-cooperative
-//                  spread / rank of fse_wave_build.h; the table is assembled in LDS in the reference layout and
-//                  written out with coalesced stores.
-__global__ __launch_bounds__(64) void k_fse_cnorm(FseCPrepArgs a)
-{
-    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.nBlocks) return;
-    FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
-    const size_t n = view_size(a.src, b);
-    size_t result = 0;
-    do {
-        if (n <= 1) { result = 0; break; }                                 // fse_compress.c:647
-        const size_t top = a.histResults[b];                               // :652-655
-        if (is_err(top)) { result = top; break; }
-        if (top == n) { result = 1; break; }
-        if (top == 1) { result = 0; break; }
-        if (top < (n >> 7)) { result = 0; break; }
-        const u32 maxSV = a.maxSVs[b];
-        const u32 tl = fse_optimal_tablelog(a.tableLogReq ? a.tableLogReq : FSE_DEF_TL, n, maxSV, 2);   // :649,658
-        s16* const norm = a.norms + b * 256;
-        const unsigned* count = a.counts + b * 256;
-        {   const size_t e = fse_normalize_count(norm, tl, count, n, maxSV);   // :659
-            if (is_err(e)) { result = e; break; }
-        }
-        u8* const dst = a.dst + b * a.dstStride;
-        const size_t h = fse_write_ncount(dst, a.dstCapacity, norm, maxSV, tl);   // :662
-        if (is_err(h)) { result = h; break; }
-        // Encoder choice.  The wave-per-block kernel (fse_encode_wave.hip) is the default; it needs every lane's share of
-        // the output to span at least one byte, which fails when one symbol takes (almost) the whole table: those blocks
-        // go to the lane-per-block kernel.  (The wave kernel re-checks exactly and hands further blocks over at run time.)
-        int top1 = 0;
-        for (u32 s = 0; s <= maxSV; ++s) top1 = norm[s] > top1 ? norm[s] : top1;
-        m.state = ((u32)top1 * 64u > (63u << tl)) ? FSE_ENC_LANE : FSE_ENC_PAR;
-        m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
-    } while (0);
-    a.meta[b] = m;
-    if (m.state == 0) a.results[b] = result;
-}
-
-__global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
+// Compress side: k_fse_cprep, one wave per block -- everything between the histogram and the hot loop
+// (lib/fse_compress.c:632-665): the early outs of FSE_compress_wksp, the table log, the normalised counters and the NCount
+// header (wave_glue.h: every symbol handled independently, totals by wave reductions, bit offsets by scans), then
+// FSE_buildCTable_wksp (lib/fse_compress.c:66-169) with the wave-cooperative spread / rank of fse_wave_build.h.  The counters
+// never leave the wave's registers / LDS; the header is assembled in LDS and copied out once.
+__global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a, u32 capTs)
 {
     extern __shared__ __attribute__((aligned(16))) u8 wbLds[];
     const size_t b = blockIdx.x;
     const u32 lane = threadIdx.x;
-    const FseMeta m = a.meta[b];
-    if (m.state == 0) return;                                              // uniform
+    const size_t n = view_size(a.src, b);
+    FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+    // early outs (fse_compress.c:647-655), uniform
+    const size_t top = a.histResults[b];
+    size_t result = 0; bool go = false;
+    if (n <= 1) result = 0;                                                // not compressible
+    else if (is_err(top)) result = top;
+    else if (top == n) result = 1;                                         // one symbol only: rle
+    else if (top == 1 || top < (n >> 7)) result = 0;                       // every symbol once / too flat to pay off
+    else go = true;
     const WaveBuildLds w = wave_build_carve(wbLds, capTs);
-    // The CTable is written straight to global memory: symbolTT entries coalesced, stateTable entries as scattered 2-byte
-    // stores inside the block's 4 KiB (the L2 merges them) -- an LDS image would cost 6 KiB per build, i.e. occupancy.
+    u32* const hdrImg = w.cnt;                                             // header image; the rank matrix is idle until the build
+    u32 maxSV = 0, tl = 0;
+    int nn[4] = { 0, 0, 0, 0 };
+    if (go) {
+        maxSV = a.maxSVs[b];
+        tl = wg_optimal_tablelog(a.tableLogReq, n, maxSV, 2);             // :649,658
+        const uint4 cv = ((const uint4*)(a.counts + b * 256))[lane];       // symbols 4*lane .. 4*lane+3
+        const u32 c[4] = { cv.x, cv.y, cv.z, cv.w };
+        for (u32 i = lane; i < 136; i += 64) hdrImg[i] = 0;
+        const size_t e = wg_normalize(nn, c, (u64)n, maxSV, tl, lane);     // :659
+        if (is_err(e)) { result = e; go = false; }
+    }
+    __syncthreads();
+    if (go) {
+        const size_t h = wg_write_ncount(hdrImg, a.dstCapacity, nn, maxSV, tl, lane);   // :662
+        if (is_err(h)) { result = h; go = false; }
+        else m.hdrSize = (u32)h;
+    }
+    __syncthreads();
+    if (!go) { if (lane == 0) { a.meta[b] = m; a.results[b] = result; } return; }          // uniform
+    {   u8* const dst = a.dst + b * a.dstStride;
+        const u8* const hb = (const u8*)hdrImg;
+        for (u32 i = lane; i < m.hdrSize; i += 64) dst[i] = hb[i];
+    }
+    // Encoder choice.  The wave-per-block kernel (fse_encode_wave.hip) is the default; it needs every lane's share of the
+    // output to span at least one byte, which fails when one symbol takes (almost) the whole table: those blocks go to the
+    // lane-per-block kernel.  (The wave kernel re-checks exactly and hands further blocks over at run time.)
+    int top1 = nn[0] > nn[1] ? nn[0] : nn[1]; top1 = nn[2] > top1 ? nn[2] : top1; top1 = nn[3] > top1 ? nn[3] : top1;
+    top1 = wave_max_i32(top1);
+    m.state = ((u32)top1 * 64u > (63u << tl)) ? FSE_ENC_LANE : FSE_ENC_PAR;
+    m.tableLog = tl; m.maxSV = maxSV;
+    if (lane == 0) a.meta[b] = m;
+    // ---- FSE_buildCTable: the table is written straight to global memory, symbolTT entries coalesced, stateTable entries as
+    // scattered 2-byte stores inside the block's 4 KiB (the L2 merges them) -- an LDS image would cost 6 KiB per build, i.e. occupancy.
     u32* const img = a.ctables + b * a.ctStrideU32;
     u16* const cumAll = w.cumP;                                            // [256] first stateTable slot of every symbol (the core leaves cumP to its caller)
-    *(uint2*)(w.nrm + 4 * lane) = *(const uint2*)(a.norms + b * 256 + 4 * lane);
+    *(uint2*)(w.nrm + 4 * lane) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
     __syncthreads();
-    const u32 tl = m.tableLog, ts = 1u << tl, maxSV = m.maxSV;
+    const u32 ts = 1u << tl;
     u16* const stateTable = (u16*)(img + 1);
     u32* const tt = img + 1 + (ts >> 1);                                   // tl >= FSE_MIN_TABLELOG here
     {   // per symbol (lane l: symbols 4l..4l+3): cumulative slot, symbolTT (fse_compress.c:136-166)
-        int n[4]; u32 eff[4], laneSum = 0;
+        u32 eff[4], laneSum = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const u32 s = 4 * lane + i; n[i] = s <= maxSV ? (int)w.nrm[s] : 0; eff[i] = n[i] == -1 ? 1u : (u32)n[i]; laneSum += eff[i]; }
+        for (int i = 0; i < 4; ++i) { eff[i] = nn[i] == -1 ? 1u : (u32)nn[i]; laneSum += eff[i]; }
         u32 total;
         u32 run = wb_scan_excl(laneSum, lane, &total);
 #pragma unroll
@@ -83,12 +87,12 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
             const u32 s = 4 * lane + i;
             cumAll[s] = (u16)run;
             if (s <= maxSV) {
-                if (n[i] == 0) { tt[2 * s] = 0; tt[2 * s + 1] = ((tl + 1) << 16) - ts; }
-                else if (n[i] == -1 || n[i] == 1) { tt[2 * s] = run - 1u; tt[2 * s + 1] = (tl << 16) - ts; }
+                if (nn[i] == 0) { tt[2 * s] = 0; tt[2 * s + 1] = ((tl + 1) << 16) - ts; }
+                else if (nn[i] == -1 || nn[i] == 1) { tt[2 * s] = run - 1u; tt[2 * s + 1] = (tl << 16) - ts; }
                 else {
-                    const u32 maxBitsOut = tl - hibit32((u32)n[i] - 1);
-                    tt[2 * s] = run - (u32)n[i];
-                    tt[2 * s + 1] = (maxBitsOut << 16) - ((u32)n[i] << maxBitsOut);
+                    const u32 maxBitsOut = tl - hibit32((u32)nn[i] - 1);
+                    tt[2 * s] = run - (u32)nn[i];
+                    tt[2 * s + 1] = (maxBitsOut << 16) - ((u32)nn[i] << maxBitsOut);
                 }
             }
             run += eff[i];
@@ -101,8 +105,9 @@ __global__ __launch_bounds__(64) void k_fse_cbuild(FseCPrepArgs a, u32 capTs)
 }
 
 // Decompress side, two kernels:
-//   k_fse_dparse : one lane per block -- FSE_readNCount (a serial bit parser, lib/entropy_common.c:41-144) and the
-//                  checks of FSE_decompress_wksp (lib/fse_decompress.c:264-269); leaves the counters in scratch;
+//   k_fse_dparse : one lane per block (the header is a serial variable-length code: ncount_reader.h) plus the checks of
+//                  FSE_decompress_wksp (lib/fse_decompress.c:264-269); sorts the blocks into the decoder classes of
+//                  internal.h and leaves the counters in scratch;
 //   k_fse_dbuild : one wave per block -- FSE_buildDTable (lib/fse_decompress.c:71-126) with the wave-cooperative
 //                  spread / rank of fse_wave_build.h, emitting the decoder's compact cell formats (u16 cell, symbol in
 //                  a separate byte table; bit-reversed layout when maxLog <= 11, see fse_decode.hip) with coalesced stores.
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
         do {
             u32 tl = 0, maxSV = 255;
             s16* const norm = a.norms + b * 256;
-            const size_t h = fse_read_ncount(norm, &maxSV, &tl, in, cSize);    // fse_decompress.c:264
+            const size_t h = ncount_read<1>(norm, &maxSV, &tl, in, cSize);     // fse_decompress.c:264
             if (is_err(h)) { result = h; break; }
             if (tl > a.maxLog) { result = FERR(tableLog_tooLarge); break; }    // :266
             // class by the block's own tableLog (internal.h); a counter above half the table makes cells with nbBits == 0
@@ -205,8 +210,7 @@ hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
     const u32 capTs = 1u << a.maxTl;
     const size_t ldsBytes = wave_build_lds_bytes(capTs);
     probe_before(PK_FSE_CPREP, s);
-    hipLaunchKernelGGL(k_fse_cnorm, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_fse_cbuild, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
+    hipLaunchKernelGGL(k_fse_cprep, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, capTs);
     probe_after(PK_FSE_CPREP, s);
     return hipGetLastError();
 }

@@ -32,7 +32,6 @@ struct FseCPrepArgs {            // glue g1-g4 (compress side): lib/fse_compress
     unsigned maxSVReq, tableLogReq;
     u32* ctables; size_t ctStrideU32;
     unsigned maxTl;              // largest tableLog FSE_optimalTableLog can pick for this request (sizes the tables)
-    s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
     FseMeta* meta;
     size_t* results;
     size_t nBlocks;

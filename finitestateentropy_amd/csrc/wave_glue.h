@@ -1,0 +1,279 @@
+// wave_glue.h -- the FSE "glue" between histogram and hot loop (SURVEY 8(a') rows g1-g2), one 64-lane wave per table:
+//   table-log selection, count normalisation (with its fallback) and the NCount header writer
+//   (behaviour of lib/fse_compress.c:316-342, :348-494, :186-298 -- restated, not transliterated).
+//
+// The reference walks the alphabet with loop-carried state (points still to distribute, best symbol so far, bit cursor of
+// the header).  Here lane l holds symbols 4l .. 4l+3 in registers and nothing is carried from symbol to symbol:
+//   * normalisation: every symbol is scaled independently; "points left" is a wave sum, "the first most probable symbol" a
+//     wave arg-max over (probability, -symbol) keys; the fallback classifies every symbol independently against two thresholds,
+//     gets its totals from wave sums and hands out the remaining points by prefix sums (the reference's running 62-bit
+//     accumulator is an exclusive scan of count * step; its round-robin top-up has the closed form quotient + (rank < rest));
+//   * header: the cost of a symbol depends only on the points still unassigned in front of it (an exclusive scan of |counter|):
+//     threshold = 2^floor(log2(remaining)), so each lane forms its symbols' (value, nbBits) chunks directly; a run of zero
+//     counters is coded by the lane holding its first zero (its length comes from a suffix-min scan of the non-zero
+//     positions); bit offsets are one more scan and the chunks are OR-ed into an LDS image of the header.
+// All functions are called by all 64 lanes of a wave with wave-uniform scalar arguments.
+#pragma once
+#include "dev_common.h"
+
+#define FSE_MIN_TL FSEHIP_FSE_MIN_TABLELOG
+#define FSE_MAX_TL FSEHIP_FSE_MAX_TABLELOG
+#define FSE_DEF_TL FSEHIP_FSE_DEFAULT_TABLELOG
+
+// ---- wave primitives ---------------------------------------------------------------------------------------------
+DEV u32 wg_sum(u32 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, WAVE);
+    return v;
+}
+DEV u64 wg_sum64(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (u64)__shfl_xor((unsigned long long)v, off, WAVE);
+    return v;
+}
+DEV u32 wg_max(u32 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o > v ? o : v; }
+    return v;
+}
+DEV u32 wg_min(u32 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o < v ? o : v; }
+    return v;
+}
+DEV u32 wg_scan_excl(u32 v, u32 lane)                      // exclusive prefix sum over the lanes
+{
+    u32 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    return incl - v;
+}
+DEV u64 wg_scan_excl64(u64 v, u32 lane)
+{
+    u64 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u64 o = (u64)__shfl_up((unsigned long long)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    return incl - v;
+}
+DEV u32 wg_suffix_min_excl(u32 v, u32 lane)                // min over the lanes above this one (0xFFFFFFFF for lane 63)
+{
+    u32 m = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_down((int)m, off, WAVE); if ((int)lane + off < 64) m = o < m ? o : m; }
+    const u32 up = (u32)__shfl_down((int)m, 1, WAVE);
+    return lane == 63 ? 0xFFFFFFFFu : up;
+}
+
+// ---- table log (lib/fse_compress.c:316-342): the largest log the source size supports, not above the request, not below what
+//      the alphabet needs
+DEV u32 wg_min_tablelog(size_t srcSize, u32 maxSV)
+{
+    const u32 bySize = hibit32((u32)srcSize) + 1, byAlphabet = hibit32(maxSV) + 2;
+    return bySize < byAlphabet ? bySize : byAlphabet;
+}
+DEV u32 wg_optimal_tablelog(u32 request, size_t srcSize, u32 maxSV, u32 minus)
+{
+    u32 tl = request ? request : FSE_DEF_TL;
+    const u32 bySrc = hibit32((u32)(srcSize - 1)) - minus;
+    tl = bySrc < tl ? bySrc : tl;
+    const u32 need = wg_min_tablelog(srcSize, maxSV);
+    tl = need > tl ? need : tl;
+    tl = tl < FSE_MIN_TL ? FSE_MIN_TL : tl;
+    return tl > FSE_MAX_TL ? FSE_MAX_TL : tl;
+}
+
+// ---- normalisation ---------------------------------------------------------------------------------------------------
+// c[i] = count of symbol 4*lane + i (zero beyond maxSV), total = their sum (>= 2, no symbol owns it all).  Leaves the
+// normalised counters in n[i] (-1 = "less than one point") and returns 0, or an error code.
+#define WG_PENDING (-2)
+DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, u32 lane)
+{
+    const u32 ts = 1u << tl;
+    const u32 tiny = (u32)(total >> tl);
+    u32 one = (u32)((total * 3) >> (tl + 1));
+    // every symbol on its own: absent / below one point / about one point / still pending
+    u32 given = 0; u64 taken = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool in = 4 * lane + i <= maxSV;
+        if (!in || c[i] == 0) n[i] = 0;
+        else if (c[i] <= tiny) { n[i] = -1; ++given; taken += c[i]; }
+        else if (c[i] <= one) { n[i] = 1; ++given; taken += c[i]; }
+        else n[i] = WG_PENDING;
+    }
+    given = wg_sum(given); total -= wg_sum64(taken);
+    u32 left = ts - given;
+    if (left == 0) return FERR(GENERIC);                      // (cannot happen once the table log covers the alphabet)
+    if (total / left > one) {                                  // the pending ones would round to zero: widen "about one point"
+        one = (u32)((total * 3) / ((u64)left * 2));
+        u32 g2 = 0; u64 t2 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (n[i] == WG_PENDING && c[i] <= one) { n[i] = 1; ++g2; t2 += c[i]; }
+        given += wg_sum(g2); total -= wg_sum64(t2);
+        left = ts - given;
+    }
+    if (given == maxSV + 1) {                                  // nothing pending: the first most frequent symbol takes the rest
+        u32 best = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) best = c[i] > best ? c[i] : best;
+        best = wg_max(best);
+        u32 who = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) if (c[i] == best && 4 * lane + i <= maxSV) who = 4 * lane + i;
+        who = wg_min(who);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4 * lane + i == who) n[i] += (int)left;
+        return 0;
+    }
+    if (total == 0) {                                          // the rest goes round robin over the one-point symbols:
+        u32 mine = 0;                                          // quotient each, one more for the first (rest) of them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine += n[i] > 0;
+        const u32 P = wg_sum(mine);
+        u32 rank = wg_scan_excl(mine, lane);
+        const u32 q = left / P, r = left % P;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (n[i] > 0) { n[i] += (int)(q + (rank < r)); ++rank; }
+        return 0;
+    }
+    // the pending symbols share `left` points in proportion to their counts: cumulative positions on a 2^(62-tl) grid
+    const u32 vlog = 62 - tl;
+    const u64 mid = ((u64)1 << (vlog - 1)) - 1;
+    const u64 rstep = ((((u64)1 << vlog) * left) + mid) / total;
+    u64 span = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (n[i] == WG_PENDING) span += (u64)c[i] * rstep;
+    u64 run = mid + wg_scan_excl64(span, lane);
+    bool starved = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (n[i] != WG_PENDING) continue;
+        const u64 end = run + (u64)c[i] * rstep;
+        const u32 w = (u32)(end >> vlog) - (u32)(run >> vlog);
+        starved |= w < 1;
+        n[i] = (int)(s16)w;
+        run = end;
+    }
+    return __any(starved) ? FERR(GENERIC) : 0;
+}
+
+DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, u32 lane)
+{
+    if (tl < FSE_MIN_TL) return FERR(GENERIC);
+    if (tl > FSE_MAX_TL) return FERR(tableLog_tooLarge);
+    if (tl < wg_min_tablelog((size_t)total, maxSV)) return FERR(GENERIC);
+    const u32 scale = 62 - tl;
+    const u64 step = ((u64)1 << 62) / total;
+    const u64 vstep = (u64)1 << (scale - 20);
+    const u32 tiny = (u32)(total >> tl);
+    // rounding thresholds of the small probabilities (lib/fse_compress.c:445), in units of vstep
+    const u32 beat[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    u32 used = 0, key = 0;                                     // key = probability << 8 | 255 - symbol: the arg-max prefers the lower symbol
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 s = 4 * lane + i;
+        if (s > maxSV || c[i] == 0) { n[i] = 0; continue; }
+        if (c[i] <= tiny) { n[i] = -1; ++used; continue; }
+        const u64 prod = (u64)c[i] * step;
+        u32 p = (u32)(prod >> scale) & 0xFFFFu;
+        if (p < 8) p += (prod - ((u64)p << scale)) > vstep * beat[p];
+        n[i] = (int)(s16)p;
+        used += p;
+        const u32 k = (p << 8) | (255u - s);
+        key = k > key ? k : key;
+    }
+    const int still = (int)(1u << tl) - (int)wg_sum(used);
+    key = wg_max(key);
+    const u32 largest = (key >> 8) ? 255u - (key & 255u) : 0u;
+    int nl = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (4 * lane + i == largest) nl = n[i];
+    nl = __shfl(nl, (int)(largest >> 2), WAVE);
+    if (-still >= (nl >> 1)) return wg_normalize_fallback(n, c, total, maxSV, tl, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (4 * lane + i == largest) n[i] += still;
+    return 0;
+}
+
+// ---- NCount header -----------------------------------------------------------------------------------------------------
+// OR `nb` (<= 16) bits into the little-endian bit image at bit position pos (LDS atomics: lanes share words)
+DEV void wg_or_bits(u32* img, u32 pos, u32 v, u32 nb)
+{
+    if (nb == 0) return;
+    const u32 w = pos >> 5, sh = pos & 31u;
+    atomicOr(&img[w], v << sh);
+    if (sh + nb > 32u) atomicOr(&img[w + 1], v >> (32u - sh));
+}
+// n[i]: counters of symbols 4*lane + i, summing (in absolute value) to 1 << tl with a non-zero counter at maxSV.  img: zeroed
+// LDS words (>= 132).  Returns the header size in bytes (the image then holds the header) or an error code: dstSize_tooSmall by the
+// reference's rule -- only checked when the destination is below the worst-case header size, at every 16-bit flush
+// (lib/fse_compress.c:186-190, :228-272), i.e. against the position of the last flush.
+DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 tl, u32 lane)
+{
+    const u32 ts = 1u << tl;
+    u32 a = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a += (u32)(n[i] < 0 ? -n[i] : n[i]);
+    u32 before = wg_scan_excl(a, lane);                         // points assigned in front of my first symbol
+    // position of the first non-zero counter above each of my symbols
+    u32 nzLane = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) if (n[i] != 0 && 4 * lane + i <= maxSV) nzLane = 4 * lane + i;
+    const u32 nzAbove = wg_suffix_min_excl(nzLane, lane);
+    int prevN = __shfl_up(n[3], 1, WAVE);                      // counter of the symbol in front of my first one
+    if (lane == 0) prevN = 1;
+    // chunks of my symbols: value + zero-run code; sizes first
+    u32 val[4], vnb[4], run[4], bits = 0;
+    bool broken = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 s = 4 * lane + i;
+        const int remaining = (int)(ts + 1) - (int)before;
+        const int pn = i ? n[i - 1] : prevN;
+        const bool coded = s <= maxSV && remaining > 1 && !(n[i] == 0 && pn == 0);
+        val[i] = 0; vnb[i] = 0; run[i] = 0xFFFFFFFFu;
+        if (coded) {
+            const u32 hb = hibit32((u32)remaining);
+            const int threshold = 1 << hb, slack = 2 * threshold - 1 - remaining;
+            int v = n[i] + 1;
+            if (v >= threshold) v += slack;
+            val[i] = (u32)v; vnb[i] = hb + 1 - (v < slack);
+            bits += vnb[i];
+            if (n[i] == 0) {                                   // first zero of a run: the rest of the run is counted here
+                u32 e = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 3; j > 0; --j) if (j > i && n[j] != 0 && 4 * lane + j <= maxSV) e = 4 * lane + j;
+                if (e == 0xFFFFFFFFu) e = nzAbove;
+                if (e == 0xFFFFFFFFu) broken = true;           // zeros up to the end of the alphabet: not a distribution
+                else { const u32 R = e - (s + 1); run[i] = R; bits += 16u * (R / 24u) + 2u * ((R % 24u) / 3u) + 2u; }
+            }
+        }
+        before += (u32)(n[i] < 0 ? -n[i] : n[i]);
+    }
+    const u32 total = wg_sum(a);
+    if (__any(broken) || total != ts) return FERR(GENERIC);
+    const u32 mine = bits + (lane == 0 ? 4u : 0u);
+    u32 pos = wg_scan_excl(mine, lane);
+    const u32 totalBits = wg_sum(mine);
+    const size_t bound = maxSV ? (size_t)((((maxSV + 1) * tl) >> 3) + 3) : (size_t)FSEHIP_FSE_NCOUNTBOUND;
+    if (cap < bound) {
+        const long lastFlush = 2 * (long)((totalBits - 1) >> 4);
+        if (lastFlush > (long)cap - 2) return FERR(dstSize_tooSmall);
+    }
+    if (lane == 0) { wg_or_bits(img, 0, tl - FSE_MIN_TL, 4); pos += 4; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wg_or_bits(img, pos, val[i], vnb[i]); pos += vnb[i];
+        if (run[i] != 0xFFFFFFFFu) {
+            u32 R = run[i];
+            for (; R >= 24; R -= 24) { wg_or_bits(img, pos, 0xFFFFu, 16); pos += 16; }
+            for (; R >= 3; R -= 3) { wg_or_bits(img, pos, 3u, 2); pos += 2; }
+            wg_or_bits(img, pos, R, 2); pos += 2;
+        }
+    }
+    return (size_t)((totalBits + 7) >> 3);
+}
