@@ -1,0 +1,723 @@
+// huf_prep.hip -- everything around the Huff0 hot loops, on the device (SURVEY 8(a') rows g5-g7):
+//   compress side   : early outs of HUF_compress_internal, table log, code lengths (sort, tree, height limit), canonical codes,
+//                     weights header incl. its small FSE coder      (behaviour of lib/huf_compress.c:637-724, :202-410, :63-147)
+//   decompress side : raw / RLE decisions of HUF_decompress, weights header reader, X1 decoding table
+//                     (behaviour of lib/huf_decompress.c:1056-1066, :118-185; lib/entropy_common.c:154-215)
+//
+// Mapping.  The work per block is a mix of wide steps (sorting up to 256 counts, ranking symbols, filling a table) and
+// strictly serial ones (the two-queue Huffman merge, the tANS coding of the weights, bit parsers).  A lone wave issues
+// one instruction every ~7 cycles however many of its lanes are active, so a serial step costs a whole wave-instruction
+// per block unless several blocks share the wave.  Hence: one 64-lane wave looks after HP_G = 8 blocks; the wide steps run
+// over the blocks one after another with all 64 lanes (lane l: symbols 4l .. 4l+3, or cell / visit l), the serial steps
+// run for the 8 blocks at once, lane g on block g.  Everything lives in registers and in the block's LDS slot
+// (about 3.7 KiB: sorted keys, internal-node counts, parent links, lengths, the small FSE tables, the header image);
+// global memory sees the counts once (coalesced) and the CElt table / header / X1 table once (coalesced).
+//
+// Restated pieces (see scripts/sim/huf_glue_sim.py for the CPU model checked against the compiled reference):
+//   * order: keys count << 9 | 1 << 8 | 255 - symbol sorted descending by a bitonic network in registers = the reference's
+//     order (count descending, ties in symbol order);
+//   * tree: the two-queue merge on the sorted leaves (ties prefer the internal queue), recording parent links only; depths by
+//     chasing the links from the leaves, 64 leaves at a time;
+//   * height limit: lengths are monotone along the sorted leaves, so classes of equal length are contiguous runs and the
+//     repair is a walk over the run boundaries (`last[k]` = last leaf of length limit - k): overlong leaves are cut to the
+//     limit, the Kraft debt is repaid by moving boundary leaves one class down, an over-payment by moving the first leaves of
+//     the limit class one class up;
+//   * codes: start value per length by the usual recurrence over <= 12 lengths; value of a symbol = start + its rank among
+//     the symbols of the same length, by wave ballots;
+//   * header: weight histogram by ballots, the wave-level normalisation / NCount writer of wave_glue.h, a <= 64-state tANS
+//     table built one spread visit per lane, the weights coded serially (lane g).
+#include "internal.h"
+#include "wave_glue.h"
+#include "ncount_reader.h"
+#include "bitreader.h"
+
+#define HUF_MAX_TL FSEHIP_HUF_TABLELOG_MAX
+#define HUF_DEF_TL FSEHIP_HUF_TABLELOG_DEFAULT
+#define HP_G 8                          // blocks per wave
+
+// ---- LDS slot of one block (bytes) ------------------------------------------------------------------------------------
+#define HP_KEYS   0                     // u32[256] sorted keys, rank order (count = key >> 9)
+#define HP_ICNT   1024                  // u32[256] counts of the internal nodes, creation order
+#define HP_PAR    2048                  // u8[512]  parent (internal-node index) of leaf rank r [r] and of internal node k [256 + k]
+#define HP_NBRANK 2560                  // u8[256]  code length by rank
+#define HP_NBSYM  2816                  // u8[256]  code length by symbol; decode side: weights by symbol
+#define HP_ST     3072                  // u16[64]  small tANS table: next-state table (encode) / cells (decode: u32[64] spans ST and TT)
+#define HP_TT     3200                  // u32[32]  small tANS table: per-symbol transforms
+#define HP_CELL   3328                  // u8[64]   symbol of every cell of the small table
+#define HP_NRM    3392                  // s16[16]  normalised counters of the weights (encode side)
+#define HP_LAST   3424                  // u16[16]  height limit: last rank of every length class
+#define HP_HDR    3456                  // u8[288]  header image (u32 aligned)
+#define HP_SCAL   3744                  // u32[8]   per-block scalars
+#define HP_SLOT   3776
+// decode side reuses the slot: HP_KEYS region = s16[256] counters of the weights' NCount header + u8[256] symbols sorted by weight
+enum { SC_STATE = 0, SC_MAXSV, SC_LOG, SC_LEAVES, SC_RESULT_LO, SC_RESULT_HI, SC_HDR, SC_AUX };
+
+DEV unsigned long long hp_below_mask(u32 lane) { return (1ull << lane) - 1ull; }
+
+// ---- bitonic sort, descending, of 64 * R keys held R per lane (element index = lane * R + r) ----------------------------
+template <int R>
+DEV void hp_sort_desc(u32 (&k)[R], u32 lane)
+{
+    constexpr u32 N = 64u * R;
+#pragma unroll
+    for (u32 size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (u32 j = size >> 1; j > 0; j >>= 1) {
+            if (j >= (u32)R) {                                            // partner in another lane, same register
+                const u32 lj = j / R;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const u32 i = lane * R + r;
+                    const u32 o = (u32)__shfl_xor((int)k[r], (int)lj, WAVE);
+                    const bool keepMax = ((i & size) == 0) == ((i & j) == 0);
+                    const u32 hi = k[r] > o ? k[r] : o, lo = k[r] > o ? o : k[r];
+                    k[r] = keepMax ? hi : lo;
+                }
+            } else {                                                     // partner in this lane
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r & j) continue;
+                    const u32 i = lane * R + r;
+                    const bool desc = (i & size) == 0;
+                    const u32 a = k[r], b = k[r | j];
+                    const u32 hi = a > b ? a : b, lo = a > b ? b : a;
+                    k[r] = desc ? hi : lo; k[r | j] = desc ? lo : hi;
+                }
+            }
+        }
+    }
+}
+
+// ---- small tANS tables (table log <= 6): one spread visit per lane ---------------------------------------------------------
+// nrm(s) = counter of symbol s (uniform access).  Cell u of the table belongs to symbol cellSym[u]; `rank` = number of lower
+// cells of the same symbol.  The spread visits cells (m * step) mod size for m = 0, 1, ...; the low-probability symbols
+// (counter -1) take the top cells; the k-th visit that is not a top cell belongs to the symbol whose cumulative range holds k.
+// Calls emit(lane's cell u, symbol, rank, slot = first slot of the symbol counting -1 as 1) for every cell, lane u = cell u.
+template <class Nrm, class Emit>
+DEV void hp_small_table(u8* cellSym, u32 maxSV, u32 tl, u32 lane, Nrm&& nrm, Emit&& emit)
+{
+    const u32 ts = 1u << tl, mask = ts - 1, step = (ts >> 1) + (ts >> 3) + 3;
+    u32 nLow = 0;
+    for (u32 s = 0; s <= maxSV; ++s) nLow += nrm(s) == -1;
+    const int high = (int)ts - 1 - (int)nLow;
+    const u32 u0 = (lane * step) & mask;
+    const bool kept = lane < ts && (int)u0 <= high;
+    const u32 k = (u32)__builtin_popcountll(__ballot(kept) & hp_below_mask(lane));
+    u32 mine = 0, cum = 0, low = 0;
+    for (u32 s = 0; s <= maxSV; ++s) {                                    // uniform walk over the alphabet
+        const int n = nrm(s);
+        if (n == -1) { if (lane == 0) cellSym[ts - 1 - low] = (u8)s; ++low; }
+        else if (n > 0) { if (k >= cum) mine = s; cum += (u32)n; }
+    }
+    if (kept) cellSym[u0] = (u8)mine;
+    __syncthreads();
+    const bool cellOn = lane < ts;
+    const u32 sy = cellOn ? cellSym[lane] : 0xFFFFu;
+    u32 first = 0;
+    for (u32 s = 0; s <= maxSV; ++s) {
+        const int n = nrm(s);
+        if (n == 0) continue;                                            // uniform
+        const unsigned long long m = __ballot(cellOn && sy == s);
+        if (cellOn && sy == s) emit(lane, s, (u32)__builtin_popcountll(m & hp_below_mask(lane)), first, n);
+        first += n == -1 ? 1u : (u32)n;
+    }
+}
+
+// =====================================================================================================================
+//  compress side
+// =====================================================================================================================
+// serial tANS coder of the weights (lane g): FSE_compress_usingCTable on the small table (lib/fse_compress.c:554-611);
+// returns the payload size (0 = does not fit / not worth it) by BIT_closeCStream's rule (lib/bitstream.h:254-260)
+DEV u32 hp_encode_weights(u8* out, long cap, const u8* nbSym, u32 n, u32 huffLog, const u16* st, const u32* tt, u32 tl)
+{
+    if (n <= 2 || cap <= 8) return 0;
+#define HP_W(s) ((u32)(nbSym[s] ? huffLog + 1 - nbSym[s] : 0))
+    u32 ch[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const u32 w = HP_W(n - 1 - j), dfs = tt[2 * w], dnb = tt[2 * w + 1];
+        const u32 nbo = (dnb + (1u << 15)) >> 16;
+        ch[j] = st[(((nbo << 16) - dnb) >> nbo) + dfs];
+    }
+    u64 acc = 0; u32 nacc = 0, pos = 0, total = 0;
+    for (u32 j = 2; j < n; ++j) {
+        const u32 w = HP_W(n - 1 - j), dfs = tt[2 * w], dnb = tt[2 * w + 1];
+        const u32 x = ch[j & 1];
+        const u32 nb = (x + dnb) >> 16;
+        acc |= (u64)(x & ((1u << nb) - 1u)) << nacc; nacc += nb; total += nb;
+        ch[j & 1] = st[(x >> nb) + dfs];
+        while (nacc >= 8) { if ((long)pos < cap) out[pos] = (u8)acc; ++pos; acc >>= 8; nacc -= 8; }
+    }
+#undef HP_W
+    const u32 c2 = (n & 1u) ? ch[1] : ch[0], c1 = (n & 1u) ? ch[0] : ch[1];
+    acc |= (u64)(c2 & ((1u << tl) - 1u)) << nacc; nacc += tl;
+    acc |= (u64)(c1 & ((1u << tl) - 1u)) << nacc; nacc += tl;
+    acc |= (u64)1 << nacc; nacc += 1;
+    total += 2 * tl + 1;
+    if ((long)(total >> 3) >= cap - 8) return 0;
+    while (nacc > 0) { if ((long)pos < cap) out[pos] = (u8)acc; ++pos; acc >>= 8; nacc = nacc > 8 ? nacc - 8 : 0; }
+    return (total + 7) >> 3;
+}
+
+// two-queue merge (lane g): leaves keys[0 .. L-1] descending; records parents only
+DEV void hp_merge(const u32* keys, u32* icnt, u8* par, u32 L)
+{
+    const u32 NO_LEAF = 1u << 31, NO_NODE = 1u << 30;                     // exhausted / not yet created: never the smaller one
+    int li = (int)L - 1;
+    u32 ii = 0;
+    u32 leaf = keys[li] >> 9, node = NO_NODE;
+    for (u32 ni = 0; ni + 1 < L; ++ni) {
+        u32 sum = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (leaf < node) { sum += leaf; par[li] = (u8)ni; --li; leaf = li >= 0 ? keys[li] >> 9 : NO_LEAF; }
+            else { sum += node; par[256 + ii] = (u8)ni; ++ii; node = ii < ni ? icnt[ii] : NO_NODE; }
+        }
+        icnt[ni] = sum;
+        if (ii == ni) node = sum;
+    }
+}
+
+// height limit (lane g): nb[] lengths by rank (non-decreasing), keys give the counts.  Returns the final maximum length.
+DEV u32 hp_limit_height(u8* nb, const u32* keys, u16* last, u32 L, u32 M)
+{
+    const u32 largest = nb[L - 1];
+    if (largest <= M) return largest;
+    const u32 NONE = 0xFFFFu;
+    int debt = 0;
+    for (u32 k = 0; k < HUF_MAX_TL + 2; ++k) last[k] = (u16)NONE;
+    int n = -1;
+    for (u32 r = 0; r < L; ++r) {                                         // ranks ascend: the last write of a class is its last leaf
+        const u32 d = nb[r];
+        if (d > M) { debt += (int)((1u << (largest - M)) - (1u << (largest - d))); nb[r] = (u8)M; }
+        else if (d < M) { last[M - d] = (u16)r; n = (int)r; }
+    }
+    debt >>= (largest - M);                                               // in units of 2^-M
+    while (debt > 0) {
+        u32 k = hibit32((u32)debt) + 1;                                   // a leaf leaving class k pays 2^(k-1)
+        for (; k > 1; --k) {                                              // a cheaper class if its last leaf is rare enough
+            const u32 hi = last[k], lo = last[k - 1];
+            if (hi == NONE) continue;
+            if (lo == NONE) break;
+            if ((keys[hi] >> 9) <= 2 * (keys[lo] >> 9)) break;
+        }
+        while (k <= HUF_MAX_TL && last[k] == NONE) ++k;
+        debt -= 1 << (k - 1);
+        const u32 r = last[k];
+        if (last[k - 1] == NONE) last[k - 1] = (u16)r;
+        nb[r] = (u8)(nb[r] + 1);
+        if (r == 0) last[k] = (u16)NONE;
+        else last[k] = (u16)(nb[r - 1] == M - k ? r - 1 : NONE);
+    }
+    while (debt < 0) {                                                    // overpaid: the first leaves of the limit class move up
+        if (last[1] == NONE) {
+            while (nb[n] == M) --n;
+            nb[n + 1] = (u8)(nb[n + 1] - 1); last[1] = (u16)(n + 1);
+        } else {
+            const u32 r = (u32)last[1] + 1;
+            nb[r] = (u8)(nb[r] - 1); last[1] = (u16)r;
+        }
+        ++debt;
+    }
+    return M;
+}
+
+__global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 hpLds[];
+    const u32 lane = threadIdx.x;
+    const size_t b0 = (size_t)blockIdx.x * HP_G;
+
+    // ---- phase A (wide, block after block): early outs, table log, sorted keys
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        const size_t b = b0 + g;
+        if (b >= a.nBlocks) { if (lane == 0) sc[SC_STATE] = 0; continue; }  // uniform
+        const size_t n = view_size(a.src, b);
+        size_t result = 0; bool go = false;
+        const size_t top = a.histResults[b];
+        if (!n || !a.dstCapacity) result = 0;                              // huf_compress.c:656-657
+        else if (n > FSEHIP_HUF_BLOCKSIZE_MAX) result = FERR(srcSize_wrong);
+        else if (is_err(top)) result = top;
+        else if (top == n) { if (lane == 0) a.dst[b * a.dstStride] = view_ptr(a.src, b)[0]; result = 1; }   // rle (:673)
+        else if (top <= (n >> 7) + 4) result = 0;                          // not compressible enough (:674)
+        else go = true;
+        if (!go) {
+            if (lane == 0) { sc[SC_STATE] = 0; HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0; a.meta[b] = m; a.results[b] = result; }
+            continue;
+        }
+        const u32 maxSV = a.maxSVs[b];
+        const u32 huffLog = wg_optimal_tablelog(a.huffLogReq ? a.huffLogReq : HUF_DEF_TL, n, maxSV, 1);   // :691
+        const uint4 cv = ((const uint4*)(a.counts + b * 256))[lane];
+        u32 k[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u32 s = 4 * lane + i; k[i] = (s <= maxSV && k[i]) ? (k[i] << 9) | (1u << 8) | (255u - s) : 0u; }
+        u32 present = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) present += k[i] != 0;
+        present = wg_sum(present);
+        if (maxSV < 64) {                                                  // uniform: one key per lane is enough
+            // symbols 0..63 sit four per lane in lanes 0..15: bring symbol `lane` to lane `lane`
+            u32 one[1];
+            const u32 src = lane >> 2;
+            const u32 v0 = (u32)__shfl((int)k[0], (int)src, WAVE), v1 = (u32)__shfl((int)k[1], (int)src, WAVE);
+            const u32 v2 = (u32)__shfl((int)k[2], (int)src, WAVE), v3 = (u32)__shfl((int)k[3], (int)src, WAVE);
+            one[0] = (lane & 2u) ? ((lane & 1u) ? v3 : v2) : ((lane & 1u) ? v1 : v0);
+            hp_sort_desc<1>(one, lane);
+            ((u32*)(slot + HP_KEYS))[lane] = one[0];
+        } else {
+            hp_sort_desc<4>(k, lane);
+            ((uint4*)(slot + HP_KEYS))[lane] = make_uint4(k[0], k[1], k[2], k[3]);
+        }
+        if (lane == 0) { sc[SC_STATE] = 1; sc[SC_MAXSV] = maxSV; sc[SC_LOG] = huffLog; sc[SC_LEAVES] = present; }
+    }
+    __syncthreads();
+
+    // ---- phase B (serial, lane g on block g): the tree
+    if (lane < HP_G) {
+        u8* const slot = hpLds + lane * HP_SLOT;
+        const u32* const sc = (const u32*)(slot + HP_SCAL);
+        if (sc[SC_STATE]) hp_merge((const u32*)(slot + HP_KEYS), (u32*)(slot + HP_ICNT), slot + HP_PAR, sc[SC_LEAVES]);
+    }
+    __syncthreads();
+
+    // ---- phase C (wide): leaf depths by chasing the parent links
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        const u32* const sc = (const u32*)(slot + HP_SCAL);
+        if (!sc[SC_STATE]) continue;                                       // uniform
+        const u32 L = sc[SC_LEAVES], root = L - 2;
+        const u8* const par = slot + HP_PAR;
+        u32 p[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u32 r = lane + 64u * i; d[i] = 1; p[i] = r < L ? par[r] : root; }
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (p[i] != root) { p[i] = par[256 + p[i]]; ++d[i]; more = true; }
+            if (!__any(more)) break;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u32 r = lane + 64u * i; if (r < L) slot[HP_NBRANK + r] = (u8)d[i]; }
+    }
+    __syncthreads();
+
+    // ---- phase D (serial): height limit
+    if (lane < HP_G) {
+        u8* const slot = hpLds + lane * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        if (sc[SC_STATE]) sc[SC_LOG] = hp_limit_height(slot + HP_NBRANK, (const u32*)(slot + HP_KEYS), (u16*)(slot + HP_LAST), sc[SC_LEAVES], sc[SC_LOG]);
+    }
+    __syncthreads();
+
+    // ---- phase E (wide): lengths by symbol, canonical values, CElt table; weight statistics and the small tANS table
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        if (!sc[SC_STATE]) continue;                                       // uniform
+        const size_t b = b0 + g;
+        const u32 L = sc[SC_LEAVES], maxSV = sc[SC_MAXSV], huffLog = sc[SC_LOG];
+        u8* const nbSym = slot + HP_NBSYM;
+        ((u32*)nbSym)[lane] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 r = lane + 64u * i;
+            if (r < L) nbSym[255u - (((const u32*)(slot + HP_KEYS))[r] & 255u)] = slot[HP_NBRANK + r];
+        }
+        __syncthreads();
+        const u32 w4 = ((const u32*)nbSym)[lane];                          // lengths of symbols 4*lane .. 4*lane+3
+        u32 nb[4], val[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { nb[i] = (w4 >> (8 * i)) & 0xFFu; val[i] = 0; }
+        // per length: how many symbols (start values, huf_compress.c:394-400) and my rank among them (symbol order).
+        // Absent symbols (length 0) are numbered too, as the reference does.
+        u32 start = 0, carry = 0;
+        for (int len = (int)huffLog; len >= 0; --len) {                    // uniform
+            u32 cntLen = 0;
+            unsigned long long m[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { m[i] = __ballot(nb[i] == (u32)len && 4 * lane + i <= maxSV); cntLen += (u32)__builtin_popcountll(m[i]); }
+            if (len > 0) { start = carry; carry = (carry + cntLen) >> 1; } else start = 0;
+            // rank in symbol order: symbols of lower lanes (all four registers) + lower registers of my lane
+            u32 lowerLanes = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lowerLanes += (u32)__builtin_popcountll(m[i] & hp_below_mask(lane));
+            u32 inLane = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { if (nb[i] == (u32)len && 4 * lane + i <= maxSV) { val[i] = start + lowerLanes + inLane; ++inLane; } }
+        }
+        {   uint4 ce;
+            u32 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = 4 * lane + i <= maxSV ? ((val[i] & 0xFFFFu) | (nb[i] << 16)) : 0u;   // zeroed beyond maxSV (:697-699)
+            ce = make_uint4(e[0], e[1], e[2], e[3]);
+            ((uint4*)(a.ctables + b * a.ctStrideU32))[lane] = ce;
+        }
+        // ---- weights (symbols 0 .. maxSV-1; the last one is implied): statistics for the small FSE coder (huf_compress.c:63-103)
+        const u32 wtSize = maxSV;
+        u32 wt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wt[i] = nb[i] ? huffLog + 1 - nb[i] : 0;
+        u32 cw[4] = { 0, 0, 0, 0 };                                        // my share of the histogram: weights 4*lane .. 4*lane+3
+        u32 topCount = 0, maxW = 0;
+        for (u32 v = 0; v <= HUF_MAX_TL; ++v) {                            // uniform
+            u32 c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c += (u32)__builtin_popcountll(__ballot(wt[i] == v && 4 * lane + i < wtSize));
+            if (c) maxW = v;
+            topCount = c > topCount ? c : topCount;
+            if ((v >> 2) == lane) cw[v & 3] = c;
+        }
+        u32 hs = 0;                                                        // size of the FSE-coded weights (0 / 1 = not usable)
+        u32 wtl = 0; bool tableReady = false;
+        size_t err = 0;
+        u32* const img = (u32*)(slot + HP_HDR);
+        for (u32 i = lane; i < 72; i += 64) img[i] = 0;
+        __syncthreads();
+        const long wcap = (long)a.dstCapacity - 1;                         // HUF_compressWeights(op + 1, maxDstSize - 1, ...)
+        u32 ncBytes = 0;
+        if (wtSize > 1) {
+            if (topCount == wtSize) hs = 1;
+            else if (topCount == 1) hs = 0;
+            else {
+                wtl = wg_optimal_tablelog(6, wtSize, maxW, 2);
+                int nn[4];
+                size_t e = wg_normalize(nn, cw, (u64)wtSize, maxW, wtl, lane);
+                if (!is_err(e)) e = wg_write_ncount(img + 1, (size_t)(wcap < 0 ? 0 : wcap), nn, maxW, wtl, lane);   // image byte 4.. = header byte 1..
+                if (is_err(e)) err = e;
+                else {
+                    ncBytes = (u32)e;
+                    if (lane < 4) *(uint2*)(slot + HP_NRM + 8 * lane) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
+                    __syncthreads();
+                    const s16* const nrm = (const s16*)(slot + HP_NRM);
+                    u16* const st = (u16*)(slot + HP_ST);
+                    u32* const tt = (u32*)(slot + HP_TT);
+                    const u32 ts = 1u << wtl;
+                    hp_small_table(slot + HP_CELL, maxW, wtl, lane, [&](u32 s) { return (int)nrm[s]; },
+                                   [&](u32 u, u32 s, u32 r, u32 first, int n) { (void)s; (void)n; st[first + r] = (u16)(ts + u); });
+                    // per-symbol transforms (lib/fse_compress.c:136-166), lane s <= maxW
+                    if (lane <= maxW) {
+                        int total = 0;
+                        for (u32 s = 0; s < lane; ++s) { const int n = nrm[s]; total += n == -1 ? 1 : n; }
+                        const int n = nrm[lane];
+                        u32 dfs = 0, dnb = ((wtl + 1) << 16) - ts;
+                        if (n == -1 || n == 1) { dfs = (u32)(total - 1); dnb = (wtl << 16) - ts; }
+                        else if (n > 1) { const u32 mbo = wtl - hibit32((u32)n - 1); dfs = (u32)(total - n); dnb = (mbo << 16) - ((u32)n << mbo); }
+                        tt[2 * lane] = dfs; tt[2 * lane + 1] = dnb;
+                    }
+                    tableReady = true;
+                }
+            }
+        }
+        if (lane == 0) { sc[SC_HDR] = hs; sc[SC_AUX] = (tableReady ? 1u : 0u) | (wtl << 8) | (ncBytes << 16); sc[SC_RESULT_LO] = (u32)err; sc[SC_RESULT_HI] = (u32)(err >> 32); }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- phase F (serial): the weights through the small coder
+    if (lane < HP_G) {
+        u8* const slot = hpLds + lane * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        if (sc[SC_STATE] && (sc[SC_AUX] & 1u)) {
+            const u32 wtl = (sc[SC_AUX] >> 8) & 0xFFu, ncBytes = sc[SC_AUX] >> 16;
+            const long wcap = (long)a.dstCapacity - 1 - (long)ncBytes;
+            const u32 cs = hp_encode_weights(slot + HP_HDR + 4 + ncBytes, wcap, slot + HP_NBSYM, sc[SC_MAXSV], sc[SC_LOG],
+                                             (const u16*)(slot + HP_ST), (const u32*)(slot + HP_TT), wtl);
+            sc[SC_HDR] = cs ? ncBytes + cs : 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase G (wide): header out (FSE-coded weights, or 4 bits per weight), final checks, meta
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        const u32* const sc = (const u32*)(slot + HP_SCAL);
+        if (!sc[SC_STATE]) continue;                                       // uniform
+        const size_t b = b0 + g;
+        const size_t n = view_size(a.src, b);
+        const u32 maxSV = sc[SC_MAXSV], huffLog = sc[SC_LOG], hs = sc[SC_HDR];
+        const size_t err = (size_t)sc[SC_RESULT_LO] | ((size_t)sc[SC_RESULT_HI] << 32);
+        u8* const dst = a.dst + b * a.dstStride;
+        HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+        size_t result = 0, h = 0;
+        if (err) result = err;
+        else if (hs > 1 && hs < maxSV / 2) {                               // FSE-coded weights (huf_compress.c:131-135)
+            const u8* const img = slot + HP_HDR + 4;
+            for (u32 i = lane; i < hs; i += 64) dst[1 + i] = img[i];
+            if (lane == 0) dst[0] = (u8)hs;
+            h = hs + 1;
+        } else if (maxSV > 128) result = FERR(GENERIC);                    // :138
+        else if ((size_t)((maxSV + 1) / 2) + 1 > a.dstCapacity) result = FERR(dstSize_tooSmall);
+        else {
+            const u8* const nbSym = slot + HP_NBSYM;
+            for (u32 i = lane; 2 * i < maxSV; i += 64) {
+                const u32 n0 = nbSym[2 * i], n1 = 2 * i + 1 < maxSV ? nbSym[2 * i + 1] : 0;
+                const u32 w0 = n0 ? huffLog + 1 - n0 : 0, w1 = n1 ? huffLog + 1 - n1 : 0;
+                dst[1 + i] = (u8)((w0 << 4) + w1);
+            }
+            if (lane == 0) dst[0] = (u8)(128 + (maxSV - 1));
+            h = (maxSV + 1) / 2 + 1;
+        }
+        if (h) {
+            if (h + 12ul >= n) result = 0;                                 // :715
+            else { m.state = 1; m.hdrSize = (u32)h; m.tableLog = huffLog; m.maxSV = maxSV; }
+        }
+        if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; }
+    }
+}
+
+// =====================================================================================================================
+//  decompress side
+// =====================================================================================================================
+// serial decode of the FSE-coded weights (lane g): FSE_decompress_usingDTable on the small table (lib/fse_decompress.c:178-238)
+// with the literal bit reader; cells = {u16 newState; u8 symbol; u8 nbBits}
+DEV size_t hp_decode_weights(u8* w, long omax, const u8* in, size_t n, const u32* cells, u32 tl, bool fast)
+{
+    BitReader r;
+    {   const size_t e = r.init(in, n); if (is_err(e)) return e; }
+    u32 s1 = r.read(tl); r.reload();
+    u32 s2 = r.read(tl); r.reload();
+    long op = 0;
+    for (;;) {
+        const int st = r.reload();
+        if (!((st == BR_UNFINISHED) & (op < omax - 3))) break;
+        w[op + 0] = (u8)fse_step(s1, r, cells, fast); w[op + 1] = (u8)fse_step(s2, r, cells, fast);
+        w[op + 2] = (u8)fse_step(s1, r, cells, fast); w[op + 3] = (u8)fse_step(s2, r, cells, fast);
+        op += 4;
+    }
+    for (;;) {
+        if (op > omax - 2) return FERR(dstSize_tooSmall);
+        w[op++] = (u8)fse_step(s1, r, cells, fast);
+        if (r.reload() == BR_OVERFLOW) { w[op++] = (u8)fse_step(s2, r, cells, fast); break; }
+        if (op > omax - 2) return FERR(dstSize_tooSmall);
+        w[op++] = (u8)fse_step(s2, r, cells, fast);
+        if (r.reload() == BR_OVERFLOW) { w[op++] = (u8)fse_step(s1, r, cells, fast); break; }
+    }
+    return (size_t)op;
+}
+
+// decode-side slot: counters of the weights' header (s16[256]) at HP_KEYS, symbols sorted by weight (u8[256]) at HP_KEYS + 512,
+// weights by symbol (u8[256 + 4]) at HP_ICNT, small DTable cells u32[64] at HP_ST (spans ST, TT)
+#define HD_NORM   HP_KEYS
+#define HD_SORTED (HP_KEYS + 512)
+#define HD_WGT    HP_ICNT
+#define HD_CELLS  HP_ST
+enum { DS_STATE = 0, DS_HDR, DS_NSYM, DS_FSE, DS_RESULT_LO, DS_RESULT_HI, DS_AUX, DS_CLS };   // DS_STATE: 0 done, 1 table pending, 2 raw copy, 3 rle fill
+
+__global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 hpLds[];
+    const u32 lane = threadIdx.x;
+    const size_t b0 = (size_t)blockIdx.x * HP_G;
+
+    // ---- phase A (serial, lane g): HUF_decompress's raw / RLE decisions, the weights' header (4-bit weights are unpacked here,
+    //      FSE-coded ones get their NCount header parsed)
+    if (lane < HP_G) {
+        u8* const slot = hpLds + lane * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        const size_t b = b0 + lane;
+        u32 state = 0; size_t result = 0;
+        sc[DS_FSE] = 0; sc[DS_CLS] = 0xFFFFFFFFu;
+        if (b < a.nBlocks) {
+            const u8* const in = view_ptr(a.csrc, b);
+            const size_t cSize = view_size(a.csrc, b), dstSize = view_size(a.dstSizes, b);
+            u8* const w = slot + HD_WGT;
+            if (dstSize == 0) result = FERR(dstSize_tooSmall);            // huf_decompress.c:1063-1066
+            else if (cSize > dstSize) result = FERR(corruption_detected);
+            else if (cSize == dstSize) { state = 2; result = dstSize; }   // not compressed: copied below, coalesced
+            else if (cSize == 1) { state = 3; result = dstSize; }         // one byte repeated
+            else {                                                         // weights header (entropy_common.c:154-182); cSize >= 2 here
+                const u32 first = in[0];
+                if (first >= 128) {                                        // 4 bits per weight
+                    const u32 nW = first - 127, bytes = (nW + 1) / 2;
+                    if ((size_t)bytes + 1 > cSize) result = FERR(srcSize_wrong);
+                    else {
+                        for (u32 i = 0; i < bytes; ++i) { const u32 v = in[1 + i]; w[2 * i] = (u8)(v >> 4); w[2 * i + 1] = (u8)(v & 15u); }
+                        state = 1; sc[DS_NSYM] = nW; sc[DS_HDR] = bytes + 1;
+                    }
+                } else if ((size_t)first + 1 > cSize) result = FERR(srcSize_wrong);
+                else {                                                     // FSE-coded: FSE_decompress_wksp(weights, 255, in + 1, first, .., 6)
+                    u32 tl = 0, maxSV = 255;
+                    const size_t h = ncount_read<1>((s16*)(slot + HD_NORM), &maxSV, &tl, in + 1, first);
+                    if (is_err(h)) result = h;
+                    else if (tl > 6) result = FERR(tableLog_tooLarge);
+                    else { state = 1; sc[DS_FSE] = 1u | (tl << 8) | (maxSV << 16); sc[DS_HDR] = first + 1; sc[DS_AUX] = (u32)h; }
+                }
+            }
+        }
+        sc[DS_STATE] = state; sc[DS_RESULT_LO] = (u32)result; sc[DS_RESULT_HI] = (u32)(result >> 32);
+    }
+    __syncthreads();
+
+    // ---- phase B (wide): small decoding table of the FSE-coded weights (FSE_buildDTable, lib/fse_decompress.c:71-126)
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        if (sc[DS_STATE] != 1 || !(sc[DS_FSE] & 1u)) continue;             // uniform
+        const u32 tl = (sc[DS_FSE] >> 8) & 0xFFu, maxSV = sc[DS_FSE] >> 16, ts = 1u << tl;
+        const s16* const nrm = (const s16*)(slot + HD_NORM);
+        u32* const cells = (u32*)(slot + HD_CELLS);
+        bool big = false;
+        for (u32 s = 0; s <= maxSV; ++s) big |= nrm[s] >= (int)(ts >> 1);
+        hp_small_table(slot + HP_CELL, maxSV, tl, lane, [&](u32 s) { return (int)nrm[s]; },
+                       [&](u32 u, u32 s, u32 r, u32 first, int n) {
+                           (void)first;
+                           const u32 next = (n > 0 ? (u32)n : 1u) + r;    // symbolNext[s]++ (fse_decompress.c:117-122)
+                           const u32 nb = tl - hibit32(next);
+                           cells[u] = (((next << nb) - ts) & 0xFFFFu) | (s << 16) | (nb << 24);
+                       });
+        // (the counters of a parsed header sum to the table size, so the spread always closes: fse_decompress.c:113 cannot fire)
+        if (lane == 0) sc[DS_FSE] |= big ? 0u : 2u;                         // fastMode: no counter takes half the table (:95)
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- phase C (serial): the weights themselves
+    if (lane < HP_G) {
+        u8* const slot = hpLds + lane * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        if (sc[DS_STATE] == 1 && (sc[DS_FSE] & 1u)) {
+            const size_t b = b0 + lane;
+            const u8* const in = view_ptr(a.csrc, b);
+            const u32 first = sc[DS_HDR] - 1, h = sc[DS_AUX];
+            const size_t nW = hp_decode_weights(slot + HD_WGT, 255, in + 1 + h, first - h, (const u32*)(slot + HD_CELLS), (sc[DS_FSE] >> 8) & 0xFFu, (sc[DS_FSE] & 2u) != 0);
+            if (is_err(nW)) { sc[DS_STATE] = 0; sc[DS_RESULT_LO] = (u32)nW; sc[DS_RESULT_HI] = (u32)(nW >> 32); }
+            else sc[DS_NSYM] = (u32)nW;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D (wide): weight statistics, implied last weight, the X1 table; raw / RLE blocks are copied here
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        const size_t b = b0 + g;
+        if (b >= a.nBlocks) continue;                                      // uniform
+        const u32 state = sc[DS_STATE];
+        size_t result = (size_t)sc[DS_RESULT_LO] | ((size_t)sc[DS_RESULT_HI] << 32);
+        HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+        if (state == 2 || state == 3) {                                    // coalesced copy / fill of the whole block
+            const u8* const in = view_ptr(a.csrc, b);
+            u8* const dst = a.dst + b * a.dstStride;
+            const size_t dstSize = view_size(a.dstSizes, b);
+            const u32 fill = (u32)in[0] * 0x01010101u;
+            size_t i = 0;
+            const size_t head = dstSize < 4 ? dstSize : (size_t)((0 - (uintptr_t)dst) & 3u);
+            if (lane < head) dst[lane] = state == 2 ? in[lane] : (u8)fill;
+            for (i = head + 4 * (size_t)lane; i + 4 <= dstSize; i += 256) {
+                u32 v = fill;
+                if (state == 2) __builtin_memcpy(&v, in + i, 4);
+                *(u32*)(dst + i) = v;
+            }
+            const size_t done = head + ((dstSize - head) & ~(size_t)3);
+            if (done + lane < dstSize) dst[done + lane] = state == 2 ? in[done + lane] : (u8)fill;
+        } else if (state == 1) {
+            const u32 nW = sc[DS_NSYM];                                    // weights read; the last symbol's is implied
+            const u8* const w = slot + HD_WGT;
+            u32 wt[4];
+            {   const u32 w4 = ((const u32*)w)[lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wt[i] = 4 * lane + i < nW ? (w4 >> (8 * i)) & 0xFFu : 0xFFu; }
+            bool bad = false; u32 mass = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (wt[i] != 0xFFu) { bad |= wt[i] >= HUF_MAX_TL; mass += (1u << (wt[i] & 15u)) >> 1; }
+            mass = wg_sum(mass);
+            size_t err = 0;
+            u32 tl = 0, lastW = 0;
+            if (__any(bad) || mass == 0) err = FERR(corruption_detected);   // entropy_common.c:188-192
+            else {
+                tl = hibit32(mass) + 1;
+                const u32 rest = (1u << tl) - mass;
+                if (tl > HUF_MAX_TL || (rest & (rest - 1)) != 0) err = FERR(corruption_detected);   // the rest must be a clean power of 2
+                else lastW = hibit32(rest) + 1;
+            }
+            if (!err) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (4 * lane + i == nW) wt[i] = lastW;
+                // per weight: how many symbols, where its cells start; my rank among the symbols of the same weight
+                u32 cnt1 = 0;
+                u32 cellStart[4] = { 0, 0, 0, 0 };
+                u32 next = 0;
+                for (u32 v = 1; v <= tl; ++v) {                            // uniform
+                    unsigned long long mk[4]; u32 c = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { mk[i] = __ballot(wt[i] == v); c += (u32)__builtin_popcountll(mk[i]); }
+                    if (v == 1) cnt1 = c;
+                    u32 lowerLanes = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lowerLanes += (u32)__builtin_popcountll(mk[i] & hp_below_mask(lane));
+                    u32 inLane = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (wt[i] == v) { cellStart[i] = next + ((lowerLanes + inLane) << (v - 1)); ++inLane; }
+                    next += c << (v - 1);
+                }
+                if (cnt1 < 2 || (cnt1 & 1u)) err = FERR(corruption_detected);   // entropy_common.c:208
+                else if (tl > (HUF_MAX_TL - 1) + 1) err = FERR(tableLog_tooLarge);   // DTable of HUF_CREATE_STATIC_DTABLEX1(.., HUF_TABLELOG_MAX)
+                else {
+                    // X1 cells {byte, nbBits} (huf_decompress.c:158-183): symbol n owns (1 << w) >> 1 consecutive cells
+                    u32* const dt = a.dtables + b * a.dtStrideU32;
+                    u16* const cells = (u16*)(dt + 1);
+                    // long runs are written by the whole wave (coalesced), short ones by their own lane
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32 sym = 4 * lane + i;
+                        const bool on = wt[i] != 0xFFu && wt[i] != 0 && sym <= nW;
+                        const u32 len = on ? (1u << wt[i]) >> 1 : 0;
+                        const u32 cell = sym | ((tl + 1 - (wt[i] & 15u)) << 8);
+                        if (on && len < 64) for (u32 u = 0; u < len; ++u) cells[cellStart[i] + u] = (u16)cell;
+                        unsigned long long wide = __ballot(on && len >= 64);
+                        while (wide) {                                     // uniform
+                            const int src = __builtin_ctzll(wide); wide &= wide - 1;
+                            const u32 s0 = (u32)__shfl((int)cellStart[i], src, WAVE), ln = (u32)__shfl((int)len, src, WAVE);
+                            const u32 cv = (u32)__shfl((int)cell, src, WAVE);
+                            u32* const row = (u32*)(cells + s0);          // (2-byte aligned at worst: fine for global stores)
+                            for (u32 u = lane; u < ln / 2; u += 64) row[u] = cv | (cv << 16);
+                        }
+                    }
+                    if (lane == 0) dt[0] = ((HUF_MAX_TL - 1) & 0xFFu) | (tl << 16);
+                }
+            }
+            const u32 hdr = sc[DS_HDR];
+            if (!err && (size_t)hdr >= view_size(a.csrc, b)) err = FERR(srcSize_wrong);   // nothing behind the header (huf_decompress.c:432)
+            if (err) result = err;
+            else { m.state = 1; m.hdrSize = hdr; m.tableLog = tl; }
+        }
+        if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; sc[DS_CLS] = m.state ? (m.tableLog > 11u ? 1u : 0u) : 0xFFFFFFFFu; }
+    }
+    __syncthreads();
+
+    // ---- append the pending blocks to their decoder-class lists (one atomic per class and wave)
+    {   int cls = -1;
+        if (lane < HP_G && b0 + lane < a.nBlocks) cls = (int)((const u32*)(hpLds + lane * HP_SLOT + HP_SCAL))[DS_CLS];
+#pragma unroll
+        for (int c = 0; c < HUF_DCLS_COUNT; ++c) {
+            const unsigned long long mask = __ballot(cls == c);
+            if (!mask) continue;                                           // uniform
+            const int leader = __builtin_ctzll(mask);
+            u32 base = 0;
+            if ((int)lane == leader) base = atomicAdd(&a.counts[c], (u32)__builtin_popcountll(mask));
+            base = (u32)__shfl((int)base, leader, WAVE);
+            if (cls == c) a.lists[(size_t)c * a.nBlocks + base + (u32)__builtin_popcountll(mask & hp_below_mask(lane))] = (u32)(b0 + lane);
+        }
+    }
+}
+
+hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* /*unused*/)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    probe_before(PK_HUF_CPREP, s);
+    hipLaunchKernelGGL(k_huf_cprep, dim3((unsigned)((a.nBlocks + HP_G - 1) / HP_G)), dim3(64), HP_G * HP_SLOT, s, a);
+    probe_after(PK_HUF_CPREP, s);
+    return hipGetLastError();
+}
+hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    {   const hipError_t e = hipMemsetAsync(a.counts, 0, HUF_DCLS_COUNT * sizeof(u32), s); if (e != hipSuccess) return e; }
+    probe_before(PK_HUF_DPREP, s);
+    hipLaunchKernelGGL(k_huf_dprep, dim3((unsigned)((a.nBlocks + HP_G - 1) / HP_G)), dim3(64), HP_G * HP_SLOT, s, a);
+    probe_after(PK_HUF_DPREP, s);
+    return hipGetLastError();
+}
