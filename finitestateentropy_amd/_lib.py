@@ -7,6 +7,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 
 
 def library_path():
+    if os.environ.get("FSEHIP_LIB"):        # development aid: benchmark a differently configured build of the same library
+        return os.environ["FSEHIP_LIB"]
     return os.path.join(_CSRC, "libfsehip.so")
 
 

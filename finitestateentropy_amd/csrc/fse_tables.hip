@@ -44,12 +44,12 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a, u32 capTs)
         const uint4 cv = ((const uint4*)(a.counts + b * 256))[lane];       // symbols 4*lane .. 4*lane+3
         const u32 c[4] = { cv.x, cv.y, cv.z, cv.w };
         for (u32 i = lane; i < 136; i += 64) hdrImg[i] = 0;
-        const size_t e = wg_normalize(nn, c, (u64)n, maxSV, tl, lane);     // :659
+        const size_t e = wg_normalize<64>(nn, c, (u64)n, maxSV, tl, lane);     // :659
         if (is_err(e)) { result = e; go = false; }
     }
     __syncthreads();
     if (go) {
-        const size_t h = wg_write_ncount(hdrImg, a.dstCapacity, nn, maxSV, tl, lane);   // :662
+        const size_t h = wg_write_ncount<64>(hdrImg, a.dstCapacity, nn, maxSV, tl, lane);   // :662
         if (is_err(h)) { result = h; go = false; }
         else m.hdrSize = (u32)h;
     }

@@ -7,9 +7,9 @@
 // Mapping.  The work per block is a mix of wide steps (sorting up to 256 counts, ranking symbols, filling a table) and
 // strictly serial ones (the two-queue Huffman merge, the tANS coding of the weights, bit parsers).  A lone wave issues
 // one instruction every ~7 cycles however many of its lanes are active, so a serial step costs a whole wave-instruction
-// per block unless several blocks share the wave.  Hence: one 64-lane wave looks after HP_G = 8 blocks; the wide steps run
+// per block unless several blocks share the wave.  Hence: one 64-lane wave looks after G = 2..4 blocks; the wide steps run
 // over the blocks one after another with all 64 lanes (lane l: symbols 4l .. 4l+3, or cell / visit l), the serial steps
-// run for the 8 blocks at once, lane g on block g.  Everything lives in registers and in the block's LDS slot
+// run for the G blocks at once, lane g on block g.  Everything lives in registers and in the block's LDS slot
 // (about 3.7 KiB: sorted keys, internal-node counts, parent links, lengths, the small FSE tables, the header image);
 // global memory sees the counts once (coalesced) and the CElt table / header / X1 table once (coalesced).
 //
@@ -31,13 +31,30 @@
 #include "ncount_reader.h"
 #include "bitreader.h"
 
+#ifdef HP_TIMING            // development aid: per-phase cycle accounting of the first workgroups (scripts/hptiming.py)
+__device__ unsigned long long g_hpTiming[2][2048 * 12];
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hpTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hpTiming), sizeof(g_hpTiming)); }
+#define HPT_DECL unsigned long long hpT[12]; int hpN = 0; hpT[hpN++] = __builtin_readcyclecounter();
+#define HPT_MARK hpT[hpN++] = __builtin_readcyclecounter();
+#define HPT_DUMP(which) if (threadIdx.x == 0 && blockIdx.x < 2048) for (int q = 0; q + 1 < hpN; ++q) g_hpTiming[which][12 * blockIdx.x + q] = hpT[q + 1] - hpT[q];
+#else
+#define HPT_DECL
+#define HPT_MARK
+#define HPT_DUMP(which)
+#endif
 #define HUF_MAX_TL FSEHIP_HUF_TABLELOG_MAX
 #define HUF_DEF_TL FSEHIP_HUF_TABLELOG_DEFAULT
-#define HP_G 8                          // blocks per wave
+// blocks per wave (template parameter G_ of the kernels): measured on MI355X, per 100k blocks P14 / P02 --
+//   compress side  G = 1: 0.96 / 3.56 ms   2: 0.58 / 1.53   4: 0.76 / 1.54   8: 1.22 / 1.95   16: 2.64 / 3.70
+//   decompress     G = 1: 1.17 / 1.37 ms   2: 0.61 / 0.74   4: 0.42 / 0.83   8: 0.64 / 1.14   16: 1.48 / 2.29
+// (few blocks per wave = small LDS footprint = many waves per CU to hide the LDS / cross-lane latencies of the wide steps;
+//  one block per wave leaves the serial steps with a single busy lane)
+#define HP_G_COMPRESS 2
+#define HP_G_DECOMPRESS 4
 
 // ---- LDS slot of one block (bytes) ------------------------------------------------------------------------------------
 #define HP_KEYS   0                     // u32[256] sorted keys, rank order (count = key >> 9)
-#define HP_ICNT   1024                  // u32[256] counts of the internal nodes, creation order
+#define HP_ICNT   1024                  // u32[256] counts of the internal nodes, creation order; later: per-symbol coder entries of the weights
 #define HP_PAR    2048                  // u8[512]  parent (internal-node index) of leaf rank r [r] and of internal node k [256 + k]
 #define HP_NBRANK 2560                  // u8[256]  code length by rank
 #define HP_NBSYM  2816                  // u8[256]  code length by symbol; decode side: weights by symbol
@@ -123,34 +140,69 @@ DEV void hp_small_table(u8* cellSym, u32 maxSV, u32 tl, u32 lane, Nrm&& nrm, Emi
     }
 }
 
+// ---- class counting with packed counters ---------------------------------------------------------------------------------
+// Symbols fall into <= 14 classes (code lengths, or weights); what the table builders need is, per class, how many symbols it
+// has and the rank of every symbol among its class mates in symbol order.  Fourteen 9-bit counters fit two 64-bit words, so one
+// 64-bit pair scan over the lanes answers both for all classes at once (instead of a ballot per class).
+struct Pk { u64 a, b; };                                    // classes 0..6 in a, 7..13 in b, 9 bits each (counts <= 256)
+DEV void pk_add(Pk& p, u32 cls) { if (cls < 7) p.a += (u64)1 << (9 * cls); else p.b += (u64)1 << (9 * (cls - 7)); }
+DEV u32 pk_get(const Pk& p, u32 cls) { return cls < 7 ? (u32)(p.a >> (9 * cls)) & 511u : (u32)(p.b >> (9 * (cls - 7))) & 511u; }
+// cls[i] = class of symbol 4*lane + i (>= 14: not counted).  rank[i] = class mates in front of it; returns the class totals.
+DEV Pk pk_rank(const u32 cls[4], u32 rank[4], u32 lane)
+{
+    Pk mine = { 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (cls[i] < 14) pk_add(mine, cls[i]);
+    Pk incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 oa = (u64)__shfl_up((unsigned long long)incl.a, off, WAVE), ob = (u64)__shfl_up((unsigned long long)incl.b, off, WAVE);
+        if ((int)lane >= off) { incl.a += oa; incl.b += ob; }
+    }
+    Pk run = { incl.a - mine.a, incl.b - mine.b };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rank[i] = 0; if (cls[i] < 14) { rank[i] = pk_get(run, cls[i]); pk_add(run, cls[i]); } }
+    Pk tot;
+    tot.a = (u64)__shfl((unsigned long long)incl.a, 63, WAVE); tot.b = (u64)__shfl((unsigned long long)incl.b, 63, WAVE);
+    return tot;
+}
+
 // =====================================================================================================================
 //  compress side
 // =====================================================================================================================
 // serial tANS coder of the weights (lane g): FSE_compress_usingCTable on the small table (lib/fse_compress.c:554-611);
-// returns the payload size (0 = does not fit / not worth it) by BIT_closeCStream's rule (lib/bitstream.h:254-260)
-DEV u32 hp_encode_weights(u8* out, long cap, const u8* nbSym, u32 n, u32 huffLog, const u16* st, const u32* tt, u32 tl)
+// returns the payload size (0 = does not fit / not worth it) by BIT_closeCStream's rule (lib/bitstream.h:254-260).
+// ent[s] = coder entry of symbol s's weight, prepared by the wide phase: low half (maxBitsOut << 8) - minStatePlus (so that
+// nbBits = (state + low) >> 8: states are below 128), high half deltaFindState (signed).  The two chains are independent:
+// one step of each per iteration, so that their table look-ups overlap.
+DEV u32 hp_encode_weights(u8* out, long cap, const u32* ent, u32 n, const u16* st, u32 tl)
 {
     if (n <= 2 || cap <= 8) return 0;
-#define HP_W(s) ((u32)(nbSym[s] ? huffLog + 1 - nbSym[s] : 0))
     u32 ch[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const u32 w = HP_W(n - 1 - j), dfs = tt[2 * w], dnb = tt[2 * w + 1];
-        const u32 nbo = (dnb + (1u << 15)) >> 16;
-        ch[j] = st[(((nbo << 16) - dnb) >> nbo) + dfs];
+    for (int j = 0; j < 2; ++j) {                                        // FSE_initCState2 (fse.h:503-512): starts at minStatePlus, no bits
+        const u32 e = ent[n - 1 - j];
+        const int lo = (int)(s16)(e & 0xFFFFu), dfs = (int)e >> 16;
+        const u32 mbo = (u32)(lo + 255) >> 8, msp = (mbo << 8) - (u32)lo;
+        ch[j] = st[(int)(msp >> mbo) + dfs];
     }
     u64 acc = 0; u32 nacc = 0, pos = 0, total = 0;
-    for (u32 j = 2; j < n; ++j) {
-        const u32 w = HP_W(n - 1 - j), dfs = tt[2 * w], dnb = tt[2 * w + 1];
-        const u32 x = ch[j & 1];
-        const u32 nb = (x + dnb) >> 16;
-        acc |= (u64)(x & ((1u << nb) - 1u)) << nacc; nacc += nb; total += nb;
-        ch[j & 1] = st[(x >> nb) + dfs];
+#define HP_STEP(c, e)                                                                              \
+    {   const u32 x = ch[c];                                                                       \
+        const u32 nb = (u32)((int)x + (int)(s16)((e) & 0xFFFFu)) >> 8;                               \
+        acc |= (u64)(x & ((1u << nb) - 1u)) << nacc; nacc += nb; total += nb;                      \
+        ch[c] = st[(int)(x >> nb) + ((int)(e) >> 16)]; }
+    u32 j = 2;
+    for (; j + 1 < n; j += 2) {                                          // j even: chain 0 then chain 1
+        const u32 e0 = ent[n - 1 - j], e1 = ent[n - 2 - j];
+        HP_STEP(0, e0) HP_STEP(1, e1)
         while (nacc >= 8) { if ((long)pos < cap) out[pos] = (u8)acc; ++pos; acc >>= 8; nacc -= 8; }
     }
-#undef HP_W
+    if (j < n) { const u32 e0 = ent[n - 1 - j]; HP_STEP(0, e0) }
+#undef HP_STEP
     const u32 c2 = (n & 1u) ? ch[1] : ch[0], c1 = (n & 1u) ? ch[0] : ch[1];
     acc |= (u64)(c2 & ((1u << tl) - 1u)) << nacc; nacc += tl;
+    while (nacc >= 8) { if ((long)pos < cap) out[pos] = (u8)acc; ++pos; acc >>= 8; nacc -= 8; }
     acc |= (u64)(c1 & ((1u << tl) - 1u)) << nacc; nacc += tl;
     acc |= (u64)1 << nacc; nacc += 1;
     total += 2 * tl + 1;
@@ -159,7 +211,8 @@ DEV u32 hp_encode_weights(u8* out, long cap, const u8* nbSym, u32 n, u32 huffLog
     return (total + 7) >> 3;
 }
 
-// two-queue merge (lane g): leaves keys[0 .. L-1] descending; records parents only
+// two-queue merge (lane g): leaves keys[0 .. L-1] descending; records parents only.  Branch-free picks (the lanes of the wave
+// work on different blocks), both queue heads re-read after every pick (one LDS round trip).
 DEV void hp_merge(const u32* keys, u32* icnt, u8* par, u32 L)
 {
     const u32 NO_LEAF = 1u << 31, NO_NODE = 1u << 30;                     // exhausted / not yet created: never the smaller one
@@ -170,29 +223,24 @@ DEV void hp_merge(const u32* keys, u32* icnt, u8* par, u32 L)
         u32 sum = 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if (leaf < node) { sum += leaf; par[li] = (u8)ni; --li; leaf = li >= 0 ? keys[li] >> 9 : NO_LEAF; }
-            else { sum += node; par[256 + ii] = (u8)ni; ++ii; node = ii < ni ? icnt[ii] : NO_NODE; }
+            const bool takeLeaf = leaf < node;                             // ties go to the internal queue
+            sum += takeLeaf ? leaf : node;
+            par[takeLeaf ? (u32)li : 256u + ii] = (u8)ni;
+            li -= takeLeaf ? 1 : 0; ii += takeLeaf ? 0u : 1u;
+            const u32 lk = keys[li > 0 ? li : 0], nk = icnt[ii & 255u];
+            leaf = li >= 0 ? lk >> 9 : NO_LEAF;
+            node = ii < ni ? nk : NO_NODE;
         }
         icnt[ni] = sum;
-        if (ii == ni) node = sum;
+        node = ii == ni ? sum : node;
     }
 }
 
-// height limit (lane g): nb[] lengths by rank (non-decreasing), keys give the counts.  Returns the final maximum length.
-DEV u32 hp_limit_height(u8* nb, const u32* keys, u16* last, u32 L, u32 M)
+// height limit, repair part (lane g).  The wide phase has cut the overlong leaves to the limit M, computed the Kraft debt (in
+// units of 2^-M) and the class boundaries: last[k] = last rank of length M - k (NONE if empty), n = last rank shorter than M.
+DEV void hp_repair_lengths(u8* nb, const u32* keys, u16* last, int n, int debt, u32 M)
 {
-    const u32 largest = nb[L - 1];
-    if (largest <= M) return largest;
     const u32 NONE = 0xFFFFu;
-    int debt = 0;
-    for (u32 k = 0; k < HUF_MAX_TL + 2; ++k) last[k] = (u16)NONE;
-    int n = -1;
-    for (u32 r = 0; r < L; ++r) {                                         // ranks ascend: the last write of a class is its last leaf
-        const u32 d = nb[r];
-        if (d > M) { debt += (int)((1u << (largest - M)) - (1u << (largest - d))); nb[r] = (u8)M; }
-        else if (d < M) { last[M - d] = (u16)r; n = (int)r; }
-    }
-    debt >>= (largest - M);                                               // in units of 2^-M
     while (debt > 0) {
         u32 k = hibit32((u32)debt) + 1;                                   // a leaf leaving class k pays 2^(k-1)
         for (; k > 1; --k) {                                              // a cheaper class if its last leaf is rare enough
@@ -219,16 +267,27 @@ DEV u32 hp_limit_height(u8* nb, const u32* keys, u16* last, u32 L, u32 M)
         }
         ++debt;
     }
-    return M;
 }
 
+enum { SC_DEBT = SC_RESULT_LO, SC_NLAST = SC_RESULT_HI };                 // (the result words are free until phase E)
+
+template <int G_>
 __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
 {
+    constexpr u32 HP_G = G_, HP_GL = 64 / G_;      // blocks per wave; lanes per block when all blocks are worked on at once
     extern __shared__ __attribute__((aligned(16))) u8 hpLds[];
     const u32 lane = threadIdx.x;
     const size_t b0 = (size_t)blockIdx.x * HP_G;
+    HPT_DECL
 
-    // ---- phase A (wide, block after block): early outs, table log, sorted keys
+    // ---- phase A (wide, block after block): early outs, table log, sorted keys.  All global loads are issued up front.
+    uint4 cvAll[HP_G]; size_t topAll[HP_G]; u32 msvAll[HP_G];
+#pragma unroll
+    for (u32 g = 0; g < HP_G; ++g) {
+        const size_t b = b0 + g < a.nBlocks ? b0 + g : a.nBlocks - 1;
+        cvAll[g] = ((const uint4*)(a.counts + b * 256))[lane]; topAll[g] = a.histResults[b]; msvAll[g] = a.maxSVs[b];
+    }
+#pragma unroll
     for (u32 g = 0; g < HP_G; ++g) {
         u8* const slot = hpLds + g * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
@@ -236,7 +295,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         if (b >= a.nBlocks) { if (lane == 0) sc[SC_STATE] = 0; continue; }  // uniform
         const size_t n = view_size(a.src, b);
         size_t result = 0; bool go = false;
-        const size_t top = a.histResults[b];
+        const size_t top = topAll[g];
         if (!n || !a.dstCapacity) result = 0;                              // huf_compress.c:656-657
         else if (n > FSEHIP_HUF_BLOCKSIZE_MAX) result = FERR(srcSize_wrong);
         else if (is_err(top)) result = top;
@@ -247,16 +306,16 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
             if (lane == 0) { sc[SC_STATE] = 0; HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0; a.meta[b] = m; a.results[b] = result; }
             continue;
         }
-        const u32 maxSV = a.maxSVs[b];
+        const u32 maxSV = msvAll[g];
         const u32 huffLog = wg_optimal_tablelog(a.huffLogReq ? a.huffLogReq : HUF_DEF_TL, n, maxSV, 1);   // :691
-        const uint4 cv = ((const uint4*)(a.counts + b * 256))[lane];
+        const uint4 cv = cvAll[g];
         u32 k[4] = { cv.x, cv.y, cv.z, cv.w };
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const u32 s = 4 * lane + i; k[i] = (s <= maxSV && k[i]) ? (k[i] << 9) | (1u << 8) | (255u - s) : 0u; }
         u32 present = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) present += k[i] != 0;
-        present = wg_sum(present);
+        present = wg_sum<64>(present);
         if (maxSV < 64) {                                                  // uniform: one key per lane is enough
             // symbols 0..63 sit four per lane in lanes 0..15: bring symbol `lane` to lane `lane`
             u32 one[1];
@@ -273,6 +332,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         if (lane == 0) { sc[SC_STATE] = 1; sc[SC_MAXSV] = maxSV; sc[SC_LOG] = huffLog; sc[SC_LEAVES] = present; }
     }
     __syncthreads();
+    HPT_MARK
 
     // ---- phase B (serial, lane g on block g): the tree
     if (lane < HP_G) {
@@ -281,13 +341,15 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         if (sc[SC_STATE]) hp_merge((const u32*)(slot + HP_KEYS), (u32*)(slot + HP_ICNT), slot + HP_PAR, sc[SC_LEAVES]);
     }
     __syncthreads();
+    HPT_MARK
 
-    // ---- phase C (wide): leaf depths by chasing the parent links
+    // ---- phase C (wide): leaf depths by chasing the parent links; when the tree is too high, the cut to the limit, its debt
+    //      and the class boundaries for the repair
     for (u32 g = 0; g < HP_G; ++g) {
         u8* const slot = hpLds + g * HP_SLOT;
-        const u32* const sc = (const u32*)(slot + HP_SCAL);
+        u32* const sc = (u32*)(slot + HP_SCAL);
         if (!sc[SC_STATE]) continue;                                       // uniform
-        const u32 L = sc[SC_LEAVES], root = L - 2;
+        const u32 L = sc[SC_LEAVES], root = L - 2, M = sc[SC_LOG];
         const u8* const par = slot + HP_PAR;
         u32 p[4], d[4];
 #pragma unroll
@@ -298,20 +360,54 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
             for (int i = 0; i < 4; ++i) if (p[i] != root) { p[i] = par[256 + p[i]]; ++d[i]; more = true; }
             if (!__any(more)) break;
         }
+        u32 deepest = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u32 r = lane + 64u * i; if (r < L) deepest = d[i] > deepest ? d[i] : deepest; }
+        const u32 largest = wg_max<64>(deepest);                           // = depth of the last leaf
+        int debt = 0;
+        if (largest > M) {                                                 // uniform
+            // classes of equal length are contiguous runs of ranks in ascending length: class counts give the boundaries
+            Pk cnt = { 0, 0 };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 r = lane + 64u * i;
+                if (r >= L) continue;
+                if (d[i] > M) { debt += (int)((1u << (largest - M)) - (1u << (largest - d[i]))); d[i] = M; }
+                pk_add(cnt, d[i]);
+            }
+            debt = (int)wg_sum<64>((u32)debt) >> (largest - M);
+            cnt.a = wg_sum64<64>(cnt.a); cnt.b = wg_sum64<64>(cnt.b);
+            u16* const last = (u16*)(slot + HP_LAST);
+            u32 upTo = 0, shorter = 0;                                     // ranks with length <= len / < M
+            for (u32 len = 1; len <= M; ++len) {                           // uniform
+                const u32 c = pk_get(cnt, len);
+                upTo += c;
+                if (len < M) { shorter = upTo; if (lane == 0) last[M - len] = (u16)(c ? upTo - 1 : 0xFFFFu); }
+            }
+            if (lane == 0) { last[0] = 0xFFFFu; for (u32 k = M; k < HUF_MAX_TL + 2; ++k) last[k] = 0xFFFFu; sc[SC_NLAST] = shorter - 1u; sc[SC_DEBT] = (u32)debt; sc[SC_LOG] = M | 0x100u; }
+        } else if (lane == 0) sc[SC_LOG] = largest;                        // the tree fits: its height is the table log
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const u32 r = lane + 64u * i; if (r < L) slot[HP_NBRANK + r] = (u8)d[i]; }
     }
     __syncthreads();
+    HPT_MARK
 
-    // ---- phase D (serial): height limit
+    // ---- phase D (serial): repair of the cut lengths
     if (lane < HP_G) {
         u8* const slot = hpLds + lane * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
-        if (sc[SC_STATE]) sc[SC_LOG] = hp_limit_height(slot + HP_NBRANK, (const u32*)(slot + HP_KEYS), (u16*)(slot + HP_LAST), sc[SC_LEAVES], sc[SC_LOG]);
+        if (sc[SC_STATE] && (sc[SC_LOG] & 0x100u)) {
+            const u32 M = sc[SC_LOG] & 0xFFu;
+            hp_repair_lengths(slot + HP_NBRANK, (const u32*)(slot + HP_KEYS), (u16*)(slot + HP_LAST), (int)sc[SC_NLAST], (int)sc[SC_DEBT], M);
+            sc[SC_LOG] = M;
+        }
     }
     __syncthreads();
+    HPT_MARK
 
-    // ---- phase E (wide): lengths by symbol, canonical values, CElt table; weight statistics and the small tANS table
+    // ---- phase E1 (wide): lengths by symbol, canonical values, CElt table; weight statistics into the lanes of group g
+    u32 cw[4] = { 0, 0, 0, 0 };                                            // lanes 8g .. 8g+7: counts of weights 4*sub .. 4*sub+3 of block g
+    u32 wTop = 0, wMax = 0;
     for (u32 g = 0; g < HP_G; ++g) {
         u8* const slot = hpLds + g * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
@@ -320,6 +416,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         const u32 L = sc[SC_LEAVES], maxSV = sc[SC_MAXSV], huffLog = sc[SC_LOG];
         u8* const nbSym = slot + HP_NBSYM;
         ((u32*)nbSym)[lane] = 0;
+        {   u32* const img = (u32*)(slot + HP_HDR); for (u32 i = lane; i < 72; i += 64) img[i] = 0; }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -328,107 +425,124 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         }
         __syncthreads();
         const u32 w4 = ((const u32*)nbSym)[lane];                          // lengths of symbols 4*lane .. 4*lane+3
-        u32 nb[4], val[4];
+        u32 nb[4], cls[4], rank[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { nb[i] = (w4 >> (8 * i)) & 0xFFu; val[i] = 0; }
-        // per length: how many symbols (start values, huf_compress.c:394-400) and my rank among them (symbol order).
-        // Absent symbols (length 0) are numbered too, as the reference does.
-        u32 start = 0, carry = 0;
-        for (int len = (int)huffLog; len >= 0; --len) {                    // uniform
-            u32 cntLen = 0;
-            unsigned long long m[4];
+        for (int i = 0; i < 4; ++i) { nb[i] = (w4 >> (8 * i)) & 0xFFu; cls[i] = 4 * lane + i <= maxSV ? nb[i] : 15u; }
+        // per length: how many symbols and my rank among them in symbol order (absent symbols, length 0, are numbered too, as
+        // the reference does); start values by the usual recurrence (huf_compress.c:394-400)
+        const Pk tot = pk_rank(cls, rank, lane);
+        u32 val[4] = { rank[0], rank[1], rank[2], rank[3] };
+        {   u32 carry = 0;
+            for (u32 len = huffLog; len >= 1; --len) {                     // uniform
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { m[i] = __ballot(nb[i] == (u32)len && 4 * lane + i <= maxSV); cntLen += (u32)__builtin_popcountll(m[i]); }
-            if (len > 0) { start = carry; carry = (carry + cntLen) >> 1; } else start = 0;
-            // rank in symbol order: symbols of lower lanes (all four registers) + lower registers of my lane
-            u32 lowerLanes = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lowerLanes += (u32)__builtin_popcountll(m[i] & hp_below_mask(lane));
-            u32 inLane = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { if (nb[i] == (u32)len && 4 * lane + i <= maxSV) { val[i] = start + lowerLanes + inLane; ++inLane; } }
-        }
-        {   uint4 ce;
-            u32 e[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = 4 * lane + i <= maxSV ? ((val[i] & 0xFFFFu) | (nb[i] << 16)) : 0u;   // zeroed beyond maxSV (:697-699)
-            ce = make_uint4(e[0], e[1], e[2], e[3]);
-            ((uint4*)(a.ctables + b * a.ctStrideU32))[lane] = ce;
-        }
-        // ---- weights (symbols 0 .. maxSV-1; the last one is implied): statistics for the small FSE coder (huf_compress.c:63-103)
-        const u32 wtSize = maxSV;
-        u32 wt[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wt[i] = nb[i] ? huffLog + 1 - nb[i] : 0;
-        u32 cw[4] = { 0, 0, 0, 0 };                                        // my share of the histogram: weights 4*lane .. 4*lane+3
-        u32 topCount = 0, maxW = 0;
-        for (u32 v = 0; v <= HUF_MAX_TL; ++v) {                            // uniform
-            u32 c = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c += (u32)__builtin_popcountll(__ballot(wt[i] == v && 4 * lane + i < wtSize));
-            if (c) maxW = v;
-            topCount = c > topCount ? c : topCount;
-            if ((v >> 2) == lane) cw[v & 3] = c;
-        }
-        u32 hs = 0;                                                        // size of the FSE-coded weights (0 / 1 = not usable)
-        u32 wtl = 0; bool tableReady = false;
-        size_t err = 0;
-        u32* const img = (u32*)(slot + HP_HDR);
-        for (u32 i = lane; i < 72; i += 64) img[i] = 0;
-        __syncthreads();
-        const long wcap = (long)a.dstCapacity - 1;                         // HUF_compressWeights(op + 1, maxDstSize - 1, ...)
-        u32 ncBytes = 0;
-        if (wtSize > 1) {
-            if (topCount == wtSize) hs = 1;
-            else if (topCount == 1) hs = 0;
-            else {
-                wtl = wg_optimal_tablelog(6, wtSize, maxW, 2);
-                int nn[4];
-                size_t e = wg_normalize(nn, cw, (u64)wtSize, maxW, wtl, lane);
-                if (!is_err(e)) e = wg_write_ncount(img + 1, (size_t)(wcap < 0 ? 0 : wcap), nn, maxW, wtl, lane);   // image byte 4.. = header byte 1..
-                if (is_err(e)) err = e;
-                else {
-                    ncBytes = (u32)e;
-                    if (lane < 4) *(uint2*)(slot + HP_NRM + 8 * lane) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
-                    __syncthreads();
-                    const s16* const nrm = (const s16*)(slot + HP_NRM);
-                    u16* const st = (u16*)(slot + HP_ST);
-                    u32* const tt = (u32*)(slot + HP_TT);
-                    const u32 ts = 1u << wtl;
-                    hp_small_table(slot + HP_CELL, maxW, wtl, lane, [&](u32 s) { return (int)nrm[s]; },
-                                   [&](u32 u, u32 s, u32 r, u32 first, int n) { (void)s; (void)n; st[first + r] = (u16)(ts + u); });
-                    // per-symbol transforms (lib/fse_compress.c:136-166), lane s <= maxW
-                    if (lane <= maxW) {
-                        int total = 0;
-                        for (u32 s = 0; s < lane; ++s) { const int n = nrm[s]; total += n == -1 ? 1 : n; }
-                        const int n = nrm[lane];
-                        u32 dfs = 0, dnb = ((wtl + 1) << 16) - ts;
-                        if (n == -1 || n == 1) { dfs = (u32)(total - 1); dnb = (wtl << 16) - ts; }
-                        else if (n > 1) { const u32 mbo = wtl - hibit32((u32)n - 1); dfs = (u32)(total - n); dnb = (mbo << 16) - ((u32)n << mbo); }
-                        tt[2 * lane] = dfs; tt[2 * lane + 1] = dnb;
-                    }
-                    tableReady = true;
-                }
+                for (int i = 0; i < 4; ++i) if (nb[i] == len) val[i] += carry;
+                carry = (carry + pk_get(tot, len)) >> 1;
             }
         }
-        if (lane == 0) { sc[SC_HDR] = hs; sc[SC_AUX] = (tableReady ? 1u : 0u) | (wtl << 8) | (ncBytes << 16); sc[SC_RESULT_LO] = (u32)err; sc[SC_RESULT_HI] = (u32)(err >> 32); }
-        __syncthreads();
+        {   u32 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = 4 * lane + i <= maxSV ? ((val[i] & 0xFFFFu) | (nb[i] << 16)) : 0u;   // zeroed beyond maxSV (:697-699)
+            ((uint4*)(a.ctables + b * a.ctStrideU32))[lane] = make_uint4(e[0], e[1], e[2], e[3]);
+        }
+        // weights (symbols 0 .. maxSV-1; the last one is implied): weight v has the symbols of length huffLog + 1 - v, less the
+        // last symbol; statistics for the small FSE coder (huf_compress.c:63-103)
+        const u32 lastNb = (u32)nbSym[maxSV];
+        u32 top = 0, mw = 0;
+        for (u32 v = 0; v <= huffLog; ++v) {                               // uniform
+            const u32 len = v ? huffLog + 1 - v : 0;
+            const u32 c = pk_get(tot, len) - (len == lastNb ? 1u : 0u);
+            if (c) mw = v;
+            top = c > top ? c : top;
+        }
+        if ((lane / HP_GL) == g) {
+            const u32 sub = lane % HP_GL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 v = 4 * sub + i;
+                const u32 len = v ? huffLog + 1 - v : 0;
+                cw[i] = v <= huffLog ? pk_get(tot, len) - (len == lastNb ? 1u : 0u) : 0u;
+            }
+            wTop = top; wMax = mw;
+        }
     }
     __syncthreads();
+    HPT_MARK
+
+    // ---- phase E2 (all blocks of the wave at once, 64 / G lanes per block): table log, counters and NCount header of the weights
+    {   const u32 g = lane / HP_GL, sub = lane % HP_GL;
+        u8* const slot = hpLds + g * HP_SLOT;
+        u32* const sc = (u32*)(slot + HP_SCAL);
+        if (sc[SC_STATE]) {                                                // uniform per group
+            const u32 wtSize = sc[SC_MAXSV];
+            u32 hs = 0, wtl = 0, ncBytes = 0; bool tableReady = false; size_t err = 0;
+            if (wtSize > 1) {
+                if (wTop == wtSize) hs = 1;                                // one weight only: not worth coding
+                else if (wTop == 1) hs = 0;
+                else {
+                    wtl = wg_optimal_tablelog(6, wtSize, wMax, 2);
+                    int nn[4];
+                    const long wcap = (long)a.dstCapacity - 1;             // HUF_compressWeights(op + 1, maxDstSize - 1, ...)
+                    size_t e = wg_normalize<HP_GL>(nn, cw, (u64)wtSize, wMax, wtl, lane);
+                    if (!is_err(e)) e = wg_write_ncount<HP_GL>((u32*)(slot + HP_HDR) + 1, (size_t)(wcap < 0 ? 0 : wcap), nn, wMax, wtl, lane);   // image byte 4.. = header byte 1..
+                    if (is_err(e)) err = e;
+                    else {
+                        ncBytes = (u32)e; tableReady = true;
+                        if (sub < 4) *(uint2*)(slot + HP_NRM + 8 * sub) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
+                    }
+                }
+            }
+            if (sub == 0) { sc[SC_HDR] = hs; sc[SC_AUX] = (tableReady ? 1u : 0u) | (wtl << 8) | (ncBytes << 16) | (wMax << 24); sc[SC_RESULT_LO] = (u32)err; sc[SC_RESULT_HI] = (u32)(err >> 32); }
+        }
+    }
+    __syncthreads();
+    HPT_MARK
+
+    // ---- phase E3 (wide): the small tANS table of the weights and the per-symbol coder entries
+    for (u32 g = 0; g < HP_G; ++g) {
+        u8* const slot = hpLds + g * HP_SLOT;
+        const u32* const sc = (const u32*)(slot + HP_SCAL);
+        if (!sc[SC_STATE] || !(sc[SC_AUX] & 1u)) continue;                 // uniform
+        const u32 wtl = (sc[SC_AUX] >> 8) & 0xFFu, maxW = (sc[SC_AUX] >> 24) & 0xFFu, ts = 1u << wtl;
+        const u32 maxSV = sc[SC_MAXSV], huffLog = sc[SC_LOG];
+        const s16* const nrm = (const s16*)(slot + HP_NRM);
+        u16* const st = (u16*)(slot + HP_ST);
+        u32* const tt = (u32*)(slot + HP_TT);
+        hp_small_table(slot + HP_CELL, maxW, wtl, lane, [&](u32 s) { return (int)nrm[s]; },
+                       [&](u32 u, u32 s, u32 r, u32 first, int n) { (void)s; (void)n; st[first + r] = (u16)(ts + u); });
+        // per-weight transforms (lib/fse_compress.c:136-166) packed for the serial coder, lane w <= maxW
+        if (lane <= maxW) {
+            int total = 0;
+            for (u32 s = 0; s < lane; ++s) { const int n = nrm[s]; total += n == -1 ? 1 : n; }
+            const int n = nrm[lane];
+            int dfs = 0; u32 mbo = wtl + 1, msp = ts;                      // absent weight: never used
+            if (n == -1 || n == 1) { dfs = total - 1; mbo = wtl; msp = ts; }
+            else if (n > 1) { mbo = wtl - hibit32((u32)n - 1); dfs = total - n; msp = (u32)n << mbo; }
+            tt[lane] = (((mbo << 8) - msp) & 0xFFFFu) | ((u32)dfs << 16);
+        }
+        __syncthreads();
+        {   const u32 w4 = ((const u32*)(slot + HP_NBSYM))[lane];
+            u32 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const u32 nbv = (w4 >> (8 * i)) & 0xFFu; e[i] = tt[nbv ? huffLog + 1 - nbv : 0]; }
+            if (4 * lane < maxSV) ((uint4*)(slot + HP_ICNT))[lane] = make_uint4(e[0], e[1], e[2], e[3]);
+        }
+    }
+    __syncthreads();
+    HPT_MARK
 
     // ---- phase F (serial): the weights through the small coder
     if (lane < HP_G) {
         u8* const slot = hpLds + lane * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
         if (sc[SC_STATE] && (sc[SC_AUX] & 1u)) {
-            const u32 wtl = (sc[SC_AUX] >> 8) & 0xFFu, ncBytes = sc[SC_AUX] >> 16;
+            const u32 wtl = (sc[SC_AUX] >> 8) & 0xFFu, ncBytes = (sc[SC_AUX] >> 16) & 0xFFu;
             const long wcap = (long)a.dstCapacity - 1 - (long)ncBytes;
-            const u32 cs = hp_encode_weights(slot + HP_HDR + 4 + ncBytes, wcap, slot + HP_NBSYM, sc[SC_MAXSV], sc[SC_LOG],
-                                             (const u16*)(slot + HP_ST), (const u32*)(slot + HP_TT), wtl);
+            const u32 cs = hp_encode_weights(slot + HP_HDR + 4 + ncBytes, wcap, (const u32*)(slot + HP_ICNT), sc[SC_MAXSV], (const u16*)(slot + HP_ST), wtl);
             sc[SC_HDR] = cs ? ncBytes + cs : 0;
         }
     }
     __syncthreads();
+    HPT_MARK
 
     // ---- phase G (wide): header out (FSE-coded weights, or 4 bits per weight), final checks, meta
     for (u32 g = 0; g < HP_G; ++g) {
@@ -466,6 +580,8 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         }
         if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; }
     }
+    HPT_MARK
+    HPT_DUMP(0)
 }
 
 // =====================================================================================================================
@@ -498,22 +614,30 @@ DEV size_t hp_decode_weights(u8* w, long omax, const u8* in, size_t n, const u32
     return (size_t)op;
 }
 
-// decode-side slot: counters of the weights' header (s16[256]) at HP_KEYS, symbols sorted by weight (u8[256]) at HP_KEYS + 512,
-// weights by symbol (u8[256 + 4]) at HP_ICNT, small DTable cells u32[64] at HP_ST (spans ST, TT)
+// decode-side slot: counters of the weights' NCount header (s16[256]) at HP_KEYS, symbols sorted by (weight, symbol) (u8[256]) at
+// HP_KEYS + 512, weights by symbol (u8[256 + 4]) at HP_ICNT, small DTable cells u32[64] at HP_ST (spans ST, TT), the FSE-coded
+// weights themselves (<= 127 bytes, copied from the block so that the serial decoder reads LDS) at HP_HDR, first cell / first
+// sorted position of every weight class (u16[16] each) at HP_LAST / HP_NRM
 #define HD_NORM   HP_KEYS
 #define HD_SORTED (HP_KEYS + 512)
 #define HD_WGT    HP_ICNT
 #define HD_CELLS  HP_ST
+#define HD_BYTES  HP_HDR
+#define HD_CSTART HP_LAST
+#define HD_CBASE  HP_NRM
 enum { DS_STATE = 0, DS_HDR, DS_NSYM, DS_FSE, DS_RESULT_LO, DS_RESULT_HI, DS_AUX, DS_CLS };   // DS_STATE: 0 done, 1 table pending, 2 raw copy, 3 rle fill
 
+template <int G_>
 __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
 {
+    constexpr u32 HP_G = G_;
     extern __shared__ __attribute__((aligned(16))) u8 hpLds[];
     const u32 lane = threadIdx.x;
     const size_t b0 = (size_t)blockIdx.x * HP_G;
+    HPT_DECL
 
     // ---- phase A (serial, lane g): HUF_decompress's raw / RLE decisions, the weights' header (4-bit weights are unpacked here,
-    //      FSE-coded ones get their NCount header parsed)
+    //      FSE-coded ones are copied into LDS and get their NCount header parsed)
     if (lane < HP_G) {
         u8* const slot = hpLds + lane * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
@@ -539,8 +663,12 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
                     }
                 } else if ((size_t)first + 1 > cSize) result = FERR(srcSize_wrong);
                 else {                                                     // FSE-coded: FSE_decompress_wksp(weights, 255, in + 1, first, .., 6)
+                    u8* const copy = slot + HD_BYTES;
+                    u32 i = 0;
+                    for (; i + 4 <= first; i += 4) { u32 v; __builtin_memcpy(&v, in + 1 + i, 4); *(u32*)(copy + i) = v; }
+                    for (; i < first; ++i) copy[i] = in[1 + i];
                     u32 tl = 0, maxSV = 255;
-                    const size_t h = ncount_read<1>((s16*)(slot + HD_NORM), &maxSV, &tl, in + 1, first);
+                    const size_t h = ncount_read<1>((s16*)(slot + HD_NORM), &maxSV, &tl, copy, first);
                     if (is_err(h)) result = h;
                     else if (tl > 6) result = FERR(tableLog_tooLarge);
                     else { state = 1; sc[DS_FSE] = 1u | (tl << 8) | (maxSV << 16); sc[DS_HDR] = first + 1; sc[DS_AUX] = (u32)h; }
@@ -550,6 +678,7 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
         sc[DS_STATE] = state; sc[DS_RESULT_LO] = (u32)result; sc[DS_RESULT_HI] = (u32)(result >> 32);
     }
     __syncthreads();
+    HPT_MARK
 
     // ---- phase B (wide): small decoding table of the FSE-coded weights (FSE_buildDTable, lib/fse_decompress.c:71-126)
     for (u32 g = 0; g < HP_G; ++g) {
@@ -573,21 +702,21 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
         __syncthreads();
     }
     __syncthreads();
+    HPT_MARK
 
     // ---- phase C (serial): the weights themselves
     if (lane < HP_G) {
         u8* const slot = hpLds + lane * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
         if (sc[DS_STATE] == 1 && (sc[DS_FSE] & 1u)) {
-            const size_t b = b0 + lane;
-            const u8* const in = view_ptr(a.csrc, b);
             const u32 first = sc[DS_HDR] - 1, h = sc[DS_AUX];
-            const size_t nW = hp_decode_weights(slot + HD_WGT, 255, in + 1 + h, first - h, (const u32*)(slot + HD_CELLS), (sc[DS_FSE] >> 8) & 0xFFu, (sc[DS_FSE] & 2u) != 0);
+            const size_t nW = hp_decode_weights(slot + HD_WGT, 255, slot + HD_BYTES + h, first - h, (const u32*)(slot + HD_CELLS), (sc[DS_FSE] >> 8) & 0xFFu, (sc[DS_FSE] & 2u) != 0);
             if (is_err(nW)) { sc[DS_STATE] = 0; sc[DS_RESULT_LO] = (u32)nW; sc[DS_RESULT_HI] = (u32)(nW >> 32); }
             else sc[DS_NSYM] = (u32)nW;
         }
     }
     __syncthreads();
+    HPT_MARK
 
     // ---- phase D (wide): weight statistics, implied last weight, the X1 table; raw / RLE blocks are copied here
     for (u32 g = 0; g < HP_G; ++g) {
@@ -603,10 +732,9 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             u8* const dst = a.dst + b * a.dstStride;
             const size_t dstSize = view_size(a.dstSizes, b);
             const u32 fill = (u32)in[0] * 0x01010101u;
-            size_t i = 0;
             const size_t head = dstSize < 4 ? dstSize : (size_t)((0 - (uintptr_t)dst) & 3u);
             if (lane < head) dst[lane] = state == 2 ? in[lane] : (u8)fill;
-            for (i = head + 4 * (size_t)lane; i + 4 <= dstSize; i += 256) {
+            for (size_t i = head + 4 * (size_t)lane; i + 4 <= dstSize; i += 256) {
                 u32 v = fill;
                 if (state == 2) __builtin_memcpy(&v, in + i, 4);
                 *(u32*)(dst + i) = v;
@@ -615,15 +743,14 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             if (done + lane < dstSize) dst[done + lane] = state == 2 ? in[done + lane] : (u8)fill;
         } else if (state == 1) {
             const u32 nW = sc[DS_NSYM];                                    // weights read; the last symbol's is implied
-            const u8* const w = slot + HD_WGT;
             u32 wt[4];
-            {   const u32 w4 = ((const u32*)w)[lane];
+            {   const u32 w4 = ((const u32*)(slot + HD_WGT))[lane];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wt[i] = 4 * lane + i < nW ? (w4 >> (8 * i)) & 0xFFu : 0xFFu; }
             bool bad = false; u32 mass = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (wt[i] != 0xFFu) { bad |= wt[i] >= HUF_MAX_TL; mass += (1u << (wt[i] & 15u)) >> 1; }
-            mass = wg_sum(mass);
+            mass = wg_sum<64>(mass);
             size_t err = 0;
             u32 tl = 0, lastW = 0;
             if (__any(bad) || mass == 0) err = FERR(corruption_detected);   // entropy_common.c:188-192
@@ -636,45 +763,51 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             if (!err) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (4 * lane + i == nW) wt[i] = lastW;
-                // per weight: how many symbols, where its cells start; my rank among the symbols of the same weight
-                u32 cnt1 = 0;
-                u32 cellStart[4] = { 0, 0, 0, 0 };
-                u32 next = 0;
-                for (u32 v = 1; v <= tl; ++v) {                            // uniform
-                    unsigned long long mk[4]; u32 c = 0;
+                // class = weight: symbols per weight and my rank among the symbols of the same weight (symbol order)
+                u32 cls[4], rank[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { mk[i] = __ballot(wt[i] == v); c += (u32)__builtin_popcountll(mk[i]); }
-                    if (v == 1) cnt1 = c;
-                    u32 lowerLanes = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) lowerLanes += (u32)__builtin_popcountll(mk[i] & hp_below_mask(lane));
-                    u32 inLane = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (wt[i] == v) { cellStart[i] = next + ((lowerLanes + inLane) << (v - 1)); ++inLane; }
-                    next += c << (v - 1);
-                }
+                for (int i = 0; i < 4; ++i) cls[i] = wt[i] == 0xFFu ? 15u : wt[i];
+                const Pk tot = pk_rank(cls, rank, lane);
+                const u32 cnt1 = pk_get(tot, 1);
                 if (cnt1 < 2 || (cnt1 & 1u)) err = FERR(corruption_detected);   // entropy_common.c:208
                 else if (tl > (HUF_MAX_TL - 1) + 1) err = FERR(tableLog_tooLarge);   // DTable of HUF_CREATE_STATIC_DTABLEX1(.., HUF_TABLELOG_MAX)
                 else {
-                    // X1 cells {byte, nbBits} (huf_decompress.c:158-183): symbol n owns (1 << w) >> 1 consecutive cells
-                    u32* const dt = a.dtables + b * a.dtStrideU32;
-                    u16* const cells = (u16*)(dt + 1);
-                    // long runs are written by the whole wave (coalesced), short ones by their own lane
+                    // X1 cells {byte, nbBits} (huf_decompress.c:158-183): symbol n owns (1 << w) >> 1 consecutive cells, the symbols of
+                    // a weight follow each other in symbol order, the weights in ascending order.  Restated by cell: the symbols are
+                    // ranked by (weight, symbol) into a list; a cell finds its weight class from the class starts and its symbol
+                    // by position -- every lane fills its own cells, two per 4-byte store.
+                    u16* const cstart = (u16*)(slot + HD_CSTART);           // first cell of every weight class (tl + 2 entries)
+                    u16* const cbase = (u16*)(slot + HD_CBASE);             // first list position of every weight class
+                    u8* const sorted = slot + HD_SORTED;
+                    u32 myStart[4] = { 0, 0, 0, 0 };
+                    {   u32 cell = 0, pos = 0;
+                        for (u32 v = 1; v <= tl + 1; ++v) {                // uniform
+                            if (lane == 0) { cstart[v] = (u16)cell; cbase[v] = (u16)pos; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const u32 sym = 4 * lane + i;
-                        const bool on = wt[i] != 0xFFu && wt[i] != 0 && sym <= nW;
-                        const u32 len = on ? (1u << wt[i]) >> 1 : 0;
-                        const u32 cell = sym | ((tl + 1 - (wt[i] & 15u)) << 8);
-                        if (on && len < 64) for (u32 u = 0; u < len; ++u) cells[cellStart[i] + u] = (u16)cell;
-                        unsigned long long wide = __ballot(on && len >= 64);
-                        while (wide) {                                     // uniform
-                            const int src = __builtin_ctzll(wide); wide &= wide - 1;
-                            const u32 s0 = (u32)__shfl((int)cellStart[i], src, WAVE), ln = (u32)__shfl((int)len, src, WAVE);
-                            const u32 cv = (u32)__shfl((int)cell, src, WAVE);
-                            u32* const row = (u32*)(cells + s0);          // (2-byte aligned at worst: fine for global stores)
-                            for (u32 u = lane; u < ln / 2; u += 64) row[u] = cv | (cv << 16);
+                            for (int i = 0; i < 4; ++i) if (cls[i] == v) myStart[i] = pos;
+                            const u32 c = v <= tl ? pk_get(tot, v) : 0;
+                            cell += c << (v - 1); pos += c;
                         }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (cls[i] >= 1 && cls[i] < 14) sorted[myStart[i] + rank[i]] = (u8)(4 * lane + i);
+                    __syncthreads();
+                    u32* const dt = a.dtables + b * a.dtStrideU32;
+                    u32* const out = dt + 1;
+                    const u32 pairs = 1u << (tl - 1);
+                    u32 csr[HUF_MAX_TL + 1];                                // class starts in registers (uniform)
+#pragma unroll
+                    for (u32 t = 2; t <= HUF_MAX_TL; ++t) csr[t] = t <= tl ? (u32)cstart[t] : 0xFFFFu;
+                    for (u32 q = lane; q < pairs; q += 64) {
+                        const u32 u = 2 * q;
+                        u32 v = 1;
+#pragma unroll
+                        for (u32 t = 2; t <= HUF_MAX_TL; ++t) v = u >= csr[t] ? t : v;   // classes ascend with the cell index
+                        const u32 cs = cstart[v], cb = cbase[v], nbits = (tl + 1 - v) << 8;
+                        u32 lo, hi;
+                        if (v == 1) { lo = sorted[cb + (u - cs)]; hi = sorted[cb + (u + 1 - cs)]; }   // one cell per symbol (their number is even)
+                        else lo = hi = sorted[cb + ((u - cs) >> (v - 1))];
+                        out[q] = (lo | nbits) | ((hi | nbits) << 16);
                     }
                     if (lane == 0) dt[0] = ((HUF_MAX_TL - 1) & 0xFFu) | (tl << 16);
                 }
@@ -685,8 +818,11 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             else { m.state = 1; m.hdrSize = hdr; m.tableLog = tl; }
         }
         if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; sc[DS_CLS] = m.state ? (m.tableLog > 11u ? 1u : 0u) : 0xFFFFFFFFu; }
+        __syncthreads();
     }
     __syncthreads();
+    HPT_MARK
+    HPT_DUMP(1)
 
     // ---- append the pending blocks to their decoder-class lists (one atomic per class and wave)
     {   int cls = -1;
@@ -708,7 +844,7 @@ hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* /*unused
 {
     if (a.nBlocks == 0) return hipSuccess;
     probe_before(PK_HUF_CPREP, s);
-    hipLaunchKernelGGL(k_huf_cprep, dim3((unsigned)((a.nBlocks + HP_G - 1) / HP_G)), dim3(64), HP_G * HP_SLOT, s, a);
+    hipLaunchKernelGGL(k_huf_cprep<HP_G_COMPRESS>, dim3((unsigned)((a.nBlocks + HP_G_COMPRESS - 1) / HP_G_COMPRESS)), dim3(64), HP_G_COMPRESS * HP_SLOT, s, a);
     probe_after(PK_HUF_CPREP, s);
     return hipGetLastError();
 }
@@ -717,7 +853,7 @@ hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s)
     if (a.nBlocks == 0) return hipSuccess;
     {   const hipError_t e = hipMemsetAsync(a.counts, 0, HUF_DCLS_COUNT * sizeof(u32), s); if (e != hipSuccess) return e; }
     probe_before(PK_HUF_DPREP, s);
-    hipLaunchKernelGGL(k_huf_dprep, dim3((unsigned)((a.nBlocks + HP_G - 1) / HP_G)), dim3(64), HP_G * HP_SLOT, s, a);
+    hipLaunchKernelGGL(k_huf_dprep<HP_G_DECOMPRESS>, dim3((unsigned)((a.nBlocks + HP_G_DECOMPRESS - 1) / HP_G_DECOMPRESS)), dim3(64), HP_G_DECOMPRESS * HP_SLOT, s, a);
     probe_after(PK_HUF_DPREP, s);
     return hipGetLastError();
 }

@@ -12,7 +12,10 @@
 //     threshold = 2^floor(log2(remaining)), so each lane forms its symbols' (value, nbBits) chunks directly; a run of zero
 //     counters is coded by the lane holding its first zero (its length comes from a suffix-min scan of the non-zero
 //     positions); bit offsets are one more scan and the chunks are OR-ed into an LDS image of the header.
-// All functions are called by all 64 lanes of a wave with wave-uniform scalar arguments.
+// All functions are templated on the group width W (a power of two, 4 .. 64): the wave is split into 64 / W groups of W lanes,
+// each working on its own table (lane `sub` of a group holds symbols 4*sub .. 4*sub+3, so a group covers alphabets of up to
+// 4*W symbols); scalar arguments and results are uniform per group.  W = 64 is one table per wave (the FSE block tables),
+// W = 8 is eight tables at once (the 13-symbol weight alphabets of eight Huffman headers, huf_prep.hip).
 #pragma once
 #include "dev_common.h"
 
@@ -20,52 +23,62 @@
 #define FSE_MAX_TL FSEHIP_FSE_MAX_TABLELOG
 #define FSE_DEF_TL FSEHIP_FSE_DEFAULT_TABLELOG
 
-// ---- wave primitives ---------------------------------------------------------------------------------------------
-DEV u32 wg_sum(u32 v)
+// ---- group primitives -----------------------------------------------------------------------------------------------------
+template <int W> DEV u32 wg_sub(u32 lane) { return lane & (u32)(W - 1); }
+template <int W> DEV u32 wg_sum(u32 v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, WAVE);
+    for (int off = W / 2; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, WAVE);
     return v;
 }
-DEV u64 wg_sum64(u64 v)
+template <int W> DEV u64 wg_sum64(u64 v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += (u64)__shfl_xor((unsigned long long)v, off, WAVE);
+    for (int off = W / 2; off > 0; off >>= 1) v += (u64)__shfl_xor((unsigned long long)v, off, WAVE);
     return v;
 }
-DEV u32 wg_max(u32 v)
+template <int W> DEV u32 wg_max(u32 v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o > v ? o : v; }
+    for (int off = W / 2; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o > v ? o : v; }
     return v;
 }
-DEV u32 wg_min(u32 v)
+template <int W> DEV u32 wg_min(u32 v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o < v ? o : v; }
+    for (int off = W / 2; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o < v ? o : v; }
     return v;
 }
-DEV u32 wg_scan_excl(u32 v, u32 lane)                      // exclusive prefix sum over the lanes
+template <int W> DEV bool wg_any(bool p, u32 lane)          // any lane of my group
 {
+    const unsigned long long m = __ballot(p);
+    if (W == 64) return m != 0;
+    return ((m >> (lane & ~(u32)(W - 1))) & ((1ull << (W & 63)) - 1ull)) != 0;
+}
+template <int W> DEV u32 wg_scan_excl(u32 v, u32 lane)     // exclusive prefix sum over the lanes of my group
+{
+    const u32 sub = wg_sub<W>(lane);
     u32 incl = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    for (int off = 1; off < W; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)sub >= off) incl += o; }
     return incl - v;
 }
-DEV u64 wg_scan_excl64(u64 v, u32 lane)
+template <int W> DEV u64 wg_scan_excl64(u64 v, u32 lane)
 {
+    const u32 sub = wg_sub<W>(lane);
     u64 incl = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const u64 o = (u64)__shfl_up((unsigned long long)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    for (int off = 1; off < W; off <<= 1) { const u64 o = (u64)__shfl_up((unsigned long long)incl, off, WAVE); if ((int)sub >= off) incl += o; }
     return incl - v;
 }
-DEV u32 wg_suffix_min_excl(u32 v, u32 lane)                // min over the lanes above this one (0xFFFFFFFF for lane 63)
+template <int W> DEV u32 wg_suffix_min_excl(u32 v, u32 lane)   // min over the lanes of my group above this one (0xFFFFFFFF for the last)
 {
+    const u32 sub = wg_sub<W>(lane);
     u32 m = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_down((int)m, off, WAVE); if ((int)lane + off < 64) m = o < m ? o : m; }
+    for (int off = 1; off < W; off <<= 1) { const u32 o = (u32)__shfl_down((int)m, off, WAVE); if ((int)sub + off < W) m = o < m ? o : m; }
     const u32 up = (u32)__shfl_down((int)m, 1, WAVE);
-    return lane == 63 ? 0xFFFFFFFFu : up;
+    return sub == (u32)(W - 1) ? 0xFFFFFFFFu : up;
 }
 
 // ---- table log (lib/fse_compress.c:316-342): the largest log the source size supports, not above the request, not below what
@@ -90,8 +103,10 @@ DEV u32 wg_optimal_tablelog(u32 request, size_t srcSize, u32 maxSV, u32 minus)
 // c[i] = count of symbol 4*lane + i (zero beyond maxSV), total = their sum (>= 2, no symbol owns it all).  Leaves the
 // normalised counters in n[i] (-1 = "less than one point") and returns 0, or an error code.
 #define WG_PENDING (-2)
+template <int W>
 DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, u32 lane)
 {
+    const u32 sub = wg_sub<W>(lane);
     const u32 ts = 1u << tl;
     const u32 tiny = (u32)(total >> tl);
     u32 one = (u32)((total * 3) >> (tl + 1));
@@ -99,13 +114,13 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
     u32 given = 0; u64 taken = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const bool in = 4 * lane + i <= maxSV;
+        const bool in = 4 * sub + i <= maxSV;
         if (!in || c[i] == 0) n[i] = 0;
         else if (c[i] <= tiny) { n[i] = -1; ++given; taken += c[i]; }
         else if (c[i] <= one) { n[i] = 1; ++given; taken += c[i]; }
         else n[i] = WG_PENDING;
     }
-    given = wg_sum(given); total -= wg_sum64(taken);
+    given = wg_sum<W>(given); total -= wg_sum64<W>(taken);
     u32 left = ts - given;
     if (left == 0) return FERR(GENERIC);                      // (cannot happen once the table log covers the alphabet)
     if (total / left > one) {                                  // the pending ones would round to zero: widen "about one point"
@@ -113,28 +128,28 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
         u32 g2 = 0; u64 t2 = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (n[i] == WG_PENDING && c[i] <= one) { n[i] = 1; ++g2; t2 += c[i]; }
-        given += wg_sum(g2); total -= wg_sum64(t2);
+        given += wg_sum<W>(g2); total -= wg_sum64<W>(t2);
         left = ts - given;
     }
     if (given == maxSV + 1) {                                  // nothing pending: the first most frequent symbol takes the rest
         u32 best = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) best = c[i] > best ? c[i] : best;
-        best = wg_max(best);
+        best = wg_max<W>(best);
         u32 who = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 3; i >= 0; --i) if (c[i] == best && 4 * lane + i <= maxSV) who = 4 * lane + i;
-        who = wg_min(who);
+        for (int i = 3; i >= 0; --i) if (c[i] == best && 4 * sub + i <= maxSV) who = 4 * sub + i;
+        who = wg_min<W>(who);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (4 * lane + i == who) n[i] += (int)left;
+        for (int i = 0; i < 4; ++i) if (4 * sub + i == who) n[i] += (int)left;
         return 0;
     }
     if (total == 0) {                                          // the rest goes round robin over the one-point symbols:
         u32 mine = 0;                                          // quotient each, one more for the first (rest) of them
 #pragma unroll
         for (int i = 0; i < 4; ++i) mine += n[i] > 0;
-        const u32 P = wg_sum(mine);
-        u32 rank = wg_scan_excl(mine, lane);
+        const u32 P = wg_sum<W>(mine);
+        u32 rank = wg_scan_excl<W>(mine, lane);
         const u32 q = left / P, r = left % P;
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (n[i] > 0) { n[i] += (int)(q + (rank < r)); ++rank; }
@@ -147,7 +162,7 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
     u64 span = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (n[i] == WG_PENDING) span += (u64)c[i] * rstep;
-    u64 run = mid + wg_scan_excl64(span, lane);
+    u64 run = mid + wg_scan_excl64<W>(span, lane);
     bool starved = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -158,11 +173,13 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
         n[i] = (int)(s16)w;
         run = end;
     }
-    return __any(starved) ? FERR(GENERIC) : 0;
+    return wg_any<W>(starved, lane) ? FERR(GENERIC) : 0;
 }
 
+template <int W>
 DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, u32 lane)
 {
+    const u32 sub = wg_sub<W>(lane);
     if (tl < FSE_MIN_TL) return FERR(GENERIC);
     if (tl > FSE_MAX_TL) return FERR(tableLog_tooLarge);
     if (tl < wg_min_tablelog((size_t)total, maxSV)) return FERR(GENERIC);
@@ -175,7 +192,7 @@ DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, 
     u32 used = 0, key = 0;                                     // key = probability << 8 | 255 - symbol: the arg-max prefers the lower symbol
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const u32 s = 4 * lane + i;
+        const u32 s = 4 * sub + i;
         if (s > maxSV || c[i] == 0) { n[i] = 0; continue; }
         if (c[i] <= tiny) { n[i] = -1; ++used; continue; }
         const u64 prod = (u64)c[i] * step;
@@ -186,16 +203,16 @@ DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, 
         const u32 k = (p << 8) | (255u - s);
         key = k > key ? k : key;
     }
-    const int still = (int)(1u << tl) - (int)wg_sum(used);
-    key = wg_max(key);
+    const int still = (int)(1u << tl) - (int)wg_sum<W>(used);
+    key = wg_max<W>(key);
     const u32 largest = (key >> 8) ? 255u - (key & 255u) : 0u;
     int nl = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (4 * lane + i == largest) nl = n[i];
-    nl = __shfl(nl, (int)(largest >> 2), WAVE);
-    if (-still >= (nl >> 1)) return wg_normalize_fallback(n, c, total, maxSV, tl, lane);
+    for (int i = 0; i < 4; ++i) if (4 * sub + i == largest) nl = n[i];
+    nl = __shfl(nl, (int)((lane - sub) + (largest >> 2)), WAVE);
+    if (-still >= (nl >> 1)) return wg_normalize_fallback<W>(n, c, total, maxSV, tl, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (4 * lane + i == largest) n[i] += still;
+    for (int i = 0; i < 4; ++i) if (4 * sub + i == largest) n[i] += still;
     return 0;
 }
 
@@ -212,26 +229,28 @@ DEV void wg_or_bits(u32* img, u32 pos, u32 v, u32 nb)
 // LDS words (>= 132).  Returns the header size in bytes (the image then holds the header) or an error code: dstSize_tooSmall by the
 // reference's rule -- only checked when the destination is below the worst-case header size, at every 16-bit flush
 // (lib/fse_compress.c:186-190, :228-272), i.e. against the position of the last flush.
+template <int W>
 DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 tl, u32 lane)
 {
+    const u32 sub = wg_sub<W>(lane);
     const u32 ts = 1u << tl;
     u32 a = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a += (u32)(n[i] < 0 ? -n[i] : n[i]);
-    u32 before = wg_scan_excl(a, lane);                         // points assigned in front of my first symbol
+    u32 before = wg_scan_excl<W>(a, lane);                         // points assigned in front of my first symbol
     // position of the first non-zero counter above each of my symbols
     u32 nzLane = 0xFFFFFFFFu;
 #pragma unroll
-    for (int i = 3; i >= 0; --i) if (n[i] != 0 && 4 * lane + i <= maxSV) nzLane = 4 * lane + i;
-    const u32 nzAbove = wg_suffix_min_excl(nzLane, lane);
+    for (int i = 3; i >= 0; --i) if (n[i] != 0 && 4 * sub + i <= maxSV) nzLane = 4 * sub + i;
+    const u32 nzAbove = wg_suffix_min_excl<W>(nzLane, lane);
     int prevN = __shfl_up(n[3], 1, WAVE);                      // counter of the symbol in front of my first one
-    if (lane == 0) prevN = 1;
+    if (sub == 0) prevN = 1;
     // chunks of my symbols: value + zero-run code; sizes first
     u32 val[4], vnb[4], run[4], bits = 0;
     bool broken = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const u32 s = 4 * lane + i;
+        const u32 s = 4 * sub + i;
         const int remaining = (int)(ts + 1) - (int)before;
         const int pn = i ? n[i - 1] : prevN;
         const bool coded = s <= maxSV && remaining > 1 && !(n[i] == 0 && pn == 0);
@@ -246,7 +265,7 @@ DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 
             if (n[i] == 0) {                                   // first zero of a run: the rest of the run is counted here
                 u32 e = 0xFFFFFFFFu;
 #pragma unroll
-                for (int j = 3; j > 0; --j) if (j > i && n[j] != 0 && 4 * lane + j <= maxSV) e = 4 * lane + j;
+                for (int j = 3; j > 0; --j) if (j > i && n[j] != 0 && 4 * sub + j <= maxSV) e = 4 * sub + j;
                 if (e == 0xFFFFFFFFu) e = nzAbove;
                 if (e == 0xFFFFFFFFu) broken = true;           // zeros up to the end of the alphabet: not a distribution
                 else { const u32 R = e - (s + 1); run[i] = R; bits += 16u * (R / 24u) + 2u * ((R % 24u) / 3u) + 2u; }
@@ -254,17 +273,17 @@ DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 
         }
         before += (u32)(n[i] < 0 ? -n[i] : n[i]);
     }
-    const u32 total = wg_sum(a);
-    if (__any(broken) || total != ts) return FERR(GENERIC);
-    const u32 mine = bits + (lane == 0 ? 4u : 0u);
-    u32 pos = wg_scan_excl(mine, lane);
-    const u32 totalBits = wg_sum(mine);
+    const u32 total = wg_sum<W>(a);
+    if (wg_any<W>(broken, lane) || total != ts) return FERR(GENERIC);
+    const u32 mine = bits + (sub == 0 ? 4u : 0u);
+    u32 pos = wg_scan_excl<W>(mine, lane);
+    const u32 totalBits = wg_sum<W>(mine);
     const size_t bound = maxSV ? (size_t)((((maxSV + 1) * tl) >> 3) + 3) : (size_t)FSEHIP_FSE_NCOUNTBOUND;
     if (cap < bound) {
         const long lastFlush = 2 * (long)((totalBits - 1) >> 4);
         if (lastFlush > (long)cap - 2) return FERR(dstSize_tooSmall);
     }
-    if (lane == 0) { wg_or_bits(img, 0, tl - FSE_MIN_TL, 4); pos += 4; }
+    if (sub == 0) { wg_or_bits(img, 0, tl - FSE_MIN_TL, 4); pos += 4; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         wg_or_bits(img, pos, val[i], vnb[i]); pos += vnb[i];
