@@ -270,7 +270,11 @@ def _huf_methods():
                "HUF_compress4X_usingCTable_batch")
         return dst, res
 
-    def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
+    def huf_decompress4x_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
+        """HUF_decompress4X_usingDTable over a batch: X1 (tableType 0) and X2 (tableType 1) tables, chosen per block"""
+        return self.huf_decompress4x1_using_dtable_batch(csrc, csizes, dtables, dst_sizes, max_table_log, shared_table, _fn="FSEHIP_HUF_decompress4X_usingDTable_batch")
+
+    def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, _fn="FSEHIP_HUF_decompress4X1_usingDTable_batch"):
         n = _blocks(csrc, "csrc").shape[0]
         width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
         dst = torch.zeros((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
@@ -278,9 +282,8 @@ def _huf_methods():
         pc, unic, keepc = _sizes_arg(csizes, csrc)
         pd, unid, keepd = _sizes_arg(dst_sizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)
-        _check(self.lib.FSEHIP_HUF_decompress4X1_usingDTable_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(res), _ptr(csrc), SZ(csrc.stride(0)),
-                                                                   pc, unic, _ptr(dtables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()),
-               "HUF_decompress4X1_usingDTable_batch")
+        _check(getattr(self.lib, _fn)(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(res), _ptr(csrc), SZ(csrc.stride(0)),
+                                      pc, unic, _ptr(dtables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()), _fn)
         return dst, res
 
     # layer 1
@@ -302,9 +305,13 @@ def _huf_methods():
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_HUF_decompress4X1_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
 
+    def huf_decompress4x_using_dtable(self, csrc, dt, dst_size):
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        return self._single("FSEHIP_HUF_decompress4X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
+
     for f in (huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch,
-              huf_decompress4x1_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
-              huf_compress4x_using_ctable, huf_decompress4x1_using_dtable):
+              huf_decompress4x1_using_dtable_batch, huf_decompress4x_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
+              huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable):
         setattr(FseHip, f.__name__, f)
 
 

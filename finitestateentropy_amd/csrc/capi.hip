@@ -499,7 +499,22 @@ extern "C" int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t ds
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
     a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
     a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
-    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.nBlocks = nBlocks;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.acceptX2 = 0; a.nBlocks = nBlocks;
+    return (int)launch_huf_decode(a, (hipStream_t)stream);
+}
+
+// HUF_decompress4X_usingDTable over a batch (lib/huf_decompress.c:980-997): dispatches per block on the table's type
+extern "C" int FSEHIP_HUF_decompress4X_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                         size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                         const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                         size_t nBlocks, void* stream)
+{
+    if (maxTableLog == 0 || maxTableLog > FSEHIP_HUF_TABLELOG_MAX) maxTableLog = FSEHIP_HUF_TABLELOG_MAX;
+    HufDecArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
+    a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
+    a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.acceptX2 = 1; a.nBlocks = nBlocks;
     return (int)launch_huf_decode(a, (hipStream_t)stream);
 }
 
@@ -591,7 +606,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
         HufDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstSizes = ds; e.results = d_results + b0;
         e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
-        e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.nBlocks = nb;
+        e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.acceptX2 = 0; e.nBlocks = nb;
         CK(launch_huf_decode_classes(e, lists, counts, s));
     }
     return 0;
@@ -629,28 +644,34 @@ extern "C" size_t FSEHIP_HUF_compress4X_usingCTable(void* dst, size_t dstSize, c
     return huf_using_ctable_host(4, dst, dstSize, src, srcSize, CTable);
 }
 
-extern "C" size_t FSEHIP_HUF_decompress4X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+static size_t huf_using_dtable_host(bool acceptX2, void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
 {
     const u32 desc = DTable[0];
-    if (((desc >> 8) & 0xFF) != 0) return FSEHIP_ERROR(GENERIC);              // huf_decompress.c:411-412
+    const unsigned type = (desc >> 8) & 0xFF;
+    if (type != 0 && !(acceptX2 && type == 1)) return FSEHIP_ERROR(GENERIC);   // huf_decompress.c:411-412
     const unsigned tl = (desc >> 16) & 0xFF;
     if (tl > FSEHIP_HUF_TABLELOG_MAX) return FSEHIP_ERROR(tableLog_tooLarge);
-    const size_t words = 1 + (tl ? ((size_t)1 << (tl - 1)) : 1);
+    // single-symbol cells are 2 bytes, double-symbol cells 4 (lib/huf_decompress.c:116, :480)
+    const size_t words = 1 + (type ? ((size_t)1 << tl) : (tl ? ((size_t)1 << (tl - 1)) : 1));
     DevBuf dsrc, ddst, ddt, dres;
     HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(maxDstSize)); HK(ddt.alloc(words * 4)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
     HK(hipMemcpy(ddt.p, DTable, words * 4, hipMemcpyHostToDevice));
-    HK((hipError_t)FSEHIP_HUF_decompress4X1_usingDTable_batch(ddst.p, maxDstSize, nullptr, maxDstSize, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
-                                                              (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
+    HK((hipError_t)(acceptX2 ? FSEHIP_HUF_decompress4X_usingDTable_batch : FSEHIP_HUF_decompress4X1_usingDTable_batch)(
+        ddst.p, maxDstSize, nullptr, maxDstSize, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize, (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= maxDstSize ? r : maxDstSize, hipMemcpyDeviceToHost));
     return r;
 }
+extern "C" size_t FSEHIP_HUF_decompress4X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+{
+    return huf_using_dtable_host(false, dst, maxDstSize, cSrc, cSrcSize, DTable);
+}
 extern "C" size_t FSEHIP_HUF_decompress4X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
 {
-    // lib/huf_decompress.c:980-997 dispatches on tableType; the device decoder implements X1 cells (tableType 0).
-    return FSEHIP_HUF_decompress4X1_usingDTable(dst, maxDstSize, cSrc, cSrcSize, DTable);
+    // lib/huf_decompress.c:980-997 dispatches on tableType: single-symbol (X1) cells -> k_huf_decode, double-symbol (X2) cells -> k_huf_decode_x2
+    return huf_using_dtable_host(true, dst, maxDstSize, cSrc, cSrcSize, DTable);
 }
 
 extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)

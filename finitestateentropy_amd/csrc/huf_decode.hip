@@ -289,7 +289,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         const size_t cSize = view_size(a.csrc, b) - hdr;
         dstSize = view_size(a.dstSizes, b);
         out = a.dst + b * a.dstStride;
-        if (((desc >> 8) & 0xFFu) != 0) blockErr = FERR(GENERIC);                       // X2 table: huf_decompress.c:411-412
+        if (((desc >> 8) & 0xFFu) != 0) blockErr = FERR(GENERIC);                       // X2 table: huf_decompress.c:411-412 (4X1 entry point)
         else if (dtLog > a.maxTableLog) blockErr = FERR(tableLog_tooLarge);
         else if (cSize < 10) blockErr = FERR(corruption_detected);                      // :269
         if (!blockErr) {
@@ -391,13 +391,93 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         anyEnd |= eq;
     }
     if (res == 0 && anyEnd) res = FERR(corruption_detected);
-    if (live && k == 0) {
+    if (live && k == 0 && !(a.acceptX2 && ((a.dtables[b * a.dtStrideU32] >> 8) & 0xFFu) == 1u)) {   // (double-symbol tables: k_huf_decode_x2)
         size_t result;
         if (blockErr) result = blockErr;
         else if (res) result = res;
         else result = dstSize;
         a.results[b] = result;
     }
+}
+
+// ---- double-symbol (X2) tables: HUF_decompress4X_usingDTable's other branch (lib/huf_decompress.c:749-862, 980-997) --------------
+// A caller that built its table with the reference's HUF_readDTableX2 hands over cells {u16 sequence; u8 nbBits; u8 length}: a
+// look-up yields one or two symbols.  The reference walks the four streams in lock step, stores two bytes per look-up and advances
+// by `length`, so what lands in the overlap between neighbouring segments -- and the verdict on corrupt input -- depends on that
+// lock step.  This is an acceptance path, not a throughput path: one lane walks one block with the reference's reader state
+// (BitReader) and its loop structure, the table stays in global memory.
+struct X2Stream { BitReader r; u8* op; };
+DEV void x2_cell(X2Stream& s, const u32* cells, u32 dtLog)                               // HUF_decodeSymbolX2, :663-670
+{
+    const u32 v = (u32)((s.r.win << (s.r.used & 63u)) >> ((64u - dtLog) & 63u));
+    const u32 c = cells[v];
+    s.op[0] = (u8)c; s.op[1] = (u8)(c >> 8);
+    s.r.used += (c >> 16) & 0xFFu;
+    s.op += c >> 24;
+}
+DEV int x2_reload_fast(BitReader& r)                                                     // BIT_reloadDStreamFast, bitstream.h:400-409
+{
+    if (r.at < 8) return BR_OVERFLOW;
+    r.at -= r.used >> 3; r.used &= 7; r.win = ldg64u(r.base + r.at);
+    return BR_UNFINISHED;
+}
+DEV void x2_finish(X2Stream& s, u8* pEnd, const u32* cells, u32 dtLog)                   // HUF_decodeStreamX2, :692-722
+{
+    while ((s.r.reload() == BR_UNFINISHED) & (s.op < pEnd - 7)) { x2_cell(s, cells, dtLog); x2_cell(s, cells, dtLog); x2_cell(s, cells, dtLog); x2_cell(s, cells, dtLog); }
+    while ((s.r.reload() == BR_UNFINISHED) & (s.op <= pEnd - 2)) x2_cell(s, cells, dtLog);
+    while (s.op <= pEnd - 2) x2_cell(s, cells, dtLog);
+    if (s.op < pEnd) {                                                                   // HUF_decodeLastSymbolX2, :672-688
+        const u32 v = (u32)((s.r.win << (s.r.used & 63u)) >> ((64u - dtLog) & 63u));
+        const u32 c = cells[v];
+        s.op[0] = (u8)c;
+        if ((c >> 24) == 1) s.r.used += (c >> 16) & 0xFFu;
+        else if (s.r.used < 64) { s.r.used += (c >> 16) & 0xFFu; if (s.r.used > 64) s.r.used = 64; }
+        s.op += 1;
+    }
+}
+__global__ __launch_bounds__(64) void k_huf_decode_x2(HufDecArgs a)
+{
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.nBlocks) return;
+    const u32* const gt = a.dtables + b * a.dtStrideU32;
+    const u32 desc = gt[0];
+    if (((desc >> 8) & 0xFFu) != 1u) return;                                              // single-symbol table: k_huf_decode's block
+    const u32 dtLog = (desc >> 16) & 0xFFu;
+    const u32* const cells = gt + 1;
+    const u8* const in = view_ptr(a.csrc, b);
+    const size_t cSize = view_size(a.csrc, b), dstSize = view_size(a.dstSizes, b);
+    u8* const ostart = a.dst + b * a.dstStride;
+    size_t result;
+    do {
+        if (dtLog > a.maxTableLog) { result = FERR(tableLog_tooLarge); break; }
+        if (cSize < 10) { result = FERR(corruption_detected); break; }                   // :758
+        const size_t l1 = ld16(in), l2 = ld16(in + 2), l3 = ld16(in + 4), l4 = cSize - (l1 + l2 + l3 + 6);
+        if (l4 > cSize) { result = FERR(corruption_detected); break; }                   // :795
+        const size_t seg = (dstSize + 3) / 4;
+        u8* const oend = ostart + dstSize;
+        u8* const start2 = ostart + seg; u8* const start3 = start2 + seg; u8* const start4 = start3 + seg;
+        X2Stream s1, s2, s3, s4;
+        s1.op = ostart; s2.op = start2; s3.op = start3; s4.op = start4;
+        size_t e;
+        e = s1.r.init(in + 6, l1); if (is_err(e)) { result = e; break; }                  // :796-799
+        e = s2.r.init(in + 6 + l1, l2); if (is_err(e)) { result = e; break; }
+        e = s3.r.init(in + 6 + l1 + l2, l3); if (is_err(e)) { result = e; break; }
+        e = s4.r.init(in + 6 + l1 + l2 + l3, l4); if (is_err(e)) { result = e; break; }
+        bool go = true;
+        while (go && ((long)(s4.op - ostart) < (long)dstSize - 7)) {                       // :802-847 (the order of the non-x86-clang build)
+            x2_cell(s1, cells, dtLog); x2_cell(s2, cells, dtLog); x2_cell(s3, cells, dtLog); x2_cell(s4, cells, dtLog);
+            x2_cell(s1, cells, dtLog); x2_cell(s2, cells, dtLog); x2_cell(s3, cells, dtLog); x2_cell(s4, cells, dtLog);
+            x2_cell(s1, cells, dtLog); x2_cell(s2, cells, dtLog); x2_cell(s3, cells, dtLog); x2_cell(s4, cells, dtLog);
+            x2_cell(s1, cells, dtLog); x2_cell(s2, cells, dtLog); x2_cell(s3, cells, dtLog); x2_cell(s4, cells, dtLog);
+            const int r1 = x2_reload_fast(s1.r), r2 = x2_reload_fast(s2.r), r3 = x2_reload_fast(s3.r), r4 = x2_reload_fast(s4.r);   // all four, always
+            go = r1 == BR_UNFINISHED && r2 == BR_UNFINISHED && r3 == BR_UNFINISHED && r4 == BR_UNFINISHED;
+        }
+        if (s1.op > start2 || s2.op > start3 || s3.op > start4) { result = FERR(corruption_detected); break; }   // :850-853
+        x2_finish(s1, start2, cells, dtLog); x2_finish(s2, start3, cells, dtLog); x2_finish(s3, start4, cells, dtLog); x2_finish(s4, oend, cells, dtLog);
+        const bool ended = (s1.r.at == 0 && s1.r.used == 64) & (s2.r.at == 0 && s2.r.used == 64) & (s3.r.at == 0 && s3.r.used == 64) & (s4.r.at == 0 && s4.r.used == 64);
+        result = ended ? dstSize : FERR(corruption_detected);                             // :861-866
+    } while (0);
+    a.results[b] = result;
 }
 
 static int huf_decode_G(size_t ldsBytes, unsigned ldsLog)
@@ -425,7 +505,11 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
     a.list = nullptr; a.count = nullptr;
     a.ldsLog = a.maxTableLog > HD_SLOT_LOG ? FSEHIP_HUF_TABLELOG_MAX : HD_SLOT_LOG;
     probe_before(PK_HUF_DECODE, s);
-    const hipError_t e = huf_decode_launch(a, s);
+    hipError_t e = huf_decode_launch(a, s);
+    if (e == hipSuccess && a.acceptX2) {                 // HUF_decompress4X_usingDTable: blocks whose table is a double-symbol one
+        hipLaunchKernelGGL(k_huf_decode_x2, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+        e = hipGetLastError();
+    }
     probe_after(PK_HUF_DECODE, s);
     return e;
 }

@@ -172,6 +172,7 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
     const u32* count;
     int G; unsigned slotU32;
     int streams;                 // 4 (4X1) or 1 (1X1)
+    int acceptX2;                // usingDTable batch only: blocks with a double-symbol table (tableType 1) go to k_huf_decode_x2 instead of failing
     size_t nBlocks;
 };
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);

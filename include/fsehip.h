@@ -156,6 +156,14 @@ FSEHIP_API int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t ds
                                                           size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
                                                           const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
                                                           size_t nBlocks, void* stream);
+/* HUF_decompress4X_usingDTable over a batch (lib/huf.h:275, lib/huf_decompress.c:980-997): per block, tables of tableType 0
+ * (single-symbol cells, from HUF_readDTableX1) take the fast decoder, tables of tableType 1 (double-symbol cells, from the
+ * reference's HUF_readDTableX2: 4 bytes per cell, 1 + (1 << tableLog) words) an acceptance path with the reference's lock-step
+ * semantics.  The 4X1 call above rejects tableType 1 with GENERIC exactly like HUF_decompress4X1_usingDTable. */
+FSEHIP_API int FSEHIP_HUF_decompress4X_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                         size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                         const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                         size_t nBlocks, void* stream);
 FSEHIP_API size_t FSEHIP_HUF_compress_batch_workspaceSize(size_t nBlocks);
 FSEHIP_API int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
                                          const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,

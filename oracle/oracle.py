@@ -345,6 +345,24 @@ class Ref(_Base):
     def _f(self, name):
         return getattr(self.lib, name)
 
+    # double-symbol (X2) decoding tables exist only in the reference (our restatement covers the X1 decoder)
+    def huf_read_dtable_x2(self, src, max_table_log=12):
+        src, ps = _u8(src)
+        dt = np.zeros(1 + (1 << 12), dtype=np.uint32)
+        dt[0] = max_table_log * 0x01000001
+        r = self._call("HUF_readDTableX2", self.sz, dt.ctypes.data_as(self.vp), ps, self.sz(src.size))
+        return int(r), dt
+
+    def huf_decompress4x_using_dtable(self, csrc, dt, dst_size):
+        """HUF_decompress4X_usingDTable: dispatches on the table type (lib/huf_decompress.c:980-997)"""
+        csrc, ps = _u8(csrc)
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        out = np.zeros(max(dst_size, 1) + 16, dtype=np.uint8)
+        out[dst_size:] = 0xA5
+        r = self._call("HUF_decompress4X_usingDTable", self.sz, out.ctypes.data_as(self.vp), self.sz(dst_size), ps, self.sz(csrc.size), dt.ctypes.data_as(self.vp))
+        assert (out[dst_size:] == 0xA5).all()
+        return int(r), out[:dst_size]
+
     def max_threads(self):
         self.lib.ref_max_threads.restype = C.c_int
         return int(self.lib.ref_max_threads())

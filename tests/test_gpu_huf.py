@@ -228,3 +228,64 @@ def test_huf_randomized_differential(hip, oracle, seed):
                 out, dres = hip.huf_decompress_batch(d_c, d_sz, size)
                 assert (dres.cpu().numpy() == size).all(), (seed, size, hl)
                 assert (out.cpu().numpy()[:, :size] == blocks[ok]).all(), (seed, size, hl)
+
+
+def test_huf_x2_tables_accepted(hip, ref):
+    """HUF_decompress4X_usingDTable with double-symbol tables built by the reference's HUF_readDTableX2
+    (lib/huf_decompress.c:551-649 -> :749-862 via the dispatcher :980-997): batch and single-block calls against the compiled
+    reference, valid streams (all distributions, several sizes), truncated / corrupted streams, mixed X1 / X2 tables in one batch;
+    the 4X1 entry points keep rejecting X2 tables (huf_decompress.c:411-412)."""
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    rng = np.random.default_rng(8)
+    W = 1 + (1 << 12)
+    for size in (32768, 5000, 257):
+        blocks, tables, streams, kinds = [], [], [], []
+        for i, P in enumerate((14, 2, 80, 50, 20, 14, 2, 80)):
+            blk = orc.probagen_batch(P, 1, size, 100 + i)[0]
+            cs, c = ref.huf_compress2(blk)
+            if cs <= 1:
+                continue
+            x2 = i % 3 != 2                                   # a few X1 tables in the same batch
+            h, dt = ref.huf_read_dtable_x2(c[:cs]) if x2 else ref.huf_read_dtable_x1(c[:cs], 11)
+            assert not is_error(h)
+            blocks.append(blk); tables.append(dt[:W].copy() if len(dt) >= W else np.pad(dt, (0, W - len(dt)))); streams.append(c[h:cs].copy()); kinds.append(x2)
+        n = len(blocks)
+        cbuf = np.zeros((n, max(len(s) for s in streams) + 8), np.uint8); csz = np.zeros(n, np.int64)
+        for i, s in enumerate(streams):
+            cbuf[i, :len(s)] = s; csz[i] = len(s)
+        d_c = torch.from_numpy(cbuf).cuda(); d_sz = torch.from_numpy(csz).cuda()
+        d_dt = torch.from_numpy(np.stack(tables).view(np.int32)).cuda()
+        for dst_size in (size, size - 1, size + 3):
+            out, res = hip.huf_decompress4x_using_dtable_batch(d_c, d_sz, d_dt, dst_size)
+            out, res = out.cpu().numpy(), res.cpu().numpy()
+            for i in range(n):
+                r, exp = ref.huf_decompress4x_using_dtable(streams[i], tables[i], dst_size)
+                assert res[i] == s64(r), (size, dst_size, i, kinds[i], res[i], r)
+                if not is_error(r):
+                    assert (out[i][:r] == exp[:r]).all(), (size, dst_size, i)
+                    if dst_size == size:
+                        assert (out[i][:size] == blocks[i]).all()
+        # the 4X1 entry point refuses double-symbol tables
+        out1, res1 = hip.huf_decompress4x1_using_dtable_batch(d_c, d_sz, d_dt, size)
+        res1 = res1.cpu().numpy()
+        for i in range(n):
+            if kinds[i]:
+                assert res1[i] == -1, (i, res1[i])
+        # corrupted / truncated streams: same verdicts (and bytes, when the reference accepts them)
+        for trial in range(12):
+            i = trial % n
+            if not kinds[i]:
+                continue
+            bad = streams[i].copy()
+            if trial % 3 == 0:
+                bad = bad[:max(10, len(bad) - int(rng.integers(1, 40)))]
+            elif trial % 3 == 1:
+                pos = rng.integers(0, len(bad), 4); bad[pos] ^= rng.integers(1, 256, 4).astype(np.uint8)
+            else:
+                bad[:6] = rng.integers(0, 256, 6, dtype=np.uint8)
+            r, exp = ref.huf_decompress4x_using_dtable(bad, tables[i], size)
+            rg, og = hip.huf_decompress4x_using_dtable(bad, tables[i], size)
+            assert rg == r, (size, trial, rg, r)
+            if not is_error(r):
+                assert (og[:r] == exp[:r]).all()
