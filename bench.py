@@ -255,18 +255,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (FSEHIP_BENCH_BACKEND=gloo lets several ranks share one GPU for a smoke test of the N>1 path; the driver's runs use RCCL)
+    backend = os.environ.get("FSEHIP_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from finitestateentropy_amd import shard
     from finitestateentropy_amd.api import FseHip, fse_compress_bound, huf_compress_bound
     hip = FseHip()
     dev = torch.device("cuda", local_rank)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

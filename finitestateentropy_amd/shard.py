@@ -13,6 +13,25 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(group=None):
+    """point-to-point transfers of device tensors go through host memory when the process group cannot move them itself
+    (gloo: the CPU tests, and two ranks sharing one GPU in a smoke test); RCCL moves device memory directly over xGMI"""
+    return dist.get_backend(group) == "gloo"
+
+
+def _isend(t, dst, group=None):
+    return dist.isend(t.cpu() if (t.is_cuda and _staged(group)) else t, dst=dst, group=group)
+
+
+def _recv_into(t, src, group=None):
+    if t.is_cuda and _staged(group):
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src, group=group)
+
+
 def shard_range(n_blocks, rank, world):
     """Contiguous range [lo, hi) of rank `rank`; sizes differ by at most one block."""
     base, rem = divmod(n_blocks, world)
@@ -34,11 +53,11 @@ def scatter_blocks(blocks_root, n_blocks, block_bytes, rank, world, device, root
             if r == root:
                 mine.copy_(blocks_root[rlo:rhi])
             elif rhi > rlo:
-                reqs.append(dist.isend(blocks_root[rlo:rhi].contiguous(), dst=r, group=group))
+                reqs.append(_isend(blocks_root[rlo:rhi].contiguous(), r, group))
         for q in reqs:
             q.wait()
     elif hi > lo:
-        dist.recv(mine, src=root, group=group)
+        _recv_into(mine, root, group)
     return mine
 
 
@@ -57,14 +76,17 @@ def gather_blocks(slots_mine, sizes_mine, n_blocks, rank, world, root=0, group=N
             if r == root:
                 out[rlo:rhi].copy_(slots_mine); sizes[rlo:rhi].copy_(sizes_mine)
             elif rhi > rlo:
-                reqs.append(dist.irecv(out[rlo:rhi], src=r, group=group))
-                reqs.append(dist.irecv(sizes[rlo:rhi], src=r, group=group))
+                if slots_mine.is_cuda and _staged(group):
+                    _recv_into(out[rlo:rhi], r, group); _recv_into(sizes[rlo:rhi], r, group)
+                else:
+                    reqs.append(dist.irecv(out[rlo:rhi], src=r, group=group))
+                    reqs.append(dist.irecv(sizes[rlo:rhi], src=r, group=group))
         for q in reqs:
             q.wait()
         return out, sizes
     if slots_mine.shape[0]:
-        dist.send(slots_mine.contiguous(), dst=root, group=group)
-        dist.send(sizes_mine.contiguous(), dst=root, group=group)
+        _isend(slots_mine.contiguous(), root, group).wait()
+        _isend(sizes_mine.contiguous(), root, group).wait()
     return None, None
 
 
