@@ -218,16 +218,22 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     blocks_per_launch = nb * steps / dom_launches
     achieved = alg * blocks_per_launch / (dom_ms / dom_launches * 1e-3) / 1e9
     traffic = None
+    by_size = None
     if traffic_tag is not None:
         tpath = os.path.join(ROOT, "profiles", "traffic_%s%s.json" % (dom, traffic_tag))
         if os.path.exists(tpath):
             try:   # PMC counters come from a separate rocprofv3 --pmc pass (scripts/pmc_summary.py -> profiles/); per launch like `achieved`
-                traffic = round(json.load(open(tpath)).get("hbm_bytes_per_block") * blocks_per_launch)
+                rec = json.load(open(tpath))
+                traffic = round(rec.get("hbm_bytes_per_block") * blocks_per_launch)
+                by_size = rec.get("request_size_bytes_per_block")
             except Exception:
                 traffic = None
-    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_block": round(alg, 1),
-            "blocks_per_launch": round(blocks_per_launch, 1), "avg_launch_ms": round(dom_ms / dom_launches, 4)}
+    out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_block": round(alg, 1),
+           "blocks_per_launch": round(blocks_per_launch, 1), "avg_launch_ms": round(dom_ms / dom_launches, 4)}
+    if by_size:   # cross-check of `traffic`: the L2's memory-side requests counted by request size (exact bytes, profiles/*_pmc.md)
+        out["traffic_by_request_size"] = {"read_bytes_per_block": by_size["read"], "write_bytes_per_block": by_size["write"]}
+    return out
 
 
 def summarize(r, codecs, nb, steps, world, reduce_max):

@@ -22,9 +22,12 @@
 #include "dev_common.h"
 
 #define WB_MAXSYM 256
-// The rank matrix covers a window of WB_WIN symbols at a time (alphabets up to 128 symbols: one pass; the LDS footprint
+// The rank matrix covers a window of WB_WIN symbols at a time (alphabets up to 64 symbols: one pass; measured per 100k blocks,
+// compress + decompress build: window 128 -> 64: Proba14 1.88 -> 1.64 ms, tableLog 12 4.48 -> 3.55 ms, Proba02 3.24 -> 3.72 ms; the LDS footprint
 // decides how many table builds a CU runs at once, and these builds are latency-bound).
-#define WB_WIN 128u
+#ifndef WB_WIN
+#define WB_WIN 64u
+#endif
 #define WB_TSTEP(ts) (((ts) >> 1) + ((ts) >> 3) + 3)     // lib/fse.h:683
 
 #ifdef FSE_WB_TIMING         // development aid: phase cycle accounting of the last table build of each workgroup

@@ -16,9 +16,13 @@ import shutil
 import sys
 
 
-def agg(path):
+def agg(path, counter=None):
     out = collections.defaultdict(lambda: [0, 0.0, 0])
+    if not os.path.exists(path):
+        return out
     for r in csv.DictReader(open(path)):
+        if counter is not None and r["Counter_Name"] != counter:
+            continue
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("void "):
             k = k[5:]
@@ -36,6 +40,21 @@ def main():
     shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
     fetch = agg(os.path.join(run, "pmc_fetch", "bench_counter_collection.csv"))
     write = agg(os.path.join(run, "pmc_write", "bench_counter_collection.csv"))
+    # exact byte counts from the L2's memory-side request counters by request size (cross-check, no calibration needed)
+    rdp, wrp = os.path.join(run, "pmc_rd", "bench_counter_collection.csv"), os.path.join(run, "pmc_wr", "bench_counter_collection.csv")
+    rd = {c: agg(rdp, "TCC_EA0_RDREQ%s_sum" % c) for c in ("", "_32B", "_64B", "_128B")}
+    wr = {c: agg(wrp, "TCC_EA0_WRREQ%s_sum" % c) for c in ("", "_64B")}
+
+    def req_bytes(k):
+        if k not in rd[""] and k not in wr[""]:
+            return None, None
+        a, b64, c = rd["_32B"].get(k, [0, 0, 0])[1], rd["_64B"].get(k, [0, 0, 0])[1], rd["_128B"].get(k, [0, 0, 0])[1]
+        tot = rd[""].get(k, [0, 0, 0])[1]
+        other = max(tot - a - b64 - c, 0.0)                      # requests not in a size class are counted as 64 B
+        rb = 32 * a + 64 * (b64 + other) + 128 * c
+        w64, wt = wr["_64B"].get(k, [0, 0, 0])[1], wr[""].get(k, [0, 0, 0])[1]
+        wb = 64 * w64 + 32 * max(wt - w64, 0.0)
+        return rb, wb
     # passes over the data per kernel in the PMC run = launches / launches-per-pass
     lines = ["# %s: HBM traffic per kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag, "",
              "PMC run: `python bench.py --steps 2 --warmup 1 --blocks %d --no-cpu-baseline` (3 passes over %d blocks)." % (nblocks, nblocks), ""]
@@ -49,16 +68,20 @@ def main():
                      "-> correction x%.3f (MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 on gfx950)." % (raw / 1e6, hist_known / 1e6, corr))
     corr_used = 2.0 if 1.8 < corr < 2.2 else 1.0
     lines += ["FETCH correction applied: x%.1f.  WRITE_SIZE calibrated on k_probagen (exact)." % corr_used, "",
-              "| kernel | launches | fetch KiB (raw) | write KiB | HBM bytes / block (corrected) |", "|---|---|---|---|---|"]
+              "| kernel | launches | fetch KiB (raw) | write KiB | HBM bytes / block (corrected) | read / write bytes per block by request size |", "|---|---|---|---|---|---|"]
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_") or k == "k_probagen":
             continue
         f = fetch.get(k, [0, 0, 0]); w = write.get(k, [0, 0, 0])
         per_block = (f[1] * 1024 * corr_used + w[1] * 1024) / (nblocks * passes)
-        lines.append("| %s | %d | %.0f | %.0f | %.0f |" % (k, f[0], f[1], w[1], per_block))
-        json.dump({"kernel": k, "hbm_bytes_per_block": round(per_block, 1), "fetch_correction": corr_used,
-                   "fetch_KiB_raw_total": f[1], "write_KiB_total": w[1], "blocks": nblocks, "passes": passes, "source": tag},
-                  open("profiles/traffic_%s.json" % k, "w"))
+        rb, wb = req_bytes(k)
+        extra = "%.0f / %.0f" % (rb / (nblocks * passes), wb / (nblocks * passes)) if rb is not None else "-"
+        lines.append("| %s | %d | %.0f | %.0f | %.0f | %s |" % (k, f[0], f[1], w[1], per_block, extra))
+        rec = {"kernel": k, "hbm_bytes_per_block": round(per_block, 1), "fetch_correction": corr_used,
+               "fetch_KiB_raw_total": f[1], "write_KiB_total": w[1], "blocks": nblocks, "passes": passes, "source": tag}
+        if rb is not None:
+            rec["request_size_bytes_per_block"] = {"read": round(rb / (nblocks * passes), 1), "write": round(wb / (nblocks * passes), 1)}
+        json.dump(rec, open("profiles/traffic_%s.json" % k, "w"))
     open("profiles/%s_pmc.md" % tag, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
