@@ -260,15 +260,12 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         if (live) { pp = ctl_load(&ctl->pubPofs); it = ctl_load(&ctl->pubIters); }
         const bool fin = (pp >> 31) != 0;
         const int P = (int)(pp & 0x7FFFFFFFu);               // byte offset of the topmost dword the decoder still reads
-        // rows of whole 128-byte lines (32 records) while the block is running: a line written in two halves microseconds apart
-        // is evicted from the L2 in between and goes to memory twice (measured: 37.4 KB written per 32 KB block)
-        const u32 pending = it - flushed;
-        const u32 avail = fin ? pending : (pending & ~31u);
-        const bool wantFlush = live && avail > 0;
+        const u32 avail = it - flushed;
+        const bool wantFlush = live && (avail >= 32u || (fin && avail > 0));
         // the chunk [validLo-CHUNK, validLo) lands on the ring bytes of [validLo+RING-CHUNK, validLo+RING): the decoder must be below
         const bool wantFill = live && !fin && validLo > 0 && P + 4 <= validLo + (FSE_IN_RING - FSE_IN_CHUNK);
         const unsigned long long fm = __ballot(wantFlush), rm = __ballot(wantFill);
-        if (live && fin && pending == 0) live = false;
+        if (live && fin && avail == 0) live = false;
         if (!(fm | rm)) {
             if (!__any(live)) break;
             __builtin_amdgcn_s_sleep(4);
@@ -304,7 +301,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         if (fillK) { if (rev) fse_ring_put_rev(rgK, SgK, fillOff, pend); else fse_ring_put(rgK, fillOff, pend); }
         if (wantFill) { validLo -= FSE_IN_CHUNK; ctl_store(&ctl->srvValidLo, validLo); }
         // (4) the ring records are in registers now: hand the slots back, then pack and store the symbols
-        if (wantFlush) { ctl_store(&ctl->srvFlushed, flushed + avail); }
+        if (wantFlush) { ctl_store(&ctl->srvFlushed, it); }
 #pragma unroll
         for (int l = 0; l < FSE_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;               // uniform
@@ -315,7 +312,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
                 __builtin_memcpy(og + 4u * lane, &w, 4);
             }
         }
-        if (wantFlush) flushed += avail;
+        if (wantFlush) flushed = it;
         TIMING({ const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy; })
     }
     TIMING(if (lane == 0 && g0 == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[4] = sBusy; t[5] = sIdle; t[6] = nBusy; })
