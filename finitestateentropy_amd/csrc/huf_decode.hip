@@ -516,13 +516,19 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
 
 // one-shot path: k_huf_dprep has sorted the blocks into two lists by their tableLog (<= 11: 4 KiB table slots, 14 blocks per
 // workgroup; 12: 8 KiB slots, 8 blocks per workgroup); one launch per list
-hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, hipStream_t s)
+hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, u32* fbLists, u32* fbCounts, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(fbCounts, 0, HUF_DCLS_COUNT * sizeof(u32), s);
+    if (e != hipSuccess) return e;
     probe_before(PK_HUF_DECODE, s);
-    hipError_t e = hipSuccess;
     for (int c = 0; c < HUF_DCLS_COUNT && e == hipSuccess; ++c) {
         a.list = lists + (size_t)c * a.nBlocks; a.count = counts + c;
+        a.ldsLog = c == 0 ? HD_SLOT_LOG : FSEHIP_HUF_TABLELOG_MAX;
+        e = launch_huf_decode_par(a, fbLists + (size_t)c * a.nBlocks, fbCounts + c, s);
+    }
+    for (int c = 0; c < HUF_DCLS_COUNT && e == hipSuccess; ++c) {      // the declined blocks: serial decoder, literal verdicts
+        a.list = fbLists + (size_t)c * a.nBlocks; a.count = fbCounts + c;
         a.ldsLog = c == 0 ? HD_SLOT_LOG : FSEHIP_HUF_TABLELOG_MAX;
         e = huf_decode_launch(a, s);
     }

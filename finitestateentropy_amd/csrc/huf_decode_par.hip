@@ -1,0 +1,237 @@
+// huf_decode_par.hip -- a5: HUF_decompress4X1 with every stream split across the 64 lanes of a wave (one wave per block)
+// (reference: lib/huf_decompress.c:194-354; bit reader lib/bitstream.h:272-448; format SURVEY A.6).
+//
+// A prefix code is self-synchronising: a decoder dropped at an arbitrary bit of the stream falls into step with the true
+// codeword boundaries after a few symbols.  That makes a Huffman stream splittable without changing a byte of the result --
+// the same speculate / verify / repair idea as the tANS encoder (fse_encode_wave.hip), here on bit positions:
+//
+//   The four streams of a block are taken one after the other; lane j walks the j-th 64th (by bit position) of the stream.
+//   Positions are counted as C = bits consumed from the top of the stream (the reference reads it from its last byte down).
+//   Pass 1: lane 0 starts at the true first bit; lane j > 0 warms up from 128 bits in front of its range and takes the first
+//     codeword boundary inside the range as its start S_j (its guess at where lane j-1 will end); it then decodes to the first
+//     boundary at or beyond the end of its range, E_j, counting its symbols n_j.
+//   Verify / repair: S_j must equal E_(j-1).  Lane 0 is exact, so if every link holds all lanes are exact by induction.  A lane
+//     whose link fails (its warm-up had not fallen into step yet) re-runs its range from E_(j-1); the check repeats until no
+//     link changes (worst case: 64 rounds = the serial walk).
+//   The stream is accepted only if it regenerates exactly its segment and ends exactly on its first bit (BIT_endOfDStream,
+//   lib/huf_decompress.c:348-349).  Otherwise -- corrupt input, tiny or irregular blocks, streams beyond the LDS budget -- the
+//   whole block is handed to the serial decoder (k_huf_decode), which reproduces the reference's verdict literally.
+//   Pass 2: a 64-lane prefix sum of n_j gives every lane its place in the output; it decodes its symbols again and stores them
+//     sixteen at a time.
+//
+// 64 busy lanes per block instead of 4 and no service waves.  In LDS: the table (bit-reversed {nbBits, byte} cells as in
+// huf_decode.hip) and the current stream, staged with coalesced loads IN CONSUMPTION ORDER (dword m = bit-reversed stream dword
+// top - m), so that the decoding loop is the serial kernel's: a cursor Q = consumed bits - 1, bits taken from the low end of a
+// three-dword register window, four symbols per iteration with one table look-up each on the dependent chain (hd_bulk_phase).
+// Near the ends of a range the lane steps symbol by symbol so that "first boundary at or beyond" is exact.
+//   (Measured dead ends: every lane refilling its own window from global memory, 20 ms per 100k blocks -- a dependent,
+//   uncoalesced load behind nearly every symbol; all four streams staged at once with 16 lanes each, 10 ms -- 24 KB of LDS per
+//   block leaves six waves per CU; the serial kernel: 8.0 ms.)
+#include "internal.h"
+
+#define HPAR_WARM 128u                // warm-up bits in front of a range
+#define HPAR_NEAR 48u                 // four symbols consume at most 48 bits: closer than this to a limit the lane steps by symbols
+#define HPAR_MIN_BITS 4096u           // streams shorter than this go to the serial decoder (ranges must dwarf warm-up and codes)
+#define HPAR_DATA_BYTES (8192u + 256u) // LDS budget for one staged stream (+ zero padding behind its end)
+
+typedef const __attribute__((address_space(3))) u16* hpar_lds_u16;
+typedef const __attribute__((address_space(3))) u32* hpar_lds_u32;
+DEV u32 hpar_cell(u32 win, u32 mask2, u32 tabOff) { return *(hpar_lds_u16)(uintptr_t)((win & mask2) | tabOff); }
+
+// one symbol at cursor C (consumed bits); returns the cell (nbBits | byte << 8)
+DEV u32 hpar_single(u32 arr, u32& C, u32 tabOff, u32 mask2)
+{
+    const u32 Q = C - 1u;
+    const hpar_lds_u32 wp = (hpar_lds_u32)(uintptr_t)(arr + ((Q >> 5) << 2));
+    const u32 lo = __builtin_amdgcn_alignbit(wp[1], wp[0], Q & 31u);      // bit 1 = next unread bit
+    const u32 c = hpar_cell(lo, mask2, tabOff);
+    C += c & 0xFFu;
+    return c;
+}
+
+// four symbols per iteration, the loop of hd_bulk_phase (huf_decode.hip) on the flat consumption-order array
+struct HparBulk {
+    u32 arr, q4, bq, w0, w1, w2, lo;
+    DEV void open(u32 a, u32 C)
+    {
+        arr = a;
+        const u32 Q = C - 1u;
+        q4 = (Q >> 5) << 2; bq = Q & 31u;
+        const hpar_lds_u32 wp = (hpar_lds_u32)(uintptr_t)(arr + q4);
+        w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
+        lo = __builtin_amdgcn_alignbit(w1, w0, bq);
+    }
+    DEV u32 cursor() const { return (q4 << 3) + bq + 1u; }
+    DEV u32 iter(u32 tabOff, u32 mask2)                                   // returns the four symbols, first in the low byte
+    {
+        const hpar_lds_u32 np = (hpar_lds_u32)(uintptr_t)(arr + q4 + 12u);
+        const u32 n0 = np[0], n1 = np[1];                                  // the two dwords behind the window
+        const u32 c1 = hpar_cell(lo, mask2, tabOff);
+        u32 l = __builtin_amdgcn_alignbit(w1, w0, bq), h = __builtin_amdgcn_alignbit(w2, w1, bq);
+        l = __builtin_amdgcn_alignbit(h, l, c1); h >>= (c1 & 31u);
+        const u32 c2 = hpar_cell(l, mask2, tabOff);
+        l = __builtin_amdgcn_alignbit(h, l, c2); h >>= (c2 & 31u);
+        const u32 c3 = hpar_cell(l, mask2, tabOff);
+        l = __builtin_amdgcn_alignbit(h, l, c3); h >>= (c3 & 31u);
+        const u32 c4 = hpar_cell(l, mask2, tabOff);
+        lo = __builtin_amdgcn_alignbit(h, l, c4);
+        u32 word = __builtin_amdgcn_perm(c1, 0u, 0x03020105u);
+        word = __builtin_amdgcn_perm(c2, word, 0x03020500u);
+        word = __builtin_amdgcn_perm(c3, word, 0x03050100u);
+        word = __builtin_amdgcn_perm(c4, word, 0x05020100u);
+        const u32 bqn = bq + ((c1 + c2 + c3 + c4) & 0xFFu);
+        const bool k1 = bqn >= 32u, k2 = bqn >= 64u;
+        w0 = k2 ? w2 : (k1 ? w1 : w0);
+        w1 = k2 ? n0 : (k1 ? w2 : w1);
+        w2 = k2 ? n1 : (k1 ? n0 : w2);
+        q4 += (bqn >> 5) << 2;
+        bq = bqn & 31u;
+        return word;
+    }
+};
+
+// decode from C up to the first boundary at or beyond `limit`, counting symbols
+DEV u32 hpar_run(u32 arr, u32& C, u32 limit, u32 tabOff, u32 mask2)
+{
+    u32 n = 0;
+    if (C + HPAR_NEAR < limit) {
+        HparBulk bk; bk.open(arr, C);
+        do { (void)bk.iter(tabOff, mask2); n += 4; C = bk.cursor(); } while (C + HPAR_NEAR < limit);
+    }
+    while (C < limit) { (void)hpar_single(arr, C, tabOff, mask2); ++n; }
+    return n;
+}
+
+__global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const u32 lane = threadIdx.x;
+    const size_t slot = blockIdx.x;
+    const size_t nTot = a.count ? (size_t)*a.count : a.nBlocks;
+    if (slot >= nTot) return;                                            // uniform
+    const size_t b = a.list ? (size_t)a.list[slot] : slot;
+    if (a.meta[b].state == 0) return;                                    // (finished by the prepare kernel)
+    const u32 hdr = a.meta[b].hdrSize;
+    const u32* const gt = a.dtables + b * a.dtStrideU32;
+    const u32 desc = gt[0];
+    const u32 dtLog = (desc >> 16) & 0xFFu;
+    const u8* const in = view_ptr(a.csrc, b) + hdr;
+    const size_t cSize = view_size(a.csrc, b) - hdr;
+    const size_t dstSize = view_size(a.dstSizes, b);
+    u8* const out = a.dst + b * a.dstStride;
+
+    // ---- can this block take the parallel path?  (uniform)  Anything unusual is the serial decoder's business.
+    bool ok = ((desc >> 8) & 0xFFu) == 0 && dtLog >= 1 && dtLog <= a.ldsLog && cSize >= 10 && cSize < (1u << 28) && dstSize >= 64 && dstSize < (1u << 28);
+    u32 len[4] = { 0, 0, 0, 0 }, T0[4] = { 0, 0, 0, 0 };
+    const u32 seg = (u32)((dstSize + 3) / 4);
+    if (ok) {
+        len[0] = ld16(in); len[1] = ld16(in + 2); len[2] = ld16(in + 4);
+        const size_t used = (size_t)len[0] + len[1] + len[2] + 6;
+        if (used > cSize) ok = false; else len[3] = (u32)(cSize - used);
+        if (3 * (size_t)seg >= dstSize) ok = false;
+    }
+    if (ok) {
+        const u8* sp = in + 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 last = len[q] ? sp[len[q] - 1] : 0;
+            if (len[q] < 8 || len[q] + 80 > HPAR_DATA_BYTES || last == 0) ok = false;
+            else T0[q] = 8u * (len[q] - 1) + hibit32(last);              // unread bits under the end mark (bitstream.h:285-290)
+            if (T0[q] < HPAR_MIN_BITS) ok = false;
+            sp += len[q];
+        }
+    }
+    if (!ok) {                                                           // uniform
+        if (lane == 0) fbList[atomicAdd(fbCount, 1u)] = (u32)b;
+        return;
+    }
+
+    // ---- stage the table: reference cells {byte, nbBits} -> bit-reversed order, {nbBits, byte}
+    {   const u32 words = 1u << (dtLog - 1);
+        u16* const s = (u16*)lds;
+        for (u32 i = lane; i < words; i += 64) {
+            const u32 w = gt[1 + i];
+            const u32 r0 = __brev(2u * i) >> (32u - dtLog);
+            s[r0] = (u16)(((w >> 8) & 0xFFu) | ((w & 0xFFu) << 8));
+            s[r0 | (1u << (dtLog - 1))] = (u16)(((w >> 24) & 0xFFu) | (((w >> 16) & 0xFFu) << 8));
+        }
+    }
+    const u32 tabOff = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds;
+    if (tabOff & ((2u << a.ldsLog) - 1u)) __builtin_trap();               // the cell address is formed with an OR (dynamic LDS starts at 0)
+    const u32 mask2 = ((1u << dtLog) - 1u) << 1;
+    u32* const data = lds + ((size_t)1 << (a.ldsLog - 1));               // the staged stream, behind the table slot
+    const u32 arr = tabOff + (2u << a.ldsLog);
+
+    const u8* sp = in + 6;
+    bool good = true;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                                        // uniform: stream after stream
+        const u32 L = len[q], Sd = (L + 3) / 4;
+        __syncthreads();                                                 // (table staged / previous stream done)
+        // consumption order: array dword m = bit-reversed stream dword Sd-1-m; zeros behind the end (= below the stream's first bit)
+        for (u32 m = lane; m < Sd + 16; m += 64) {
+            u32 v = 0;
+            if (m < Sd) {
+                const u32 d = Sd - 1 - m;
+                if (4 * d + 4 <= L) __builtin_memcpy(&v, sp + 4 * d, 4);
+                else for (u32 t = 4 * d; t < L; ++t) v |= (u32)sp[t] << (8 * (t & 3u));
+            }
+            data[m] = __brev(v);
+        }
+        __syncthreads();
+        const u32 C0 = 32u * Sd - T0[q];                                 // cursor of the first code bit (bits above it: padding, end mark)
+        const u32 want = q < 3 ? seg : (u32)dstSize - 3 * seg;
+        const u32 stepA = (T0[q] + 63u) / 64u;
+        const u32 aLo = lane * stepA < T0[q] ? lane * stepA : T0[q];
+        const u32 aHi = (lane + 1) * stepA < T0[q] ? (lane + 1) * stepA : T0[q];
+        const u32 cLo = C0 + aLo, cHi = C0 + aHi;
+        // ---- pass 1: warm up to my start, then my range
+        u32 S = C0;
+        if (lane > 0) { u32 C = aLo > HPAR_WARM ? cLo - HPAR_WARM : C0; (void)hpar_run(arr, C, cLo, tabOff, mask2); S = C; }
+        u32 E = S;
+        u32 n = hpar_run(arr, E, cHi, tabOff, mask2);
+        // ---- verify / repair
+        for (;;) {
+            const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
+            const bool bad = lane > 0 && S != prevE;
+            if (!__any(bad)) break;
+            if (bad) { S = prevE; E = S; n = hpar_run(arr, E, cHi, tabOff, mask2); }
+        }
+        // ---- verdict for this stream
+        u32 incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+        const u32 total = (u32)__shfl((int)incl, 63, WAVE), endC = (u32)__shfl((int)E, 63, WAVE);
+        if (total != want || endC != C0 + T0[q]) { good = false; break; }   // uniform: not a stream the reference accepts as is
+        // ---- pass 2: my symbols again, stored sixteen at a time
+        {   u8* p = out + (size_t)q * seg + (incl - n);
+            u32 left = n, C = S;
+            while (left && ((uintptr_t)p & 3u)) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
+            if (left >= 16) {
+                HparBulk bk; bk.open(arr, C);
+                do {
+                    u32 w[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[t] = bk.iter(tabOff, mask2);
+                    __builtin_memcpy(p, w, 16);
+                    p += 16; left -= 16;
+                } while (left >= 16);
+                C = bk.cursor();
+            }
+            while (left) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
+        }
+        sp += L;
+    }
+    if (!good) { if (lane == 0) fbList[atomicAdd(fbCount, 1u)] = (u32)b; return; }
+    if (lane == 0) a.results[b] = dstSize;
+}
+
+// one-shot path: the parallel decoder over a class list; what it declines is appended to fbList (length *fbCount, zeroed by the
+// caller) for the serial decoder
+hipError_t launch_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    const size_t ldsBytes = ((size_t)2 << a.ldsLog) + HPAR_DATA_BYTES;
+    hipLaunchKernelGGL(k_huf_decode_par, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, fbList, fbCount);
+    return hipGetLastError();
+}

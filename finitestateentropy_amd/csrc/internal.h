@@ -176,7 +176,10 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
     size_t nBlocks;
 };
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
-hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, hipStream_t s);
+// one-shot path: per class list the stream-parallel decoder (huf_decode_par.hip) first; what it declines -- corrupt, tiny or irregular
+// blocks -- lands in fbLists / fbCounts (same shape as lists / counts) and is decoded by the serial kernel
+hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, u32* fbLists, u32* fbCounts, hipStream_t s);
+hipError_t launch_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount, hipStream_t s);
 
 // ---- workload generator -----------------------------------------------------------------------------
 hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, u32 seedStep, hipStream_t s);
