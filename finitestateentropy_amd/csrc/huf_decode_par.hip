@@ -90,18 +90,33 @@ struct HparBulk {
     }
 };
 
-// decode from C up to the first boundary at or beyond `limit`, counting symbols
+// decode from C up to the first boundary at or beyond `limit`, counting symbols: four at a time while that certainly stays below
+// the limit, then four at a time on trial -- the iteration that crosses the limit is taken back and redone symbol by symbol
 DEV u32 hpar_run(u32 arr, u32& C, u32 limit, u32 tabOff, u32 mask2)
 {
     u32 n = 0;
-    if (C + HPAR_NEAR < limit) {
+    if (C < limit) {
         HparBulk bk; bk.open(arr, C);
-        do { (void)bk.iter(tabOff, mask2); n += 4; C = bk.cursor(); } while (C + HPAR_NEAR < limit);
+        while (C + HPAR_NEAR < limit) { (void)bk.iter(tabOff, mask2); n += 4; C = bk.cursor(); }
+        for (;;) {                                                         // (at most a dozen trial iterations)
+            const HparBulk keep = bk;
+            (void)bk.iter(tabOff, mask2);
+            const u32 Cn = bk.cursor();
+            if (Cn >= limit) { bk = keep; break; }
+            n += 4; C = Cn;
+        }
+        while (C < limit) { (void)hpar_single(arr, C, tabOff, mask2); ++n; }   // at most four
     }
-    while (C < limit) { (void)hpar_single(arr, C, tabOff, mask2); ++n; }
     return n;
 }
 
+#ifdef HPAR_STATS            // development aid: repair rounds / bad links / cycles of the first blocks (scripts/hparstats.py)
+__device__ unsigned long long g_hparStats[4096 * 8];
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hparStats(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hparStats), sizeof(g_hparStats)); }
+#define HST(...) __VA_ARGS__
+#else
+#define HST(...)
+#endif
 __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 last = len[q] ? sp[len[q] - 1] : 0;
-            if (len[q] < 8 || len[q] + 80 > HPAR_DATA_BYTES || last == 0) ok = false;
+            if (len[q] < 8 || len[q] + 96 > HPAR_DATA_BYTES || last == 0) ok = false;
             else T0[q] = 8u * (len[q] - 1) + hibit32(last);              // unread bits under the end mark (bitstream.h:285-290)
             if (T0[q] < HPAR_MIN_BITS) ok = false;
             sp += len[q];
@@ -164,21 +179,43 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
 
     const u8* sp = in + 6;
     bool good = true;
+    HST(unsigned long long stRounds = 0, stBad = 0, tStage = 0, tP1 = 0, tRep = 0, tP2 = 0, tA = __builtin_readcyclecounter();)
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {                                        // uniform: stream after stream
         const u32 L = len[q], Sd = (L + 3) / 4;
         __syncthreads();                                                 // (table staged / previous stream done)
-        // consumption order: array dword m = bit-reversed stream dword Sd-1-m; zeros behind the end (= below the stream's first bit)
-        for (u32 m = lane; m < Sd + 16; m += 64) {
-            u32 v = 0;
-            if (m < Sd) {
-                const u32 d = Sd - 1 - m;
-                if (4 * d + 4 <= L) __builtin_memcpy(&v, sp + 4 * d, 4);
-                else for (u32 t = 4 * d; t < L; ++t) v |= (u32)sp[t] << (8 * (t & 3u));
+        // consumption order: array dword m = bit-reversed stream dword Sd-1-m; zeros behind the end (= below the stream's first bit).
+        // Units of four dwords, one 16-byte load each, all loads of a lane issued before the first LDS store; the top unit (its
+        // last dword may be partial) and the bottom one (the stream rarely starts on a unit boundary) go dword by dword.
+        {   const u32 units = (Sd + 3) / 4 + 4;                          // + 16 dwords of zeros
+            constexpr u32 MAXU = (HPAR_DATA_BYTES / 16 + 63) / 64;
+            uint4 buf[MAXU];
+#pragma unroll
+            for (u32 t = 0; t < MAXU; ++t) {
+                const u32 u = lane + 64 * t;
+                buf[t] = make_uint4(0, 0, 0, 0);
+                if (u >= units) continue;
+                const int dLo = (int)Sd - 4 - 4 * (int)u;                // lowest stream dword of the unit
+                if (u > 0 && dLo >= 0) __builtin_memcpy(&buf[t], sp + 4 * dLo, 16);
+                else {
+                    u32 w[4] = { 0, 0, 0, 0 };
+                    for (int i = 0; i < 4; ++i) {
+                        const int d = dLo + i;
+                        if (d < 0 || d >= (int)Sd) continue;
+                        if (4 * (u32)d + 4 <= L) __builtin_memcpy(&w[i], sp + 4 * d, 4);
+                        else for (u32 b8 = 4 * (u32)d; b8 < L; ++b8) w[i] |= (u32)sp[b8] << (8 * (b8 & 3u));
+                    }
+                    buf[t] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
             }
-            data[m] = __brev(v);
+#pragma unroll
+            for (u32 t = 0; t < MAXU; ++t) {
+                const u32 u = lane + 64 * t;
+                if (u < units) ((uint4*)data)[u] = make_uint4(__brev(buf[t].w), __brev(buf[t].z), __brev(buf[t].y), __brev(buf[t].x));
+            }
         }
         __syncthreads();
+        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tStage += tB - tA; tA = tB; })
         const u32 C0 = 32u * Sd - T0[q];                                 // cursor of the first code bit (bits above it: padding, end mark)
         const u32 want = q < 3 ? seg : (u32)dstSize - 3 * seg;
         const u32 stepA = (T0[q] + 63u) / 64u;
@@ -190,13 +227,16 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
         if (lane > 0) { u32 C = aLo > HPAR_WARM ? cLo - HPAR_WARM : C0; (void)hpar_run(arr, C, cLo, tabOff, mask2); S = C; }
         u32 E = S;
         u32 n = hpar_run(arr, E, cHi, tabOff, mask2);
+        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
         // ---- verify / repair
         for (;;) {
             const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
             const bool bad = lane > 0 && S != prevE;
             if (!__any(bad)) break;
+            HST(++stRounds; stBad += __builtin_popcountll(__ballot(bad));)
             if (bad) { S = prevE; E = S; n = hpar_run(arr, E, cHi, tabOff, mask2); }
         }
+        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tRep += tB - tA; tA = tB; })
         // ---- verdict for this stream
         u32 incl = n;
 #pragma unroll
@@ -216,12 +256,15 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
                     __builtin_memcpy(p, w, 16);
                     p += 16; left -= 16;
                 } while (left >= 16);
+                while (left >= 4) { const u32 w = bk.iter(tabOff, mask2); __builtin_memcpy(p, &w, 4); p += 4; left -= 4; }
                 C = bk.cursor();
             }
             while (left) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
         }
         sp += L;
+        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP2 += tB - tA; tA = tB; })
     }
+    HST(if (lane == 0 && slot < 4096) { unsigned long long* t = g_hparStats + 8 * slot; t[0] = stRounds; t[1] = stBad; t[2] = tStage; t[3] = tP1; t[4] = tRep; t[5] = tP2; })
     if (!good) { if (lane == 0) fbList[atomicAdd(fbCount, 1u)] = (u32)b; return; }
     if (lane == 0) a.results[b] = dstSize;
 }
