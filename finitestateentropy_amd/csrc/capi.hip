@@ -572,7 +572,7 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
     return 0;
 }
 
-static const size_t HUF_DWS_PER_BLOCK = sizeof(HufMeta) + 4 * (size_t)FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1) + 2 * HUF_DCLS_COUNT * sizeof(u32);
+static const size_t HUF_DWS_PER_BLOCK = sizeof(HufMeta) + 4 * (size_t)FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1) + HUF_DCLS_COUNT * sizeof(u32);
 extern "C" size_t FSEHIP_HUF_decompress_batch_workspaceSize(size_t nBlocks)
 {
     size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
@@ -594,8 +594,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
     HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
     u32* dtables = (u32*)p; p += align_up(chunk * dtU32 * 4, 256);
     u32* lists = (u32*)p; p += align_up(chunk * HUF_DCLS_COUNT * sizeof(u32), 256);
-    u32* fbLists = (u32*)p; p += align_up(chunk * HUF_DCLS_COUNT * sizeof(u32), 256);
-    u32* counts = (u32*)p; u32* fbCounts = counts + HUF_DCLS_COUNT;
+    u32* counts = (u32*)p;
     for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
         const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
         const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
@@ -608,7 +607,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstSizes = ds; e.results = d_results + b0;
         e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
         e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.acceptX2 = 0; e.nBlocks = nb;
-        CK(launch_huf_decode_classes(e, lists, counts, fbLists, fbCounts, s));
+        CK(launch_huf_decode_classes(e, lists, counts, s));
     }
     return 0;
 }

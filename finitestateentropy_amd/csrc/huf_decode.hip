@@ -514,23 +514,19 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
     return e;
 }
 
-// one-shot path: k_huf_dprep has sorted the blocks into two lists by their tableLog (<= 11: 4 KiB table slots, 14 blocks per
-// workgroup; 12: 8 KiB slots, 8 blocks per workgroup); one launch per list
-hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, u32* fbLists, u32* fbCounts, hipStream_t s)
+// one-shot path: k_huf_dprep has sorted the blocks into class lists (internal.h: by tableLog -- 4 KiB or 8 KiB LDS table slots --
+// and by decoder); one launch per list, the serial decoder's last because the parallel one appends what it declines to them
+hipError_t launch_huf_decode_classes(HufDecArgs a, u32* lists, u32* counts, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(fbCounts, 0, HUF_DCLS_COUNT * sizeof(u32), s);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
     probe_before(PK_HUF_DECODE, s);
     for (int c = 0; c < HUF_DCLS_COUNT && e == hipSuccess; ++c) {
+        const int kind = c >> 1, ser = 2 * HUF_DKIND_SERIAL + (c & 1);
         a.list = lists + (size_t)c * a.nBlocks; a.count = counts + c;
-        a.ldsLog = c == 0 ? HD_SLOT_LOG : FSEHIP_HUF_TABLELOG_MAX;
-        e = launch_huf_decode_par(a, fbLists + (size_t)c * a.nBlocks, fbCounts + c, s);
-    }
-    for (int c = 0; c < HUF_DCLS_COUNT && e == hipSuccess; ++c) {      // the declined blocks: serial decoder, literal verdicts
-        a.list = fbLists + (size_t)c * a.nBlocks; a.count = fbCounts + c;
-        a.ldsLog = c == 0 ? HD_SLOT_LOG : FSEHIP_HUF_TABLELOG_MAX;
-        e = huf_decode_launch(a, s);
+        a.ldsLog = (c & 1) ? FSEHIP_HUF_TABLELOG_MAX : HD_SLOT_LOG;
+        if (kind == HUF_DKIND_SERIAL) e = huf_decode_launch(a, s);
+        else e = launch_huf_decode_par(a, kind == HUF_DKIND_PAR_TINY ? HPAR_DATA_TINY : kind == HUF_DKIND_PAR_SMALL ? HPAR_DATA_SMALL : HPAR_DATA_LARGE, lists + (size_t)ser * a.nBlocks, counts + ser, s);
     }
     probe_after(PK_HUF_DECODE, s);
     return e;

@@ -19,6 +19,13 @@
 //   Pass 2: a 64-lane prefix sum of n_j gives every lane its place in the output; it decodes its symbols again and stores them
 //     sixteen at a time.
 //
+// The kernel is latency-bound (a dependent LDS look-up per symbol), so what counts is waves per CU = LDS per wave: the table slot
+// plus ONE staged stream.  k_huf_dprep reads the jump table and files every block under the smallest of three per-stream budgets
+// that holds its longest stream (internal.h: 2.3 / 4.6 / 8.4 KB -> 25 / 18 / 12 waves per CU with 4 KiB tables), one launch each;
+// measured per 100k 32 KB blocks: P80 3.46 -> 2.7 ms, P14 3.4 -> 3.0 ms, P02 (incompressible, 7 KB streams) 3.65 unchanged.
+//   (Dead end: a workgroup of four waves, one per stream, sharing the table -- 28 waves per CU with the small budget -- P80 2.6 ms
+//   but P14 3.8 and P02 5.0: the workgroup lives as long as its slowest stream and the LDS pipe is already half busy.)
+//
 // 64 busy lanes per block instead of 4 and no service waves.  In LDS: the table (bit-reversed {nbBits, byte} cells as in
 // huf_decode.hip) and the current stream, staged with coalesced loads IN CONSUMPTION ORDER (dword m = bit-reversed stream dword
 // top - m), so that the decoding loop is the serial kernel's: a cursor Q = consumed bits - 1, bits taken from the low end of a
@@ -31,8 +38,6 @@
 
 #define HPAR_WARM 128u                // warm-up bits in front of a range
 #define HPAR_NEAR 48u                 // four symbols consume at most 48 bits: closer than this to a limit the lane steps by symbols
-#define HPAR_MIN_BITS 4096u           // streams shorter than this go to the serial decoder (ranges must dwarf warm-up and codes)
-#define HPAR_DATA_BYTES (8192u + 256u) // LDS budget for one staged stream (+ zero padding behind its end)
 
 typedef const __attribute__((address_space(3))) u16* hpar_lds_u16;
 typedef const __attribute__((address_space(3))) u32* hpar_lds_u32;
@@ -117,6 +122,7 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hparStats(uns
 #else
 #define HST(...)
 #endif
+template <u32 DATA>
 __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -150,13 +156,13 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 last = len[q] ? sp[len[q] - 1] : 0;
-            if (len[q] < 8 || len[q] + 96 > HPAR_DATA_BYTES || last == 0) ok = false;
+            if (len[q] < 8 || len[q] + 96 > DATA || last == 0) ok = false;
             else T0[q] = 8u * (len[q] - 1) + hibit32(last);              // unread bits under the end mark (bitstream.h:285-290)
             if (T0[q] < HPAR_MIN_BITS) ok = false;
             sp += len[q];
         }
     }
-    if (!ok) {                                                           // uniform
+    if (!ok) {                                                           // uniform (rare: k_huf_dprep has looked at the jump table)
         if (lane == 0) fbList[atomicAdd(fbCount, 1u)] = (u32)b;
         return;
     }
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
         // Units of four dwords, one 16-byte load each, all loads of a lane issued before the first LDS store; the top unit (its
         // last dword may be partial) and the bottom one (the stream rarely starts on a unit boundary) go dword by dword.
         {   const u32 units = (Sd + 3) / 4 + 4;                          // + 16 dwords of zeros
-            constexpr u32 MAXU = (HPAR_DATA_BYTES / 16 + 63) / 64;
+            constexpr u32 MAXU = (DATA / 16 + 63) / 64;
             uint4 buf[MAXU];
 #pragma unroll
             for (u32 t = 0; t < MAXU; ++t) {
@@ -269,12 +275,21 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     if (lane == 0) a.results[b] = dstSize;
 }
 
-// one-shot path: the parallel decoder over a class list; what it declines is appended to fbList (length *fbCount, zeroed by the
-// caller) for the serial decoder
-hipError_t launch_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount, hipStream_t s)
+// (Measured: a grid of resident waves striding over the list instead of one wave per block -- cheaper empty launches for the
+// classes without blocks -- is 5 to 35 % slower on the class that has them.)
+template <u32 DATA>
+static hipError_t hpar_launch(const HufDecArgs& a, u32* serialList, u32* serialCount, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_huf_decode_par<DATA>, dim3((unsigned)a.nBlocks), dim3(64), ((size_t)2 << a.ldsLog) + DATA, s, a, serialList, serialCount);
+    return hipGetLastError();
+}
+
+// one-shot path: the parallel decoder over a class list, `dataBytes` of LDS per staged stream (with 4 KiB tables HPAR_DATA_TINY:
+// 25 waves per CU, HPAR_DATA_SMALL: 18, HPAR_DATA_LARGE: 12); what it declines is appended to the serial decoder's list
+hipError_t launch_huf_decode_par(HufDecArgs a, unsigned dataBytes, u32* serialList, u32* serialCount, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const size_t ldsBytes = ((size_t)2 << a.ldsLog) + HPAR_DATA_BYTES;
-    hipLaunchKernelGGL(k_huf_decode_par, dim3((unsigned)a.nBlocks), dim3(64), ldsBytes, s, a, fbList, fbCount);
-    return hipGetLastError();
+    if (dataBytes == HPAR_DATA_TINY) return hpar_launch<HPAR_DATA_TINY>(a, serialList, serialCount, s);
+    if (dataBytes == HPAR_DATA_SMALL) return hpar_launch<HPAR_DATA_SMALL>(a, serialList, serialCount, s);
+    return hpar_launch<HPAR_DATA_LARGE>(a, serialList, serialCount, s);
 }

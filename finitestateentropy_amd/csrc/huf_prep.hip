@@ -675,6 +675,21 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
                 }
             }
         }
+        if (state == 1) {                                                  // which decoder?  (until phase D: the kind, kept in DS_CLS)
+            const u8* const in = view_ptr(a.csrc, b);
+            const size_t cSize = view_size(a.csrc, b), hdr = sc[DS_HDR];
+            u32 kind = HUF_DKIND_SERIAL;
+            if (cSize >= hdr + 10 && view_size(a.dstSizes, b) >= 64) {     // the jump table (huf_decompress.c:277-287)
+                const u8* const jt = in + hdr;
+                const size_t l0 = jt[0] | ((u32)jt[1] << 8), l1 = jt[2] | ((u32)jt[3] << 8), l2 = jt[4] | ((u32)jt[5] << 8), used = 6 + l0 + l1 + l2;
+                if (used < cSize - hdr) {
+                    const size_t l3 = cSize - hdr - used;
+                    const size_t mn = min(min(l0, l1), min(l2, l3)), mx = max(max(l0, l1), max(l2, l3));
+                    if (8 * mn >= HPAR_MIN_BITS + 8) kind = mx + 96 <= HPAR_DATA_TINY ? HUF_DKIND_PAR_TINY : mx + 96 <= HPAR_DATA_SMALL ? HUF_DKIND_PAR_SMALL : mx + 96 <= HPAR_DATA_LARGE ? HUF_DKIND_PAR_LARGE : HUF_DKIND_SERIAL;
+                }
+            }
+            sc[DS_CLS] = kind;
+        }
         sc[DS_STATE] = state; sc[DS_RESULT_LO] = (u32)result; sc[DS_RESULT_HI] = (u32)(result >> 32);
     }
     __syncthreads();
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             if (err) result = err;
             else { m.state = 1; m.hdrSize = hdr; m.tableLog = tl; }
         }
-        if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; sc[DS_CLS] = m.state ? (m.tableLog > 11u ? 1u : 0u) : 0xFFFFFFFFu; }
+        if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; sc[DS_CLS] = m.state ? 2u * sc[DS_CLS] + (m.tableLog > 11u ? 1u : 0u) : 0xFFFFFFFFu; }
         __syncthreads();
     }
     __syncthreads();

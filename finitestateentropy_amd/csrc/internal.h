@@ -145,7 +145,14 @@ struct HufEncArgs {              // a4: HUF_compress4X_usingCTable (streams = 4)
 };
 hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s);
 
-enum { HUF_DCLS_COUNT = 2 };      // decoder classes by tableLog: 0 = up to 11 (4 KiB LDS table slots), 1 = 12 (8 KiB)
+// decoder classes: class = 2 * kind + (tableLog == 12).  tableLog up to 11: 4 KiB LDS table slots, 12: 8 KiB.  kind: the
+// stream-parallel decoder (huf_decode_par.hip) with one of its three LDS budgets per staged stream, or the serial decoder (tiny and
+// irregular blocks, chosen by k_huf_dprep from the jump table; the parallel decoder appends what it declines to the serial lists)
+enum { HUF_DKIND_PAR_TINY = 0, HUF_DKIND_PAR_SMALL = 1, HUF_DKIND_PAR_LARGE = 2, HUF_DKIND_SERIAL = 3, HUF_DCLS_COUNT = 8 };
+#define HPAR_DATA_TINY  2304u           // LDS budgets for one staged stream (+ 96 bytes of zero padding behind its end)
+#define HPAR_DATA_SMALL 4608u
+#define HPAR_DATA_LARGE (8192u + 256u)
+#define HPAR_MIN_BITS 4096u             // streams shorter than this go to the serial decoder (ranges must dwarf warm-up and codes)
 struct HufDPrepArgs {            // glue g6: HUF_readStats + HUF_readDTableX1 (+ raw / RLE decisions of HUF_decompress)
     BlockView csrc;
     BlockView dstSizes;          // only sizes/uniform used
@@ -176,10 +183,10 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
     size_t nBlocks;
 };
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
-// one-shot path: per class list the stream-parallel decoder (huf_decode_par.hip) first; what it declines -- corrupt, tiny or irregular
-// blocks -- lands in fbLists / fbCounts (same shape as lists / counts) and is decoded by the serial kernel
-hipError_t launch_huf_decode_classes(HufDecArgs a, const u32* lists, const u32* counts, u32* fbLists, u32* fbCounts, hipStream_t s);
-hipError_t launch_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount, hipStream_t s);
+// one-shot path: one launch per class list, the stream-parallel decoder's first; what it declines -- corrupt or irregular blocks --
+// it appends to the serial list of the same tableLog, decoded by the serial kernel afterwards
+hipError_t launch_huf_decode_classes(HufDecArgs a, u32* lists, u32* counts, hipStream_t s);
+hipError_t launch_huf_decode_par(HufDecArgs a, unsigned dataBytes, u32* serialList, u32* serialCount, hipStream_t s);
 
 // ---- workload generator -----------------------------------------------------------------------------
 hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, u32 seedStep, hipStream_t s);
