@@ -45,14 +45,21 @@
 // the fast ones (bitstream.h:378-388), so it is reconstructed from the cursor when the bulk loop ends.
 // NB0 = some cell of some table staged by this workgroup has nbBits == 0: a v_alignbit by 32 would return the low
 // word, so that one select is made explicit.
-#define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration
+#ifndef FSE_DEC_RING
+#define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration = four phases.  (Any multiple of
+#endif                           // FSE_CHECK_EVERY works.  Measured with 48 entries, which makes room for a 17th block per workgroup: the lanes of
+                                 // the decoder wave fall out of step waiting for their flushes -- 541 instead of 481 phase rounds per 32 KB block,
+                                 // service waves 96 % busy -- 14.6 ms per 100k blocks instead of 12.9.)
 #define FSE_IN_RING 256          // per-block LDS input ring (bytes of compressed stream, direct-mapped by offset mod 256)
 #define FSE_IN_RING_LOG 8
 #define FSE_IN_CHUNK 64          // refill granule: one 4-byte load per lane of a 16-lane group (one group per block of a service wave)
 #define FSE_IN_LANES (FSE_IN_CHUNK / 4)
 #define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so reads of 2 dwords never wrap
 #define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
-#define FSE_MAXG 16              // blocks per workgroup
+#ifndef FSE_SRV_WAVES
+#define FSE_SRV_WAVES 4
+#endif
+#define FSE_MAXG (4 * FSE_SRV_WAVES)              // blocks per workgroup at most (FSE_SRV_WAVES x FSE_SRV_G; the LDS holds 16 with 4 KiB tables)
 
 #ifdef FSE_DEC_TIMING       // development aid: per-workgroup cycle accounting of the decoder and service waves
 __device__ unsigned long long g_decTiming[4096 * 8];
@@ -182,7 +189,6 @@ struct DecCtl {
     int initValidLo;   // set-up constants for the service wave
     int S32;
     u32 inLo, inHi, outLo, outHi, symLo, symHi;
-    u32 pad[4];
 };
 #define FSE_DEC_THREADS (64 * (1 + FSE_SRV_WAVES))     // wave 0 decodes, the others serve
 
@@ -200,8 +206,11 @@ DEV void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, _
 //        * output: record i of a block = the 4 states (as cell addresses) iteration i decoded FROM; symbol = symbolOf[state], gathered
 //                  from the L2-resident table in global memory (byte table from k_fse_dbuild, or the symbol bytes of the
 //                  reference-layout cells: stride 1 << symShift), packed, stored as one 256-byte row per 64 records.
-#define FSE_SRV_WAVES 4
-#define FSE_SRV_G (FSE_MAXG / FSE_SRV_WAVES)
+#define FSE_SRV_G 4
+#ifndef FSE_FLUSH_MIN
+#define FSE_FLUSH_MIN 32u        // records (of 4 symbols) a block must have before its row is flushed
+#endif
+static_assert(FSE_SRV_WAVES * FSE_SRV_G == FSE_MAXG, "every block of a workgroup has a service wave");
 DEV void fse_ring_put(u32* rg, int off, u32 w)
 {
     const u32 j = (u32)off & (FSE_IN_RING - 1);
@@ -223,7 +232,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
     const unsigned long long tabBits = ((unsigned long long)ctl->symHi << 32) | ctl->symLo;
     const int S32 = ctl->S32;
     int validLo = ctl->initValidLo;
-    u32 flushed = 0;
+    u32 flushed = 0, fpos = 0;                               // records flushed so far, and that count modulo the ring size
     bool live = lane < FSE_SRV_G && myG < a.G && !(ctl->pubPofs >> 31);   // blocks that never enter the bulk loop need no service
 
     // Input refills: the 16-lane group k of this wave serves block g0 + k, so one load instruction and one LDS store
@@ -261,7 +270,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         const bool fin = (pp >> 31) != 0;
         const int P = (int)(pp & 0x7FFFFFFFu);               // byte offset of the topmost dword the decoder still reads
         const u32 avail = it - flushed;
-        const bool wantFlush = live && (avail >= 32u || (fin && avail > 0));
+        const bool wantFlush = live && (avail >= FSE_FLUSH_MIN || (fin && avail > 0));
         // the chunk [validLo-CHUNK, validLo) lands on the ring bytes of [validLo+RING-CHUNK, validLo+RING): the decoder must be below
         const bool wantFill = live && !fin && validLo > 0 && P + 4 <= validLo + (FSE_IN_RING - FSE_IN_CHUNK);
         const unsigned long long fm = __ballot(wantFlush), rm = __ballot(wantFill);
@@ -284,11 +293,12 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 #pragma unroll
         for (int l = 0; l < FSE_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;               // uniform
-            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
+            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
             const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, l, WAVE);
             if ((u32)lane < cnt) {
                 // iteration i lives in slot pair (i >> 1): 16 bytes = lane A's {iteration 2p, 2p+1} words, then lane B's
-                const u32 ri = (fl_g + lane) & (FSE_DEC_RING - 1);
+                u32 ri = fp_g + (u32)lane;
+                ri = ri >= FSE_DEC_RING ? ri - FSE_DEC_RING : ri;
                 const u32* const rw = (const u32*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff) + 4u * (ri >> 1) + (ri & 1u);
                 uint2 rec; rec.x = rw[0]; rec.y = rw[2];      // x: state 1 before symbols 0 / 2, y: state 2 before symbols 1 / 3
                 // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+ldsLog)
@@ -312,7 +322,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
                 __builtin_memcpy(og + 4u * lane, &w, 4);
             }
         }
-        if (wantFlush) flushed = it;
+        if (wantFlush) { fpos += it - flushed; fpos = fpos >= FSE_DEC_RING ? fpos - FSE_DEC_RING : fpos; flushed = it; }
         TIMING({ const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy; })
     }
     TIMING(if (lane == 0 && g0 == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[4] = sBusy; t[5] = sIdle; t[6] = nBusy; })
@@ -358,7 +368,7 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
 }
 
 // LDS: G tables A[2^ldsLog] (u16) on table-size aligned addresses | DecCtl[G] | per block: state ring
-// (64 x 8 B), input ring (256 + 16 B)
+// (FSE_DEC_RING x 8 B), input ring (256 + 16 B) | two flag words
 template <bool FAST>
 __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // ---- stage: reference cells {u16 newState; u8 symbol; u8 nbBits} -> compact u16 (uniform control flow, both waves).
     //      A table whose fields do not fit 12+4 bits (cannot come from FSE_buildDTable) is flagged and decoded
     //      by the literal path only.
-    u32* const flagsSh = ctlAll[0].pad;                          // [0] bad-table mask, [1] any nbBits == 0
+    u32* const flagsSh = (u32*)(ldsb + (size_t)a.G * slotBytes);  // behind the slots: [0] bad-table mask, [1] any nbBits == 0
     if (tid < 2) flagsSh[tid] = 0;
     __syncthreads();
     {   u32 badBits = 0; bool anyNb0 = false;
@@ -526,6 +536,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // round, so their LDS round trip hides under this round's phase.  Stale values are conservative (srvFlushed only grows,
     // srvValidLo only falls); LDS operations of one wave execute in order, so the ring reads of a phase cannot overtake
     // the progress loads they depend on (the compiler is held back by the barrier in ctl_peek).
+    u32 rpos = 0;                                    // iters modulo the ring size
     u32 flNext = ctl_peek(&ctl->srvFlushed);
     int vloNext = ctl_peek(&ctl->srvValidLo);
     while (__any(can)) {
@@ -537,7 +548,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         // (bit-reversed loop: 16 iterations of at most 44 bits, three window dwords below the last one -> 92 bytes below q + 8)
         const bool ready = can && (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - (FAST ? 84 : 6 * FSE_CHECK_EVERY + 8) >= vlo);
         if (ready) {
-            uint2* const ring = myRing + (iters & (FSE_DEC_RING - 1));       // 16 consecutive slots: a phase never wraps
+            uint2* const ring = myRing + rpos;                               // 16 consecutive slots: a phase never wraps
+            rpos = rpos + FSE_CHECK_EVERY == FSE_DEC_RING ? 0u : rpos + FSE_CHECK_EVERY;
             if (FAST) {
                 fse_bulk_phase_rev(bs.s, P, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
                 const u32 B = R8 - P;
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
     *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
-    int g = (int)(ldsBytes / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));
+    int g = (int)((ldsBytes - 16) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (16 bytes: the flag words)
     if (g > FSE_MAXG) g = FSE_MAXG;
     *G = g;
 }
