@@ -85,8 +85,10 @@ DEV u32 he_count_tile(const HeTile& t, u32 len, u32 j0, const u32* ct, u32 lane)
 }
 // pass 2 over one tile: every lane packs its 16 symbols of a row into four <= 48-bit chunks; one wave prefix sum per row
 // gives the lane's bit position; the chunks are OR-ed into the image.  Returns the bit position behind the tile.
+// `limit`: bits the image may hold; a row that would pass it is not written and HE_OVERFLOW is returned (uniform).
+#define HE_OVERFLOW (~(u64)0)
 template <bool GLOBAL>
-DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, const u32* ct, u32 lane)
+DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, const u32* ct, u32 lane, u64 limit = HE_OVERFLOW)
 {
 #pragma unroll
     for (u32 r = 0; r < HE_ROWS; ++r) {
@@ -107,10 +109,12 @@ DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, co
             cb[c] = bits; cn[c] = nb; tot += nb;
         }
         const u32 incl = wave_incl_scan_u32(tot, lane);
+        const u32 rowBits = (u32)__shfl((int)incl, 63, WAVE);
+        if (rowBase + rowBits > limit) return HE_OVERFLOW;   // uniform
         u64 pos = rowBase + (incl - tot);
 #pragma unroll
         for (u32 c = 0; c < 4; ++c) { or_bits<GLOBAL>(img, pos, cb[c], cn[c]); pos += cn[c]; }
-        rowBase += (u32)__shfl((int)incl, 63, WAVE);
+        rowBase += rowBits;
     }
     return rowBase;
 }
@@ -147,11 +151,43 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     const u32 myStart = wave * segSize;
     const u32 myLen = (int)wave < streams ? (streams == 4 && wave == 3 ? n - 3 * segSize : segSize) : 0;
 
-    // ---- pass 1: code bits of my stream (the first tile stays in registers for pass 2)
     const u8* const seg = src + myStart;
     HeTile tile0;
     he_load_tile(tile0, seg, myLen, 0, lane);
-    {   // every tile is loaded while the one before it is being processed
+
+    // ---- single pass (4 streams): every wave emits its stream from bit 0 of its own quarter of the image; the sizes are then
+    //      known and the streams are moved to their places while being copied out (byte-granular: every stream starts on a
+    //      byte).  A stream that does not fit its quarter (> 8 KB from an 8 KB segment: the block is all but incompressible)
+    //      sends the block to the two-pass path below.
+    const u32 regionBytes = (imgBytes / 4u) & ~15u;
+    bool single = streams == 4 && regionBytes >= 1024u;
+    if (single) {
+        {   uint4* const z = (uint4*)img;
+            for (u32 i = tid; i < regionBytes / 4u; i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0); }
+        if (tid < 8) sh[tid] = 0;
+        __syncthreads();
+        u32* const region = img + wave * (regionBytes / 4u);
+        const u64 limit = 8ull * regionBytes - 64u;
+        u64 pos = 0;
+        HeTile cur = tile0;
+        for (u32 j0 = 0; j0 < myLen && pos != HE_OVERFLOW; j0 += HE_TILE) {
+            HeTile nxt = cur;
+            if (j0 + HE_TILE < myLen) he_load_tile(nxt, seg, myLen, j0 + HE_TILE, lane);
+            __asm__ volatile("" ::: "memory");
+            pos = he_emit_tile<false>(region, pos, cur, myLen, j0, ct, lane, limit);
+            cur = nxt;
+        }
+        if (lane == 0) {
+            if (pos == HE_OVERFLOW) sh[4] = 1;
+            else { or_bits<false>(region, pos, 1, 1); sh[wave] = (u32)pos; }
+        }
+        __syncthreads();
+        if (sh[4]) single = false;                               // uniform
+        __syncthreads();
+    }
+
+    // ---- pass 1 of the two-pass path: code bits of my stream (the first tile stays in registers for pass 2)
+    if (!single) {   // every tile is loaded while the one before it is being processed
         u32 bits = 0;
         HeTile cur = tile0;
         for (u32 j0 = 0; j0 < myLen; j0 += HE_TILE) {
@@ -181,6 +217,28 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     size_t result = fail ? 0 : total;
     if (a.meta && !fail) result = ((size_t)hdr + total < n64 - 1) ? (size_t)hdr + total : 0;   // huf_compress.c:625
     if (result == 0) { if (tid == 0) a.results[b] = 0; return; }
+
+    if (single) {
+        // ---- copy-out of the single-pass path: wave k moves stream k; output dwords on aligned addresses, each from two image
+        //      dwords (v_alignbyte), the edges bytewise; the jump table goes out bytewise too
+        const u32* const region = img + wave * (regionBytes / 4u);
+        u8* const D = dst + start[wave];
+        const u32 size = (u32)ssize[wave];
+        u32 h = (u32)((0 - (uintptr_t)D) & 3u);
+        h = h < size ? h : size;
+        const u8* const rb = (const u8*)region;
+        if (lane < h) D[lane] = rb[lane];
+        const u32 nW = (size - h) / 4u;
+        for (u32 i = lane; i < nW; i += 64) {
+            const u32 w = __builtin_amdgcn_alignbyte(region[i + 1], region[i], h);
+            *(u32*)(D + h + 4u * i) = w;
+        }
+        const u32 done = h + 4u * nW;
+        if (lane < size - done) D[done + lane] = rb[done + lane];
+        if (lane == 0 && wave < 3) { dst[2 * wave] = (u8)ssize[wave]; dst[2 * wave + 1] = (u8)(ssize[wave] >> 8); }
+        if (tid == 0) a.results[b] = result;
+        return;
+    }
 
     // ---- pass 2: emit.  The image is addressed from the 4-byte aligned word holding dst[0].
     const u32 lead = (u32)((uintptr_t)dst & 3u);
