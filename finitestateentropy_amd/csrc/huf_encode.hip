@@ -95,18 +95,29 @@ DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, co
         const u32 j = j0 + r * 1024u + 16u * lane;
         if (j0 + r * 1024u >= len) break;                    // uniform
         u64 cb[4]; u32 cn[4]; u32 tot = 0;
+        if (j0 + (r + 1) * 1024u <= len) {                   // uniform: a whole row -- no per-symbol bounds, codes joined in pairs (<= 22 bits) first
 #pragma unroll
-        for (u32 c = 0; c < 4; ++c) {
-            u64 bits = 0; u32 nb = 0;
-#pragma unroll
-            for (u32 k = 0; k < 4; ++k) {
-                if (j + 4 * c + k < len) {
-                    const u32 e = ct[he_sym(t.v[r], 4 * c + k)];
-                    bits |= (u64)(e & 0xFFFFu) << nb;
-                    nb += (e >> 16) & 0xFFu;
-                }
+            for (u32 c = 0; c < 4; ++c) {
+                const u32 e0 = ct[he_sym(t.v[r], 4 * c)], e1 = ct[he_sym(t.v[r], 4 * c + 1)], e2 = ct[he_sym(t.v[r], 4 * c + 2)], e3 = ct[he_sym(t.v[r], 4 * c + 3)];
+                const u32 n0 = (e0 >> 16) & 0xFFu, n1 = (e1 >> 16) & 0xFFu, n2 = (e2 >> 16) & 0xFFu, n3 = (e3 >> 16) & 0xFFu;
+                const u32 p01 = ((e1 & 0xFFFFu) << n0) | (e0 & 0xFFFFu), p23 = ((e3 & 0xFFFFu) << n2) | (e2 & 0xFFFFu);
+                const u32 n01 = n0 + n1;
+                cb[c] = (u64)p01 | ((u64)p23 << n01); cn[c] = n01 + n2 + n3; tot += cn[c];
             }
-            cb[c] = bits; cn[c] = nb; tot += nb;
+        } else {
+#pragma unroll
+            for (u32 c = 0; c < 4; ++c) {
+                u64 bits = 0; u32 nb = 0;
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) {
+                    if (j + 4 * c + k < len) {
+                        const u32 e = ct[he_sym(t.v[r], 4 * c + k)];
+                        bits |= (u64)(e & 0xFFFFu) << nb;
+                        nb += (e >> 16) & 0xFFu;
+                    }
+                }
+                cb[c] = bits; cn[c] = nb; tot += nb;
+            }
         }
         const u32 incl = wave_incl_scan_u32(tot, lane);
         const u32 rowBits = (u32)__shfl((int)incl, 63, WAVE);
