@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="headline only (skip configs 3/4/5 and the tableLog-12 variants)")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--cfg5-blocks", type=int, default=125000, help="blocks per GPU of config 5 (1M / 8)")
+    ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=32768)
     ap.add_argument("--cpu-seconds", type=float, default=1.0, help="minimum timed seconds per direction and repetition")
@@ -172,6 +173,59 @@ def check_parity(cd, rank, n_check=1024):
     for b in range(len(rh)):
         assert (dh[b][:rh[b]] == odst[b][:rh[b]]).all(), "%s encode bytes differ from the CPU %s (block %d)" % (cd.name, lib.kind, int(idx[b]))
     return parity + "+%s-bytes-%d-blocks-strided" % (lib.kind, len(rh))
+
+
+def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
+    """the 16-bit-symbol coder (lib/fseU16.c; what programs/bench.c:221,248 times in its U16 mode) -- round trip of
+    n_blocks x 16384 symbols (= 32 KB) per GPU.  Corpus: 256 distinct blocks from the generator of programs/fuzzerU16.c:107-134
+    (p = 0.08 from symbol 240, wrapping inside the 287-symbol alphabet), tiled; bytes checked against the compiled reference."""
+    nsym, distinct = BLOCK // 2, 256
+    rng = np.random.default_rng(16)
+    table = np.zeros(4096, np.uint16)
+    remaining, pos, val = 4096, 0, 240
+    while remaining:
+        k = int(remaining * 0.08) + 1
+        table[pos:pos + k] = val
+        pos += k; remaining -= k
+        val = val + 1 if val + 1 < 286 else 1
+    host = table[rng.integers(0, 4096, (distinct, nsym))]
+    base = torch.from_numpy(host.view(np.int16)).to(dev)
+    src = base.repeat((n_blocks + distinct - 1) // distinct, 1)[:n_blocks].contiguous()
+    cdst, cres = hip.fse_compress_u16_batch(src)
+    out, dres = hip.fse_decompress_u16_batch(cdst, cres, nsym)
+    torch.cuda.synchronize()
+    assert bool((dres == nsym).all()) and torch.equal(out, src), "u16 decode(encode(x)) != x"
+    parity = "roundtrip-all-blocks"
+    if rank == 0:
+        try:
+            from oracle.oracle import Ref
+            if Ref.available():
+                ref = Ref()
+                ch, rh = cdst[:distinct:4].cpu().numpy(), cres[:distinct:4].cpu().numpy()
+                for b in range(len(rh)):
+                    rr, rout = ref.fse_compress_u16(host[4 * b], 0, 0)
+                    assert rr == int(rh[b]) and (rout[:rr] == ch[b][:rr]).all(), "u16 encode differs from the reference (block %d)" % (4 * b)
+                parity += "+reference-bytes-%d-blocks" % len(rh)
+        except OSError:
+            parity += "(checker unavailable)"
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        hip.fse_compress_u16_batch(src, dst=cdst, results=cres); ev[2 * i + 1].record()
+        hip.fse_decompress_u16_batch(cdst, cres, nsym, dst=out, results=dres); ev[2 * i + 2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    enc = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)) * 1e-3
+    dec = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(steps)) * 1e-3
+    elapsed, enc, dec = reduce_max([elapsed, enc, dec])
+    total = world * n_blocks * BLOCK * steps
+    return {"value": round(total / 2.0 ** 20 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "blocks_per_gpu": n_blocks,
+            "encode_GBps": round(total / enc / 1e9, 2), "decode_GBps": round(total / dec / 1e9, 2),
+            "compressed_bytes_per_block": round(float(cres.sum().item()) / n_blocks, 1), "parity": parity,
+            "workload": "16-bit symbols (lib/fseU16.c): %d x 16384 symbols per GPU, 287-symbol alphabet (fuzzerU16's generator, p = 0.08), "
+                        "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the chains run one lane per block" % n_blocks}
 
 
 def run_case(hip, codecs, steps, warmup, barrier, rank, check=True):
@@ -366,6 +420,8 @@ def main():
                         "codecs' fixed-stride compressed slots and sizes; one pass, untimed warm-up = the compute-only run above" % n_total}
             del corpus, gathered
         del s5, cds5
+        if hasattr(hip, "fse_compress_u16_batch"):
+            configs["fse_u16"] = u16_case(hip, dev, args.u16_blocks, cs, barrier, reduce_max, world, rank)
 
     if rank != 0:
         if dist is not None:

@@ -73,7 +73,9 @@ class FseHip:
                      "FSEHIP_HUF_compress", "FSEHIP_HUF_compress2", "FSEHIP_HUF_decompress",
                      "FSEHIP_FSE_compress_batch_workspaceSize", "FSEHIP_FSE_decompress_batch_workspaceSize",
                      "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize",
-                     "FSEHIP_frame_compressBound", "FSEHIP_frame_compress", "FSEHIP_frame_decompress"):
+                     "FSEHIP_frame_compressBound", "FSEHIP_frame_compress", "FSEHIP_frame_decompress",
+                     "FSEHIP_FSE_countU16", "FSEHIP_FSE_compressU16", "FSEHIP_FSE_decompressU16",
+                     "FSEHIP_FSE_compressU16_batch_workspaceSize", "FSEHIP_FSE_decompressU16_batch_workspaceSize"):
             if hasattr(L, name):
                 getattr(L, name).restype = SZ
         L.FSEHIP_getErrorName.restype = C.c_char_p
@@ -336,3 +338,91 @@ def _frame_methods():
 
 
 _frame_methods()
+
+
+# ---------------------------------------------------------------------------------------------------------
+#  FSE for 16-bit symbols (lib/fseU16.h): sizes of the uncompressed side are in symbols
+# ---------------------------------------------------------------------------------------------------------
+FSEU16_MAX_SYMBOL_VALUE = 286
+
+
+def fse_u16_compress_bound(n_symbols):      # FSE_compressBound over the bytes of the symbols (what programs/bench.c:221 hands over)
+    return fse_compress_bound(2 * n_symbols)
+
+
+def _u16_methods():
+    def _blocks16(t, what):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int16 or t.dim() != 2:
+            raise TypeError("%s must be a 2-D CUDA int16 tensor (16-bit symbols; torch has no uint16 arithmetic, the bits are what counts)" % what)
+        if t.shape[1] > 1 and t.stride(1) != 1:
+            raise ValueError("%s: symbols of a block must be contiguous" % what)
+        return t
+
+    def fse_count_u16_batch(self, src, sizes=None, max_symbol_value=FSEU16_MAX_SYMBOL_VALUE):
+        n = _blocks16(src, "src").shape[0]
+        counts = torch.empty((n, FSEU16_MAX_SYMBOL_VALUE + 1), dtype=torch.int32, device=src.device)
+        maxsv = torch.empty(n, dtype=torch.int32, device=src.device)
+        results = torch.empty(n, dtype=torch.int64, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
+        _check(self.lib.FSEHIP_FSE_countU16_batch(_ptr(counts), _ptr(maxsv), _ptr(results), _ptr(src), SZ(2 * src.stride(0)), ps, uni,
+                                                  C.c_uint(max_symbol_value), SZ(n), _stream()), "FSE_countU16_batch")
+        return counts, maxsv, results
+
+    def fse_compress_u16_batch(self, src, table_log=0, max_symbol_value=0, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
+        n = _blocks16(src, "src").shape[0]
+        cap = fse_u16_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        if dst is None:
+            dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=src.device)
+        if workspace is None:
+            workspace = torch.empty(int(self.lib.FSEHIP_FSE_compressU16_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
+        _check(self.lib.FSEHIP_FSE_compressU16_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(2 * src.stride(0)), ps, uni,
+                                                     C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()),
+               "FSE_compressU16_batch")
+        return dst, results
+
+    def fse_decompress_u16_batch(self, csrc, csizes, dst_capacity, dst=None, results=None, workspace=None):
+        n = _blocks(csrc, "csrc").shape[0]
+        if dst is None:
+            dst = torch.empty((n, max(dst_capacity, 1)), dtype=torch.int16, device=csrc.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=csrc.device)
+        if workspace is None:
+            workspace = torch.empty(int(self.lib.FSEHIP_FSE_decompressU16_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=csrc.device)
+        ps, uni, keep = _sizes_arg(csizes, csrc)
+        _check(self.lib.FSEHIP_FSE_decompressU16_batch(_ptr(dst), SZ(2 * dst.stride(0)), SZ(dst_capacity), _ptr(results), _ptr(csrc), SZ(csrc.stride(0)), ps, uni,
+                                                       SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()), "FSE_decompressU16_batch")
+        return dst, results
+
+    # host pointers, reference signatures
+    def fse_count_u16(self, src, max_sv=FSEU16_MAX_SYMBOL_VALUE):
+        src = np.ascontiguousarray(src, dtype=np.uint16)
+        count = np.zeros(max(max_sv, FSEU16_MAX_SYMBOL_VALUE) + 1, dtype=np.uint32)
+        msv = C.c_uint(max_sv)
+        r = int(self.lib.FSEHIP_FSE_countU16(count.ctypes.data_as(VP), C.byref(msv), src.ctypes.data_as(VP), SZ(src.size)))
+        return r, count, int(msv.value)
+
+    def fse_compress_u16(self, src, max_sv=0, table_log=0, cap=None):
+        src = np.ascontiguousarray(src, dtype=np.uint16)
+        cap = fse_u16_compress_bound(src.size) if cap is None else cap
+        out = np.zeros(max(cap, 1) + 16, dtype=np.uint8)
+        out[cap:] = 0xA5
+        r = int(self.lib.FSEHIP_FSE_compressU16(out.ctypes.data_as(VP), SZ(cap), src.ctypes.data_as(VP), SZ(src.size), C.c_uint(max_sv), C.c_uint(table_log)))
+        assert (out[cap:] == 0xA5).all(), "FSE_compressU16 wrote past dstCapacity"
+        return r, out[:cap]
+
+    def fse_decompress_u16(self, csrc, cap):
+        csrc = np.ascontiguousarray(csrc, dtype=np.uint8)
+        out = np.zeros(max(cap, 1) + 8, dtype=np.uint16)
+        out[cap:] = 0xA5A5
+        r = int(self.lib.FSEHIP_FSE_decompressU16(out.ctypes.data_as(VP), SZ(cap), csrc.ctypes.data_as(VP), SZ(csrc.size)))
+        assert (out[cap:] == 0xA5A5).all(), "FSE_decompressU16 wrote past dstCapacity"
+        return r, out[:cap]
+
+    for f in (fse_count_u16_batch, fse_compress_u16_batch, fse_decompress_u16_batch, fse_count_u16, fse_compress_u16, fse_decompress_u16):
+        setattr(FseHip, f.__name__, f)
+
+
+_u16_methods()

@@ -711,3 +711,124 @@ extern "C" size_t FSEHIP_HUF_decompress(void* dst, size_t dstSize, const void* c
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstSize ? r : dstSize, hipMemcpyDeviceToHost));
     return r;
 }
+
+// =====================================================================================================
+//  FSE for 16-bit symbols (lib/fseU16.c)
+// =====================================================================================================
+static const size_t U16_CWS_PER_BLOCK = ((size_t)2 << FSEHIP_FSEU16_MAX_TABLELOG) + 8 * (FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1) + sizeof(U16Meta);
+static const size_t U16_DWS_PER_BLOCK = ((size_t)4 << FSEHIP_FSEU16_MAX_TABLELOG) + sizeof(U16Meta);
+extern "C" size_t FSEHIP_FSE_compressU16_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    return (c ? c : 1) * U16_CWS_PER_BLOCK + WS_SLACK;
+}
+extern "C" size_t FSEHIP_FSE_decompressU16_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    return (c ? c : 1) * U16_DWS_PER_BLOCK + WS_SLACK;
+}
+
+extern "C" int FSEHIP_FSE_countU16_batch(unsigned* d_counts, unsigned* d_maxSymbolValues, size_t* d_results, const unsigned short* d_src, size_t srcStrideBytes,
+                                         const size_t* d_srcSizes, size_t uniformSrcSize, unsigned maxSymbolValue, size_t nBlocks, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    U16CArgs a;
+    a.src = d_src; a.srcStrideBytes = srcStrideBytes; a.srcSizes = d_srcSizes; a.uniformSrcSize = uniformSrcSize;
+    a.dst = nullptr; a.dstStride = 0; a.dstCapacity = 0; a.maxSVReq = maxSymbolValue; a.tableLogReq = 0;
+    a.stateTables = nullptr; a.symTT = nullptr; a.meta = nullptr; a.countsOut = d_counts; a.maxSVOut = d_maxSymbolValues;
+    a.results = d_results; a.nBlocks = nBlocks;
+    return (int)launch_u16_compress(a, (hipStream_t)stream);
+}
+
+extern "C" int FSEHIP_FSE_compressU16_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results, const unsigned short* d_src, size_t srcStrideBytes,
+                                            const size_t* d_srcSizes, size_t uniformSrcSize, unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                            void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) return 0;
+    if (workspaceBytes < U16_CWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / U16_CWS_PER_BLOCK;
+    if (chunk >= nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    u16* stateTables = (u16*)p; p += align_up(chunk * ((size_t)2 << FSEHIP_FSEU16_MAX_TABLELOG), 256);
+    u32* symTT = (u32*)p; p += align_up(chunk * 8 * (FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1), 256);
+    U16Meta* meta = (U16Meta*)p;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        U16CArgs a;
+        a.src = (const u16*)((const u8*)d_src + b0 * srcStrideBytes); a.srcStrideBytes = srcStrideBytes;
+        a.srcSizes = d_srcSizes ? d_srcSizes + b0 : nullptr; a.uniformSrcSize = uniformSrcSize;
+        a.dst = (u8*)d_dst + b0 * dstStride; a.dstStride = dstStride; a.dstCapacity = dstCapacity;
+        a.maxSVReq = maxSymbolValue; a.tableLogReq = tableLog;
+        a.stateTables = stateTables; a.symTT = symTT; a.meta = meta; a.countsOut = nullptr; a.maxSVOut = nullptr;
+        a.results = d_results + b0; a.nBlocks = nb;
+        CK(launch_u16_compress(a, s));
+    }
+    return 0;
+}
+
+extern "C" int FSEHIP_FSE_decompressU16_batch(unsigned short* d_dst, size_t dstStrideBytes, size_t dstCapacity, size_t* d_results, const void* d_cSrc, size_t cStride,
+                                              const size_t* d_cSizes, size_t uniformCSize, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) return 0;
+    if (workspaceBytes < U16_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / U16_DWS_PER_BLOCK;
+    if (chunk >= nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    u32* cells = (u32*)p; p += align_up(chunk * ((size_t)4 << FSEHIP_FSEU16_MAX_TABLELOG), 256);
+    U16Meta* meta = (U16Meta*)p;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        U16DArgs a;
+        a.dst = (u16*)((u8*)d_dst + b0 * dstStrideBytes); a.dstStrideBytes = dstStrideBytes; a.dstCapacity = dstCapacity;
+        a.csrc = (const u8*)d_cSrc + b0 * cStride; a.cStride = cStride; a.cSizes = d_cSizes ? d_cSizes + b0 : nullptr; a.uniformCSize = uniformCSize;
+        a.cells = cells; a.meta = meta; a.results = d_results + b0; a.nBlocks = nb;
+        CK(launch_u16_decompress(a, s));
+    }
+    return 0;
+}
+
+extern "C" size_t FSEHIP_FSE_countU16(unsigned* count, unsigned* maxSymbolValuePtr, const unsigned short* src, size_t srcSize)
+{
+    const unsigned in = *maxSymbolValuePtr;
+    if (in > FSEHIP_FSEU16_MAX_SYMBOL_VALUE) return FSEHIP_ERROR(maxSymbolValue_tooLarge);
+    DevBuf dsrc, dcnt, dmsv, dres;
+    HK(dsrc.alloc(srcSize * 2)); HK(dcnt.alloc(4 * (FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1))); HK(dmsv.alloc(4)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize * 2, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_countU16_batch((unsigned*)dcnt.p, (unsigned*)dmsv.p, (size_t*)dres.p, (const unsigned short*)dsrc.p, srcSize * 2, nullptr, srcSize, in, 1, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (FSEHIP_isError(r)) return r;
+    HK(hipMemcpy(count, dcnt.p, 4 * ((size_t)in + 1), hipMemcpyDeviceToHost));
+    HK(hipMemcpy(maxSymbolValuePtr, dmsv.p, 4, hipMemcpyDeviceToHost));
+    return r;
+}
+
+extern "C" size_t FSEHIP_FSE_compressU16(void* dst, size_t dstCapacity, const unsigned short* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)
+{
+    const size_t wsBytes = FSEHIP_FSE_compressU16_batch_workspaceSize(1);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(srcSize * 2)); HK(ddst.alloc(dstCapacity)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, src, srcSize * 2, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_compressU16_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, (const unsigned short*)dsrc.p, srcSize * 2, nullptr, srcSize,
+                                                maxSymbolValue, tableLog, 1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 1) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
+    return r;
+}
+
+extern "C" size_t FSEHIP_FSE_decompressU16(unsigned short* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize)
+{
+    const size_t wsBytes = FSEHIP_FSE_decompressU16_batch_workspaceSize(1);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstCapacity * 2)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_decompressU16_batch((unsigned short*)ddst.p, dstCapacity * 2, dstCapacity, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
+                                                  1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (dstCapacity) HK(hipMemcpy(dst, ddst.p, dstCapacity * 2, hipMemcpyDeviceToHost));   // (the reference writes what it decoded before it notices corruption)
+    return r;
+}

@@ -1,0 +1,334 @@
+// fse_u16.hip -- SURVEY 8(f) rank 4: the 16-bit-symbol variant of FSE (lib/fseU16.c: FSE_countU16 :121-146, FSE_compressU16 :203-256
+// with FSE_compressU16_usingCTable :150-200, FSE_decompressU16 :306-329 with FSE_decompressU16_usingDTable :273-301).
+//
+// Same table construction as the byte coder (lib/fse_compress.c:66-169, lib/fse_decompress.c:71-126 compiled with
+// FSE_FUNCTION_TYPE U16) over a wider alphabet -- up to FSEU16_MAX_SYMBOL_VALUE = 286 symbols, table logs up to 13, default 12
+// (fseU16.c:43-48) -- but a different stream: ONE tANS state (fseU16.c:159-199), decoded until the bit stream is used up and the
+// state is back at 0 (:288-298).  Not a throughput configuration of the reference (no BASELINE entry), so the split is:
+//   * everything around the chain is wave-parallel, one wave per block: histogram (LDS atomics), table log, normalisation and
+//     NCount header with the per-symbol-lane code of wave_glue.h (five symbols per lane), and a table builder restated for any
+//     alphabet: the spread as "the k-th kept visit of the walk m -> m*step gets the symbol whose cumulative range holds k" (every
+//     lane takes a run of visits and walks the cumulative counts alongside), the ranks -- the order of a symbol's cells -- by
+//     walking the cells 64 at a time: lanes holding the same symbol find each other with nine ballots (one per symbol bit);
+//   * the chain itself is the reference's loop, one lane per block (tables in global memory: 16-32 KB per block would leave
+//     five blocks per CU in LDS for a single chain each), with the reference's flush cadence and clamping, so that return values
+//     agree with it in every case that is defined there.
+// Where the reference's behaviour is undefined the device path refuses instead: FSE_compressU16 with 8 bytes or less behind the
+// header (BIT_initCStream's error is ignored at fseU16.c:164 and the flushes then write in front of the buffer) stores no payload
+// and returns what the reference would (the header size alone); FSE_decompressU16 with nothing behind the header (the reference
+// dereferences a null stream pointer) returns srcSize_wrong.
+#include "internal.h"
+#include "wave_glue.h"
+#include "ncount_reader.h"
+#include "bitreader.h"
+
+#define U16_MAXSV   FSEHIP_FSEU16_MAX_SYMBOL_VALUE      // 286
+#define U16_MAXTL   FSEHIP_FSEU16_MAX_TABLELOG          // 13
+#define U16_DEFTL   FSEHIP_FSEU16_DEFAULT_TABLELOG      // 12
+#define U16_SPL     5                                    // symbols per lane: 64 x 5 = 320 >= 287
+#define U16_SYMS    (64 * U16_SPL)
+
+// ---- LDS of the builders (one wave per block) ------------------------------------------------------------------------------
+struct U16Lds {
+    u32 cnt[U16_SYMS];          // histogram / scratch
+    s16 nrm[U16_SYMS];          // normalised counters
+    u16 cum[U16_SYMS + 1];      // cells in front of every symbol (|counter|, symbol order)
+    u16 pcum[U16_SYMS + 1];     // kept visits in front of every symbol (positive counters only)
+    u16 seen[U16_SYMS];         // cells of the symbol met so far (rank pass)
+    u32 img[160];               // NCount header image
+    u32 scal[8];
+    u16 symTab[1u << U16_MAXTL];   // symbol of every cell
+};
+
+DEV u32 u16_scan_excl(u32 v, u32 lane, u32* total)
+{
+    u32 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    *total = (u32)__shfl((int)incl, 63, WAVE);
+    return incl - v;
+}
+
+// Spread + rank for the counters in L.nrm (zero beyond maxSV).  Fills L.symTab and L.cum, then calls emit(u, symbol, rank) once per
+// cell, ranks ascending with u inside a symbol.  All 64 lanes, uniform arguments, the workgroup is this wave.
+template <class Emit>
+DEV void u16_spread_rank(U16Lds& L, u32 maxSV, u32 tl, u32 lane, Emit&& emit)
+{
+    const u32 ts = 1u << tl, mask = ts - 1u, step = (ts >> 1) + (ts >> 3) + 3u;
+    // ---- cumulative counts (lane l: symbols 5l .. 5l+4)
+    int n[U16_SPL]; u32 mineAbs = 0, minePos = 0, mineLow = 0;
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) {
+        const u32 s = U16_SPL * lane + i;
+        n[i] = s <= maxSV ? (int)L.nrm[s] : 0;
+        mineAbs += (u32)(n[i] < 0 ? 1 : n[i]); minePos += (u32)(n[i] > 0 ? n[i] : 0); mineLow += n[i] == -1;
+    }
+    u32 tAbs, tPos, nLow;
+    u32 a = u16_scan_excl(mineAbs, lane, &tAbs), p = u16_scan_excl(minePos, lane, &tPos), lw = u16_scan_excl(mineLow, lane, &nLow);
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) {
+        const u32 s = U16_SPL * lane + i;
+        L.cum[s] = (u16)a; L.pcum[s] = (u16)p; L.seen[s] = 0;
+        if (n[i] == -1) { L.symTab[ts - 1u - lw] = (u16)s; ++lw; }         // low-probability symbols take the top cells, in symbol order downwards
+        a += (u32)(n[i] < 0 ? 1 : n[i]); p += (u32)(n[i] > 0 ? n[i] : 0);
+    }
+    if (lane == 63) { L.cum[U16_SYMS] = (u16)a; L.pcum[U16_SYMS] = (u16)p; }
+    __syncthreads();
+    const u32 high = ts - 1u - nLow;                                         // highThreshold (ts - 1 - nLow >= 0: a table of only such symbols has nLow == ts)
+    // ---- spread: my run of visits m, the kept ones numbered by a wave scan
+    const u32 C = ts >= 64u ? ts >> 6 : 1u;
+    const bool act = lane * C < ts;
+    u32 kept = 0;
+    if (act && nLow < ts) for (u32 i = 0; i < C; ++i) kept += (((lane * C + i) * step) & mask) <= high;
+    u32 tk;
+    u32 k = u16_scan_excl(kept, lane, &tk);
+    if (act && kept) {
+        // symbol of visit k: the last s with pcum[s] <= k among the symbols with a positive counter (binary search, then walk along)
+        u32 lo = 0, hi = U16_SYMS;                                           // invariant: pcum[lo] <= k < pcum[hi]
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u32)L.pcum[mid] <= k) lo = mid; else hi = mid; }
+        u32 s = lo, next = L.pcum[s + 1];
+        for (u32 i = 0; i < C; ++i) {
+            const u32 u = ((lane * C + i) * step) & mask;
+            if (u > high) continue;
+            while (k >= next) { ++s; next = L.pcum[s + 1]; }
+            L.symTab[u] = (u16)s;
+            ++k;
+        }
+    }
+    __syncthreads();
+    // ---- ranks: the cells in ascending order, 64 at a time
+    for (u32 u0 = 0; u0 < ts; u0 += 64) {
+        const u32 u = u0 + lane;
+        const bool in = u < ts;
+        const u32 s = in ? (u32)L.symTab[u] : 0xFFFFu;
+        unsigned long long same = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {                                        // lanes with my symbol: agree on every bit of it
+            const unsigned long long bal = __ballot((s >> b) & 1u);
+            same &= ((s >> b) & 1u) ? bal : ~bal;
+        }
+        if (in) {
+            const u32 before = (u32)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            const u32 base = L.seen[s];
+            emit(u, s, base + before);
+            if ((same >> lane) == 1ull) L.seen[s] = (u16)(base + (u32)__builtin_popcountll(same));   // the group's top lane
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+    }
+}
+
+// ---- compress side: FSE_compressU16 up to the table (fseU16.c:203-249) -------------------------------------------------------
+__global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
+{
+    __shared__ U16Lds L;
+    const u32 lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
+    const size_t n = a.srcSizes ? a.srcSizes[b] : a.uniformSrcSize;
+    const bool countOnly = a.countsOut != nullptr;
+    U16Meta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+    size_t result = 0; bool done = false;
+    u32 maxSV = a.maxSVReq, tlReq = a.tableLogReq;
+    if (!countOnly) {                                                        // fseU16.c:217-222
+        if (n <= 1) { result = n; done = true; }
+        else {
+            if (!maxSV) maxSV = U16_MAXSV;
+            if (!tlReq) tlReq = U16_DEFTL;
+            if (maxSV > U16_MAXSV) { result = FERR(maxSymbolValue_tooLarge); done = true; }
+            else if (tlReq > U16_MAXTL) { result = FERR(tableLog_tooLarge); done = true; }
+        }
+    } else if (maxSV > U16_MAXSV) { result = FERR(maxSymbolValue_tooLarge); done = true; }   // (our count array holds 287 entries)
+    if (done) { if (lane == 0) { a.results[b] = result; if (a.meta) a.meta[b] = m; } return; }   // uniform
+
+    // ---- FSE_countU16 (:121-146)
+    for (u32 s = lane; s < U16_SYMS; s += 64) { L.cnt[s] = 0; L.nrm[s] = 0; }
+    if (lane < 8) L.scal[lane] = 0;
+    __syncthreads();
+    bool over = false;
+    for (size_t i = lane; i < n; i += 64) { const u32 s = src[i]; if (s > maxSV) over = true; else atomicAdd(&L.cnt[s], 1u); }
+    __syncthreads();
+    if (__any(over)) { if (lane == 0) { a.results[b] = FERR(maxSymbolValue_tooSmall); if (a.meta) a.meta[b] = m; } return; }
+    u32 c[U16_SPL], top = 0, big = 0;
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) { const u32 s = U16_SPL * lane + i; c[i] = L.cnt[s]; if (c[i]) top = s; big = c[i] > big ? c[i] : big; }
+    top = wg_max<64>(top); big = wg_max<64>(big);
+    if (n == 0) top = 0;
+    if (countOnly) {
+        for (u32 s = lane; s <= a.maxSVReq; s += 64) a.countsOut[b * (U16_MAXSV + 1) + s] = L.cnt[s];
+        if (lane == 0) { a.maxSVOut[b] = top; a.results[b] = big; }
+        return;
+    }
+    maxSV = top;
+    if (big == n) { if (lane == 0) { a.results[b] = 1; a.meta[b] = m; } return; }    // one symbol only: the caller should use RLE (:228)
+
+    // ---- table log, normalisation, header (:231-240)
+    // FSE_optimalTableLog, FSE_normalizeCount and FSE_writeNCount are NOT re-instantiated for 16-bit symbols (fseU16.c:88 includes the
+    // templates only): the calls at :231-240 reach the byte coder's objects, whose table-log limit is 12 -- a request of 13 passes
+    // the check at :222 and is then clamped to 12.  (The decoder side does accept 13: FSE_buildDTableU16 is a template instance.)
+    const u32 tl = wg_optimal_tablelog(tlReq, n, maxSV, 2, U16_DEFTL, FSE_MAX_TL);
+    int nn[U16_SPL];
+    size_t e = wg_normalize<64, U16_SPL, FSE_MAX_TL>(nn, c, (u64)n, maxSV, tl, lane);
+    if (is_err(e)) { if (lane == 0) { a.results[b] = e; a.meta[b] = m; } return; }
+    for (u32 i = lane; i < 160; i += 64) L.img[i] = 0;
+    __syncthreads();
+    const size_t hdr = wg_write_ncount<64, U16_SPL>(L.img, a.dstCapacity, nn, maxSV, tl, lane);
+    if (is_err(hdr)) { if (lane == 0) { a.results[b] = hdr; a.meta[b] = m; } return; }
+    __syncthreads();
+    u8* const dst = a.dst + b * a.dstStride;
+    for (u32 i = lane; i < (u32)hdr; i += 64) dst[i] = ((const u8*)L.img)[i];
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) L.nrm[U16_SPL * lane + i] = (s16)nn[i];
+    __syncthreads();
+
+    // ---- FSE_buildCTable (lib/fse_compress.c:66-169 as instantiated at fseU16.c:103-111)
+    u16* const st = a.stateTables + (b << U16_MAXTL);
+    u32* const tt = a.symTT + b * 2 * (U16_MAXSV + 1);
+    const u32 ts = 1u << tl;
+    u16_spread_rank(L, maxSV, tl, lane, [&](u32 u, u32 s, u32 r) { st[(u32)L.cum[s] + r] = (u16)(ts + u); });
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) {                                     // the symbols' transforms (:131-154)
+        const u32 s = U16_SPL * lane + i;
+        if (s > maxSV) continue;
+        const int v = nn[i];
+        const u32 total = L.cum[s];
+        u32 dnb, dfs = 0;
+        if (v == 0) dnb = ((tl + 1u) << 16) - ts;
+        else if (v == -1 || v == 1) { dnb = (tl << 16) - ts; dfs = total - 1u; }
+        else { const u32 mbo = tl - hibit32((u32)(v - 1)); dnb = (mbo << 16) - ((u32)v << mbo); dfs = total - (u32)v; }
+        tt[2 * s] = dfs; tt[2 * s + 1] = dnb;
+    }
+    m.state = 1; m.hdrSize = (u32)hdr; m.tableLog = tl; m.maxSV = maxSV;
+    if (lane == 0) a.meta[b] = m;
+}
+
+// FSE_compressU16_usingCTable (:150-200) + the verdicts of FSE_compressU16 (:245-255): one lane per block
+__global__ void k_u16_encode(U16CArgs a)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.nBlocks) return;
+    const U16Meta m = a.meta[b];
+    if (m.state == 0) return;
+    const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
+    const size_t n = a.srcSizes ? a.srcSizes[b] : a.uniformSrcSize;
+    const u16* const st = a.stateTables + (b << U16_MAXTL);
+    const uint2* const tt = (const uint2*)(a.symTT + b * 2 * (U16_MAXSV + 1));
+    u8* const dst = a.dst + b * a.dstStride + m.hdrSize;
+    const size_t cap = a.dstCapacity - m.hdrSize;
+    const u32 tl = m.tableLog;
+    size_t cs = 0;
+    if (cap > 8) {
+        const size_t lim = cap - 8;                                          // endPtr (bitstream.h:190)
+        u64 acc = 0; u32 nacc = 0; size_t pos = 0;
+        u32 x = 1u << tl;                                                    // FSE_initCState
+        auto enc = [&](u32 sym) {                                            // FSE_encodeSymbol (fse.h:514-521)
+            const uint2 e = tt[sym];
+            const u32 nb = (x + e.y) >> 16;
+            acc |= (u64)(x & ((1u << nb) - 1u)) << nacc; nacc += nb;
+            x = st[(x >> nb) + e.x];
+        };
+        auto flush = [&]() {                                                 // BIT_flushBits (bitstream.h:239-249)
+            __builtin_memcpy(dst + pos, &acc, 8);
+            const u32 nby = nacc >> 3;
+            pos += nby; pos = pos > lim ? lim : pos;
+            acc = nby >= 8 ? 0 : acc >> (8 * nby); nacc &= 7u;
+        };
+        size_t ip = n;
+        if (n & 1) { enc(src[--ip]); flush(); }
+        if (n & 2) { enc(src[ip - 1]); enc(src[ip - 2]); ip -= 2; flush(); }
+        while (ip > 0) {                                                     // four symbols (<= 52 bits) per flush
+            u64 w; __builtin_memcpy(&w, src + ip - 4, 8);
+            enc((u32)(w >> 48)); enc((u32)(w >> 32) & 0xFFFFu); enc((u32)(w >> 16) & 0xFFFFu); enc((u32)w & 0xFFFFu);
+            ip -= 4; flush();
+        }
+        acc |= (u64)(x & ((1u << tl) - 1u)) << nacc; nacc += tl; flush();    // FSE_flushCState
+        acc |= (u64)1 << nacc; nacc += 1; flush();                           // BIT_closeCStream
+        cs = pos >= lim ? 0 : pos + (nacc > 0);
+    }
+    const size_t total = (size_t)m.hdrSize + cs;
+    a.results[b] = total >= (n - 1) * 2 ? 0 : total;                         // "no compression" (:252-253)
+}
+
+// ---- decompress side ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
+{
+    __shared__ U16Lds L;
+    const u32 lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const u8* const in = a.csrc + b * a.cStride;
+    const size_t cSize = a.cSizes ? a.cSizes[b] : a.uniformCSize;
+    U16Meta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+    for (u32 s = lane; s < U16_SYMS; s += 64) L.nrm[s] = 0;
+    __syncthreads();
+    if (lane == 0) {                                                         // fseU16.c:316-325
+        size_t r = 0; u32 maxSV = U16_MAXSV, tl = 0;
+        if (cSize < 2) r = FERR(srcSize_wrong);
+        else {
+            r = ncount_read<1>(L.nrm, &maxSV, &tl, in, cSize);
+            if (!is_err(r) && tl > U16_MAXTL) r = FERR(tableLog_tooLarge);   // FSE_buildDTable's check (fse_decompress.c:83)
+            if (!is_err(r) && r >= cSize) r = FERR(srcSize_wrong);           // nothing behind the header (undefined in the reference)
+        }
+        L.scal[0] = (u32)r; L.scal[1] = (u32)(r >> 32); L.scal[2] = maxSV; L.scal[3] = tl;
+    }
+    __syncthreads();
+    const size_t r = ((size_t)L.scal[1] << 32) | L.scal[0];
+    if (is_err(r)) { if (lane == 0) { a.results[b] = r; a.meta[b] = m; } return; }
+    const u32 maxSV = L.scal[2], tl = L.scal[3], ts = 1u << tl;
+    u32* const cells = a.cells + (b << U16_MAXTL);
+    u16_spread_rank(L, maxSV, tl, lane, [&](u32 u, u32 s, u32 rk) {       // FSE_buildDTable (fse_decompress.c:116-123)
+        const int v = L.nrm[s];
+        const u32 next = (v == -1 ? 1u : (u32)v) + rk;
+        const u32 nb = tl - hibit32(next);
+        cells[u] = (((next << nb) - ts) & 0xFFFFu) | (nb << 16) | (s << 20);
+    });
+    m.state = 1; m.hdrSize = (u32)r; m.tableLog = tl; m.maxSV = maxSV;
+    if (lane == 0) a.meta[b] = m;
+}
+
+// FSE_decompressU16_usingDTable (:273-301): one lane per block, the reference's loop with its bit reader
+__global__ void k_u16_decode(U16DArgs a)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.nBlocks) return;
+    const U16Meta m = a.meta[b];
+    if (m.state == 0) return;
+    const u8* const in = a.csrc + b * a.cStride + m.hdrSize;
+    const size_t size = (a.cSizes ? a.cSizes[b] : a.uniformCSize) - m.hdrSize;
+    const u32* const cells = a.cells + (b << U16_MAXTL);
+    u16* const out = (u16*)((u8*)a.dst + b * a.dstStrideBytes);
+    const size_t cap = a.dstCapacity;
+    BitReader r;
+    (void)r.init(in, size);                                                  // (the verdict of BIT_initDStream is not looked at, :284)
+    u32 state = r.read(m.tableLog); (void)r.reload();                        // FSE_initDState
+    size_t op = 0;
+    auto step = [&]() {                                                      // FSE_decodeSymbolU16 (:262-271)
+        const u32 c = cells[state];
+        const u32 low = r.read((c >> 16) & 15u);
+        state = (c & 0xFFFFu) + low;
+        return (u16)(c >> 20);
+    };
+    while (r.reload() < BR_COMPLETED && op < cap) out[op++] = step();
+    size_t result;
+    if (!(r.at == 0 && r.used == 64)) result = FERR(corruption_detected);   // BIT_endOfDStream
+    else {
+        while (state && op < cap) out[op++] = step();
+        result = state ? FERR(corruption_detected) : op;
+    }
+    a.results[b] = result;
+}
+
+// ---- launchers --------------------------------------------------------------------------------------------------------------------
+hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_u16_cprep, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    if (!a.countsOut) hipLaunchKernelGGL(k_u16_encode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_u16_dprep, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_u16_decode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}

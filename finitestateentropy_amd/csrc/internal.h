@@ -188,6 +188,25 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
 hipError_t launch_huf_decode_classes(HufDecArgs a, u32* lists, u32* counts, hipStream_t s);
 hipError_t launch_huf_decode_par(HufDecArgs a, unsigned dataBytes, u32* serialList, u32* serialCount, hipStream_t s);
 
+// ---- FSE for 16-bit symbols (fse_u16.hip) --------------------------------------------------------------------
+struct U16Meta { u32 state, hdrSize, tableLog, maxSV; };      // state 0: result final; 1: run the chain
+struct U16CArgs {
+    const u16* src; size_t srcStrideBytes; const size_t* srcSizes; size_t uniformSrcSize;     // sizes in symbols
+    u8* dst; size_t dstStride; size_t dstCapacity;
+    u32 maxSVReq, tableLogReq;
+    u16* stateTables; u32* symTT; U16Meta* meta;       // per block: 1 << 13 u16, 2 * 287 u32
+    unsigned* countsOut; unsigned* maxSVOut;           // FSE_countU16 only (then nothing else is done)
+    size_t* results; size_t nBlocks;
+};
+struct U16DArgs {
+    u16* dst; size_t dstStrideBytes; size_t dstCapacity;                     // capacity in symbols
+    const u8* csrc; size_t cStride; const size_t* cSizes; size_t uniformCSize;
+    u32* cells; U16Meta* meta;                                               // per block: 1 << 13 cells = newState | nbBits << 16 | symbol << 20
+    size_t* results; size_t nBlocks;
+};
+hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s);
+hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s);
+
 // ---- workload generator -----------------------------------------------------------------------------
 hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, u32 seedStep, hipStream_t s);
 

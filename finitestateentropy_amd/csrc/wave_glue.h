@@ -88,23 +88,23 @@ DEV u32 wg_min_tablelog(size_t srcSize, u32 maxSV)
     const u32 bySize = hibit32((u32)srcSize) + 1, byAlphabet = hibit32(maxSV) + 2;
     return bySize < byAlphabet ? bySize : byAlphabet;
 }
-DEV u32 wg_optimal_tablelog(u32 request, size_t srcSize, u32 maxSV, u32 minus)
+DEV u32 wg_optimal_tablelog(u32 request, size_t srcSize, u32 maxSV, u32 minus, u32 defTl = FSE_DEF_TL, u32 maxTl = FSE_MAX_TL)
 {
-    u32 tl = request ? request : FSE_DEF_TL;
+    u32 tl = request ? request : defTl;
     const u32 bySrc = hibit32((u32)(srcSize - 1)) - minus;
     tl = bySrc < tl ? bySrc : tl;
     const u32 need = wg_min_tablelog(srcSize, maxSV);
     tl = need > tl ? need : tl;
     tl = tl < FSE_MIN_TL ? FSE_MIN_TL : tl;
-    return tl > FSE_MAX_TL ? FSE_MAX_TL : tl;
+    return tl > maxTl ? maxTl : tl;
 }
 
 // ---- normalisation ---------------------------------------------------------------------------------------------------
-// c[i] = count of symbol 4*lane + i (zero beyond maxSV), total = their sum (>= 2, no symbol owns it all).  Leaves the
+// c[i] = count of symbol SPL*lane + i (SPL symbols per lane, 4 unless the alphabet is wider than 4*W; zero beyond maxSV), total = their sum (>= 2, no symbol owns it all).  Leaves the
 // normalised counters in n[i] (-1 = "less than one point") and returns 0, or an error code.
 #define WG_PENDING (-2)
-template <int W>
-DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, u32 lane)
+template <int W, int SPL = 4>
+DEV size_t wg_normalize_fallback(int n[SPL], const u32 c[SPL], u64 total, u32 maxSV, u32 tl, u32 lane)
 {
     const u32 sub = wg_sub<W>(lane);
     const u32 ts = 1u << tl;
@@ -113,8 +113,8 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
     // every symbol on its own: absent / below one point / about one point / still pending
     u32 given = 0; u64 taken = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool in = 4 * sub + i <= maxSV;
+    for (int i = 0; i < SPL; ++i) {
+        const bool in = SPL * sub + i <= maxSV;
         if (!in || c[i] == 0) n[i] = 0;
         else if (c[i] <= tiny) { n[i] = -1; ++given; taken += c[i]; }
         else if (c[i] <= one) { n[i] = 1; ++given; taken += c[i]; }
@@ -127,32 +127,32 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
         one = (u32)((total * 3) / ((u64)left * 2));
         u32 g2 = 0; u64 t2 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (n[i] == WG_PENDING && c[i] <= one) { n[i] = 1; ++g2; t2 += c[i]; }
+        for (int i = 0; i < SPL; ++i) if (n[i] == WG_PENDING && c[i] <= one) { n[i] = 1; ++g2; t2 += c[i]; }
         given += wg_sum<W>(g2); total -= wg_sum64<W>(t2);
         left = ts - given;
     }
     if (given == maxSV + 1) {                                  // nothing pending: the first most frequent symbol takes the rest
         u32 best = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) best = c[i] > best ? c[i] : best;
+        for (int i = 0; i < SPL; ++i) best = c[i] > best ? c[i] : best;
         best = wg_max<W>(best);
         u32 who = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 3; i >= 0; --i) if (c[i] == best && 4 * sub + i <= maxSV) who = 4 * sub + i;
+        for (int i = SPL - 1; i >= 0; --i) if (c[i] == best && SPL * sub + i <= maxSV) who = SPL * sub + i;
         who = wg_min<W>(who);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (4 * sub + i == who) n[i] += (int)left;
+        for (int i = 0; i < SPL; ++i) if (SPL * sub + i == who) n[i] += (int)left;
         return 0;
     }
     if (total == 0) {                                          // the rest goes round robin over the one-point symbols:
         u32 mine = 0;                                          // quotient each, one more for the first (rest) of them
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mine += n[i] > 0;
+        for (int i = 0; i < SPL; ++i) mine += n[i] > 0;
         const u32 P = wg_sum<W>(mine);
         u32 rank = wg_scan_excl<W>(mine, lane);
         const u32 q = left / P, r = left % P;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (n[i] > 0) { n[i] += (int)(q + (rank < r)); ++rank; }
+        for (int i = 0; i < SPL; ++i) if (n[i] > 0) { n[i] += (int)(q + (rank < r)); ++rank; }
         return 0;
     }
     // the pending symbols share `left` points in proportion to their counts: cumulative positions on a 2^(62-tl) grid
@@ -161,11 +161,11 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
     const u64 rstep = ((((u64)1 << vlog) * left) + mid) / total;
     u64 span = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (n[i] == WG_PENDING) span += (u64)c[i] * rstep;
+    for (int i = 0; i < SPL; ++i) if (n[i] == WG_PENDING) span += (u64)c[i] * rstep;
     u64 run = mid + wg_scan_excl64<W>(span, lane);
     bool starved = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SPL; ++i) {
         if (n[i] != WG_PENDING) continue;
         const u64 end = run + (u64)c[i] * rstep;
         const u32 w = (u32)(end >> vlog) - (u32)(run >> vlog);
@@ -176,12 +176,12 @@ DEV size_t wg_normalize_fallback(int n[4], const u32 c[4], u64 total, u32 maxSV,
     return wg_any<W>(starved, lane) ? FERR(GENERIC) : 0;
 }
 
-template <int W>
-DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, u32 lane)
+template <int W, int SPL = 4, int MAXTL = FSE_MAX_TL>
+DEV size_t wg_normalize(int n[SPL], const u32 c[SPL], u64 total, u32 maxSV, u32 tl, u32 lane)
 {
     const u32 sub = wg_sub<W>(lane);
     if (tl < FSE_MIN_TL) return FERR(GENERIC);
-    if (tl > FSE_MAX_TL) return FERR(tableLog_tooLarge);
+    if (tl > (u32)MAXTL) return FERR(tableLog_tooLarge);
     if (tl < wg_min_tablelog((size_t)total, maxSV)) return FERR(GENERIC);
     const u32 scale = 62 - tl;
     const u64 step = ((u64)1 << 62) / total;
@@ -189,10 +189,10 @@ DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, 
     const u32 tiny = (u32)(total >> tl);
     // rounding thresholds of the small probabilities (lib/fse_compress.c:445), in units of vstep
     const u32 beat[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
-    u32 used = 0, key = 0;                                     // key = probability << 8 | 255 - symbol: the arg-max prefers the lower symbol
+    u32 used = 0, key = 0;                                     // key = probability << 12 | 4095 - symbol: the arg-max prefers the lower symbol
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 s = 4 * sub + i;
+    for (int i = 0; i < SPL; ++i) {
+        const u32 s = SPL * sub + i;
         if (s > maxSV || c[i] == 0) { n[i] = 0; continue; }
         if (c[i] <= tiny) { n[i] = -1; ++used; continue; }
         const u64 prod = (u64)c[i] * step;
@@ -200,19 +200,19 @@ DEV size_t wg_normalize(int n[4], const u32 c[4], u64 total, u32 maxSV, u32 tl, 
         if (p < 8) p += (prod - ((u64)p << scale)) > vstep * beat[p];
         n[i] = (int)(s16)p;
         used += p;
-        const u32 k = (p << 8) | (255u - s);
+        const u32 k = (p << 12) | (4095u - s);
         key = k > key ? k : key;
     }
     const int still = (int)(1u << tl) - (int)wg_sum<W>(used);
     key = wg_max<W>(key);
-    const u32 largest = (key >> 8) ? 255u - (key & 255u) : 0u;
+    const u32 largest = (key >> 12) ? 4095u - (key & 4095u) : 0u;
     int nl = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (4 * sub + i == largest) nl = n[i];
-    nl = __shfl(nl, (int)((lane - sub) + (largest >> 2)), WAVE);
-    if (-still >= (nl >> 1)) return wg_normalize_fallback<W>(n, c, total, maxSV, tl, lane);
+    for (int i = 0; i < SPL; ++i) if (SPL * sub + i == largest) nl = n[i];
+    nl = __shfl(nl, (int)((lane - sub) + largest / (u32)SPL), WAVE);
+    if (-still >= (nl >> 1)) return wg_normalize_fallback<W, SPL>(n, c, total, maxSV, tl, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (4 * sub + i == largest) n[i] += still;
+    for (int i = 0; i < SPL; ++i) if (SPL * sub + i == largest) n[i] += still;
     return 0;
 }
 
@@ -229,28 +229,28 @@ DEV void wg_or_bits(u32* img, u32 pos, u32 v, u32 nb)
 // LDS words (>= 132).  Returns the header size in bytes (the image then holds the header) or an error code: dstSize_tooSmall by the
 // reference's rule -- only checked when the destination is below the worst-case header size, at every 16-bit flush
 // (lib/fse_compress.c:186-190, :228-272), i.e. against the position of the last flush.
-template <int W>
-DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 tl, u32 lane)
+template <int W, int SPL = 4>
+DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[SPL], u32 maxSV, u32 tl, u32 lane)
 {
     const u32 sub = wg_sub<W>(lane);
     const u32 ts = 1u << tl;
     u32 a = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a += (u32)(n[i] < 0 ? -n[i] : n[i]);
+    for (int i = 0; i < SPL; ++i) a += (u32)(n[i] < 0 ? -n[i] : n[i]);
     u32 before = wg_scan_excl<W>(a, lane);                         // points assigned in front of my first symbol
     // position of the first non-zero counter above each of my symbols
     u32 nzLane = 0xFFFFFFFFu;
 #pragma unroll
-    for (int i = 3; i >= 0; --i) if (n[i] != 0 && 4 * sub + i <= maxSV) nzLane = 4 * sub + i;
+    for (int i = SPL - 1; i >= 0; --i) if (n[i] != 0 && SPL * sub + i <= maxSV) nzLane = SPL * sub + i;
     const u32 nzAbove = wg_suffix_min_excl<W>(nzLane, lane);
-    int prevN = __shfl_up(n[3], 1, WAVE);                      // counter of the symbol in front of my first one
+    int prevN = __shfl_up(n[SPL - 1], 1, WAVE);                      // counter of the symbol in front of my first one
     if (sub == 0) prevN = 1;
     // chunks of my symbols: value + zero-run code; sizes first
-    u32 val[4], vnb[4], run[4], bits = 0;
+    u32 val[SPL], vnb[SPL], run[SPL], bits = 0;
     bool broken = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 s = 4 * sub + i;
+    for (int i = 0; i < SPL; ++i) {
+        const u32 s = SPL * sub + i;
         const int remaining = (int)(ts + 1) - (int)before;
         const int pn = i ? n[i - 1] : prevN;
         const bool coded = s <= maxSV && remaining > 1 && !(n[i] == 0 && pn == 0);
@@ -265,7 +265,7 @@ DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 
             if (n[i] == 0) {                                   // first zero of a run: the rest of the run is counted here
                 u32 e = 0xFFFFFFFFu;
 #pragma unroll
-                for (int j = 3; j > 0; --j) if (j > i && n[j] != 0 && 4 * sub + j <= maxSV) e = 4 * sub + j;
+                for (int j = SPL - 1; j > 0; --j) if (j > i && n[j] != 0 && SPL * sub + j <= maxSV) e = SPL * sub + j;
                 if (e == 0xFFFFFFFFu) e = nzAbove;
                 if (e == 0xFFFFFFFFu) broken = true;           // zeros up to the end of the alphabet: not a distribution
                 else { const u32 R = e - (s + 1); run[i] = R; bits += 16u * (R / 24u) + 2u * ((R % 24u) / 3u) + 2u; }
@@ -285,7 +285,7 @@ DEV size_t wg_write_ncount(u32* img, size_t cap, const int n[4], u32 maxSV, u32 
     }
     if (sub == 0) { wg_or_bits(img, 0, tl - FSE_MIN_TL, 4); pos += 4; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SPL; ++i) {
         wg_or_bits(img, pos, val[i], vnb[i]); pos += vnb[i];
         if (run[i] != 0xFFFFFFFFu) {
             u32 R = run[i];

@@ -197,6 +197,34 @@ FSEHIP_API size_t FSEHIP_frame_compressBound(size_t srcSize, unsigned blockSizeI
 FSEHIP_API size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec);
 FSEHIP_API size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 
+/* ---- FSE for 16-bit symbols (lib/fseU16.h:62-80, lib/fseU16.c) -- SURVEY 8(f) rank 4.  Alphabets of up to
+ * FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1 symbols, table logs up to 13 (default 12), ONE tANS state per stream: a different format from
+ * the byte coder's.  Sizes of the uncompressed side are in SYMBOLS (as in the reference), strides in bytes.
+ *   FSE_countU16      lib/fseU16.c:121-146   count[0..*maxSymbolValuePtr], returns the largest count; a symbol above the limit:
+ *                                            maxSymbolValue_tooSmall (limits above FSEHIP_FSEU16_MAX_SYMBOL_VALUE: maxSymbolValue_tooLarge)
+ *   FSE_compressU16   lib/fseU16.c:203-256   returns the compressed size, 0 (not compressible), 1 (one symbol only), or an error
+ *   FSE_decompressU16 lib/fseU16.c:306-329   returns the number of symbols regenerated or an error
+ * Undefined behaviour of the reference is refused instead of reproduced: 8 bytes or less of room behind the header store no payload
+ * (the reference writes in front of its buffer, fseU16.c:164 ignoring bitstream.h:191) and a stream without payload is
+ * srcSize_wrong (the reference reads through a null pointer). */
+#define FSEHIP_FSEU16_MAX_SYMBOL_VALUE 286
+#define FSEHIP_FSEU16_MAX_TABLELOG 13
+#define FSEHIP_FSEU16_DEFAULT_TABLELOG 12
+FSEHIP_API size_t FSEHIP_FSE_countU16(unsigned* count, unsigned* maxSymbolValuePtr, const unsigned short* src, size_t srcSize);
+FSEHIP_API size_t FSEHIP_FSE_compressU16(void* dst, size_t dstCapacity, const unsigned short* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);
+FSEHIP_API size_t FSEHIP_FSE_decompressU16(unsigned short* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize);
+/* batched, device-resident: block b reads d_src + b * srcStrideBytes (d_srcSizes[b] or uniformSrcSize symbols) and writes
+ * d_dst + b * dstStride; d_counts holds (FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1) entries per block */
+FSEHIP_API size_t FSEHIP_FSE_compressU16_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API size_t FSEHIP_FSE_decompressU16_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API int FSEHIP_FSE_countU16_batch(unsigned* d_counts, unsigned* d_maxSymbolValues, size_t* d_results, const unsigned short* d_src, size_t srcStrideBytes,
+                                         const size_t* d_srcSizes, size_t uniformSrcSize, unsigned maxSymbolValue, size_t nBlocks, void* stream);
+FSEHIP_API int FSEHIP_FSE_compressU16_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results, const unsigned short* d_src, size_t srcStrideBytes,
+                                            const size_t* d_srcSizes, size_t uniformSrcSize, unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                            void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API int FSEHIP_FSE_decompressU16_batch(unsigned short* d_dst, size_t dstStrideBytes, size_t dstCapacity, size_t* d_results, const void* d_cSrc, size_t cStride,
+                                              const size_t* d_cSizes, size_t uniformCSize, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+
 /* Kernel timing probe for benchmarks: between probe_begin and probe_collect every kernel launch of the library is
  * bracketed by HIP events on its own stream.  probe_collect synchronises and returns, per kernel id
  * (0 hist, 1 fse_cprep, 2 fse_encode [lane per block], 3 fse_dprep, 4 fse_decode, 5 huf_cprep, 6 huf_encode, 7 huf_dprep,
@@ -223,6 +251,11 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define HUF_compress4X_usingCTable FSEHIP_HUF_compress4X_usingCTable
 #define HUF_decompress4X_usingDTable FSEHIP_HUF_decompress4X_usingDTable
 #define HUF_decompress4X1_usingDTable FSEHIP_HUF_decompress4X1_usingDTable
+#endif
+#ifdef FSEHIP_DROPIN_U16_NAMES       /* separate switch: programs/fuzzer.c declares FSE_countU16 with another (stale) prototype */
+#define FSE_countU16 FSEHIP_FSE_countU16
+#define FSE_compressU16 FSEHIP_FSE_compressU16
+#define FSE_decompressU16 FSEHIP_FSE_decompressU16
 #endif
 
 #ifdef __cplusplus

@@ -2,7 +2,7 @@
  * Force-included (gcc -include) when compiling the reference's own programs/fuzzer.c and programs/fuzzerHuff0.c, AFTER
  * which every hot-path call written in those programs (HIST_count, FSE_compress[2], FSE_decompress,
  * FSE_compress_usingCTable, FSE_decompress_usingDTable, HUF_compress[2], HUF_decompress, HUF_compress1X/4X_usingCTable,
- * HUF_decompress4X[1]_usingDTable) resolves to libfsehip.so; the reference's lib/ objects are compiled WITHOUT it and
+ * HUF_decompress4X[1]_usingDTable; in programs/fuzzerU16.c FSE_countU16, FSE_compressU16, FSE_decompressU16) resolves to libfsehip.so; the reference's lib/ objects are compiled WITHOUT it and
  * still provide the table builders the programs call (FSE_normalizeCount, FSE_readNCount, FSE_buildCTable_raw, ...). */
 #ifndef FSE_ON_MI355X_H
 #define FSE_ON_MI355X_H
@@ -11,6 +11,10 @@
 #include "fse.h"
 #include "huf.h"
 #include "hist.h"
+#ifdef FSE_ON_MI355X_fuzzerU16
+#include "fseU16.h"
+#define FSEHIP_DROPIN_U16_NAMES
+#endif
 #define FSEHIP_DROPIN_NAMES
 #include "fsehip.h"
 #endif

@@ -105,7 +105,7 @@ class _Base:
 
     def fse_read_ncount(self, src, max_sv=255):
         src, ps = _u8(src)
-        norm = np.zeros(256, dtype=np.int16)
+        norm = np.zeros(max(256, max_sv + 1), dtype=np.int16)
         msv = C.c_uint(max_sv)
         tl = C.c_uint(0)
         r = self._call(self.N["read_ncount"], self.sz, norm.ctypes.data_as(self.vp), C.byref(msv), C.byref(tl), ps, self.sz(src.size))
@@ -362,6 +362,30 @@ class Ref(_Base):
         r = self._call("HUF_decompress4X_usingDTable", self.sz, out.ctypes.data_as(self.vp), self.sz(dst_size), ps, self.sz(csrc.size), dt.ctypes.data_as(self.vp))
         assert (out[dst_size:] == 0xA5).all()
         return int(r), out[:dst_size]
+
+    # FSE for 16-bit symbols (lib/fseU16.c): only the compiled reference has it (a side path: SURVEY 8(f) rank 4)
+    def fse_count_u16(self, src, max_sv=286):
+        src = np.ascontiguousarray(src, dtype=np.uint16)
+        count = np.zeros(max(max_sv, 286) + 1, dtype=np.uint32)
+        msv = C.c_uint(max_sv)
+        r = self._call("FSE_countU16", self.sz, count.ctypes.data_as(self.vp), C.byref(msv), src.ctypes.data_as(self.vp), self.sz(src.size))
+        return int(r), count, int(msv.value)
+
+    def fse_compress_u16(self, src, max_sv=0, table_log=0, cap=None):
+        src = np.ascontiguousarray(src, dtype=np.uint16)
+        cap = fse_compress_bound(2 * src.size) if cap is None else cap
+        out = np.zeros(max(cap, 1) + 16, dtype=np.uint8)
+        r = self._call("FSE_compressU16", self.sz, out.ctypes.data_as(self.vp), self.sz(cap), src.ctypes.data_as(self.vp), self.sz(src.size),
+                       C.c_uint(max_sv), C.c_uint(table_log))
+        return int(r), out[:cap]
+
+    def fse_decompress_u16(self, csrc, cap):
+        csrc, ps = _u8(csrc)
+        out = np.zeros(max(cap, 1) + 8, dtype=np.uint16)
+        out[cap:] = 0xA5A5
+        r = self._call("FSE_decompressU16", self.sz, out.ctypes.data_as(self.vp), self.sz(cap), ps, self.sz(csrc.size))
+        assert (out[cap:] == 0xA5A5).all()
+        return int(r), out[:cap]
 
     def max_threads(self):
         self.lib.ref_max_threads.restype = C.c_int

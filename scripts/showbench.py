@@ -6,5 +6,5 @@ print('HEAD value', d['value'], 'ms/step', d['ms_per_step'], 'enc', d['encode_GB
 print('    ', d['kernel_ms_per_step'])
 for k, v in c.items():
     print(k, {a: b for a, b in v.items() if a not in ('workload', 'parity', 'kernel_ms_per_step', 'roofline', 'value_note', 'steps', 'blocks_per_gpu')})
-    print('    ', v['kernel_ms_per_step'], v['roofline']['kernel'], v['roofline']['frac'])
+    if 'kernel_ms_per_step' in v: print('    ', v['kernel_ms_per_step'], v['roofline']['kernel'], v['roofline']['frac'])
 if cb: print(cb)
