@@ -3,8 +3,10 @@
 //                     (reference: lib/fse_compress.c:632-677, :325-342, :348-494, :192-298, :66-169)
 //   decompress side : FSE_readNCount, FSE_buildDTable
 //                     (reference: lib/entropy_common.c:41-144, lib/fse_decompress.c:71-126,255-274)
-// v1 mapping: one lane per block (64 blocks per wavefront), the tables are produced in the
-// reference's in-memory layout in global scratch; the hot-loop kernels stage them into LDS.
+// Mapping: one wave per block wherever the work is wide (k_fse_cprep, k_fse_dbuild: per-symbol lanes, scans, the wave-cooperative
+// spread / rank); one lane per block only for the NCount header parser, whose fields depend on all fields before them
+// (k_fse_dparse).  The CTable is produced in the reference's in-memory layout, the decoding table in the decoder's own cell formats,
+// both in global scratch; the hot-loop kernels stage them into LDS.
 #include "internal.h"
 
 #include "wave_glue.h"

@@ -57,7 +57,7 @@ hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
 size_t fse_encode_blocks_per_round(unsigned maxTableLog);
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s);  // block-parallel variant (one wave per block, streaming I/O)
 // picks the wave-per-block kernel for uniformly sized blocks of >= 2 KiB, the lane-per-block kernel otherwise (both exact)
-// With prepare-kernel metadata the choice is per block (k_fse_cnorm marks extremely skewed tables FSE_ENC_LANE, the wave
+// With prepare-kernel metadata the choice is per block (k_fse_cprep marks extremely skewed tables FSE_ENC_LANE, the wave
 // kernel hands over blocks it cannot write word-wise): both kernels are launched and each one skips the other's blocks.
 inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
 {
