@@ -225,7 +225,7 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
             "encode_GBps": round(total / enc / 1e9, 2), "decode_GBps": round(total / dec / 1e9, 2),
             "compressed_bytes_per_block": round(float(cres.sum().item()) / n_blocks, 1), "parity": parity,
             "workload": "16-bit symbols (lib/fseU16.c): %d x 16384 symbols per GPU, 287-symbol alphabet (fuzzerU16's generator, p = 0.08), "
-                        "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the chains run one lane per block" % n_blocks}
+                        "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
 
 
 def run_case(hip, codecs, steps, warmup, barrier, rank, check=True):

@@ -10,9 +10,12 @@
 //     alphabet: the spread as "the k-th kept visit of the walk m -> m*step gets the symbol whose cumulative range holds k" (every
 //     lane takes a run of visits and walks the cumulative counts alongside), the ranks -- the order of a symbol's cells -- by
 //     walking the cells 64 at a time: lanes holding the same symbol find each other with nine ballots (one per symbol bit);
-//   * the chain itself is the reference's loop, one lane per block (tables in global memory: 16-32 KB per block would leave
-//     five blocks per CU in LDS for a single chain each), with the reference's flush cadence and clamping, so that return values
-//     agree with it in every case that is defined there.
+//   * the encoder's chain is split across the 64 lanes of a wave by speculation and verification (k_u16_encode_wave: the scheme of
+//     fse_encode_wave.hip on one chain); blocks under 2048 symbols take the reference's loop on one lane (k_u16_encode), with its flush
+//     cadence and clamping;
+//   * a tANS decoder cannot be split (it does not resynchronise), and a single chain per block with 16-32 KB of tables would leave
+//     five to ten blocks per CU if the tables lived in LDS: the decoder runs the reference's loop one lane per block on tables in
+//     global memory (k_u16_decode) -- bound by random table reads.
 // Where the reference's behaviour is undefined the device path refuses instead: FSE_compressU16 with 8 bytes or less behind the
 // header (BIT_initCStream's error is ignored at fseU16.c:164 and the flushes then write in front of the buffer) stores no payload
 // and returns what the reference would (the header size alone); FSE_decompressU16 with nothing behind the header (the reference
@@ -202,13 +205,134 @@ __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
     if (lane == 0) a.meta[b] = m;
 }
 
-// FSE_compressU16_usingCTable (:150-200) + the verdicts of FSE_compressU16 (:245-255): one lane per block
+// ---- FSE_compressU16_usingCTable (:150-200) split across the 64 lanes of a wave -------------------------------------------------
+// The single chain "forgets" like the byte coder's two (fse_encode_wave.hip): lane t owns the t-th 64th of the symbols in emission
+// order (last symbol first); pass 1 warms up in front of its range from an arbitrary state, takes the state it arrives with as its
+// speculated start, runs its range counting bits and keeps its end state; a lane whose start differs from its predecessor's end
+// re-runs from there until no link changes (lane 0 starts from FSE_initCState's exact state, so verified links make every lane exact);
+// a prefix sum places every lane's bits, the verdicts of BIT_closeCStream (bitstream.h:254-260) and FSE_compressU16 (:252-253) are
+// known before a bit is written, and pass 2 emits: the payload area is zeroed first, whole aligned words inside a lane's bit range
+// are plain stores, the words it shares with its neighbours are OR-ed in (two atomics per lane).
+// Blocks it finishes are marked U16_DONE; shorter ones are left to the lane-per-block kernel behind it.
+#define U16_DONE 3u
+#define U16_WAVE_MIN 2048u          // symbols: below this the launch of 64 lanes per block does not pay
+struct U16Sink {                    // bit sink of one lane: its bits go out as ALIGNED dwords (the payload may start anywhere: bit positions are
+    u32* p; u64 acc; u32 nacc; bool shared;     // counted from the aligned word holding its first byte); shared: the next word also holds a neighbour's bits
+    DEV void open(u8* payload, u32 bit0)
+    {
+        const uintptr_t a = (uintptr_t)payload;
+        bit0 += 8u * (u32)(a & 3u);
+        p = (u32*)(a & ~(uintptr_t)3) + (bit0 >> 5); nacc = bit0 & 31u; acc = 0; shared = nacc != 0;
+    }
+    DEV void put(u32 v, u32 nb) { acc |= (u64)v << nacc; nacc += nb; if (nacc >= 32u) word(); }
+    DEV void word()
+    {
+        if (shared) { atomicOr(p, (u32)acc); shared = false; } else *p = (u32)acc;
+        ++p; acc >>= 32; nacc -= 32u;
+    }
+    DEV void close() { if (nacc) atomicOr(p, (u32)acc); }                    // < 32 bits left: their word is shared with the next lane (or ends the stream)
+};
+__global__ __launch_bounds__(64) void k_u16_encode_wave(U16CArgs a)
+{
+    __shared__ u16 st[1u << FSEHIP_FSE_MAX_TABLELOG];                        // the encoder never picks a table log above 12 (see k_u16_cprep)
+    __shared__ uint2 tt[U16_SYMS];
+    const u32 lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const U16Meta m = a.meta[b];
+    const size_t n64 = a.srcSizes ? a.srcSizes[b] : a.uniformSrcSize;
+    if (m.state != 1 || n64 < U16_WAVE_MIN || n64 >= ((size_t)1 << 27) || m.tableLog > FSEHIP_FSE_MAX_TABLELOG) return;   // uniform
+    {   const uintptr_t blockDst = (uintptr_t)(a.dst + b * a.dstStride);     // the aligned word holding the first payload byte must belong to this block
+        if (((blockDst + m.hdrSize) & ~(uintptr_t)3) < blockDst) return; }
+    const u32 n = (u32)n64, tl = m.tableLog, ts = 1u << tl;
+    const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
+    u32 presentLane = 0;
+    {   const u32* const g = (const u32*)(a.stateTables + (b << U16_MAXTL));
+        for (u32 i = lane; i < ts / 2; i += 64) ((u32*)st)[i] = g[i];
+        const uint2* const gt = (const uint2*)(a.symTT + b * 2 * (U16_MAXSV + 1));
+        for (u32 sy = lane; sy <= m.maxSV; sy += 64) { const uint2 e = gt[sy]; tt[sy] = e; presentLane += e.y != ((tl + 1u) << 16) - ts; }
+    }
+    __syncthreads();
+    const u32 present = wg_sum<64>(presentLane);
+    u32 warm = (4u << tl) / (present ? present : 1u);                        // two states fed the same symbols merge with probability ~ present / tableSize per step
+    warm = warm < 64u ? 64u : (warm > 2048u ? 2048u : warm);
+    auto step = [&](u32& x, u32 sym, u32& nb) { const uint2 e = tt[sym]; nb = (x + e.y) >> 16; const u32 low = x & ((1u << nb) - 1u); x = st[(x >> nb) + e.x]; return low; };
+    // symbols j in [ja, jb) in emission order (j = 0 is the LAST symbol of the source): eight per 16-byte load, the next load issued
+    // before the current eight are used (a load behind every symbol would cost a memory round trip per step)
+    auto walk = [&](u32 ja, u32 jb, auto&& f) {
+        u32 j = ja;
+        if (j + 8u <= jb) {
+            uint4 cur; __builtin_memcpy(&cur, src + (n - 8u - j), 16);
+            for (;;) {
+                const u32 jn = j + 8u;
+                const bool more = jn + 8u <= jb;
+                uint4 nxt = cur;
+                if (more) __builtin_memcpy(&nxt, src + (n - 8u - jn), 16);
+                __asm__ volatile("" ::: "memory");
+                f(cur.w >> 16); f(cur.w & 0xFFFFu); f(cur.z >> 16); f(cur.z & 0xFFFFu); f(cur.y >> 16); f(cur.y & 0xFFFFu); f(cur.x >> 16); f(cur.x & 0xFFFFu);
+                j = jn;
+                if (!more) break;
+                cur = nxt;
+            }
+        }
+        for (; j < jb; ++j) f((u32)src[n - 1u - j]);
+    };
+    auto count = [&](u32& x, u32 ja, u32 jb) { u32 bits = 0; walk(ja, jb, [&](u32 sym) { u32 nb; (void)step(x, sym, nb); bits += nb; }); return bits; };
+    const u32 C = (n + 63u) / 64u;
+    const u32 j0 = lane * C < n ? lane * C : n, j1 = (lane + 1u) * C < n ? (lane + 1u) * C : n;
+    const bool mine = j0 < j1;
+    const u32 lastLane = (n - 1u) / C;
+    // ---- pass 1
+    u32 x = ts, start = ts, end = ts, bits = 0;
+    if (mine) {
+        if (j0 > warm) (void)count(x, j0 - warm, j0); else if (j0) (void)count(x, 0, j0);      // (close to the end of the source: exact from FSE_initCState)
+        start = x; bits = count(x, j0, j1); end = x;
+    }
+    for (;;) {                                                               // ---- verification / repair
+        const u32 prevEnd = (u32)__shfl_up((int)end, 1, WAVE);
+        const bool bad = mine && lane > 0 && start != prevEnd;
+        if (!__any(bad)) break;
+        if (bad) { start = prevEnd; x = start; bits = count(x, j0, j1); end = x; }
+    }
+    if (lane == lastLane) bits += tl + 1u;                                    // FSE_flushCState and the end mark
+    u32 incl = bits;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+    const u32 total = (u32)__shfl((int)incl, 63, WAVE), excl = incl - bits;
+    // ---- verdicts
+    u8* const payload = a.dst + b * a.dstStride + m.hdrSize;
+    const size_t cap = a.dstCapacity - m.hdrSize;
+    const size_t cs = (cap > 8 && (size_t)(total >> 3) < cap - 8) ? (size_t)((total + 7u) >> 3) : 0;
+    const size_t sum = (size_t)m.hdrSize + cs, result = sum >= (n64 - 1) * 2 ? 0 : sum;
+    if (cs) {
+        // ---- pass 2: zero the payload (aligned words, bytes at the edges), then every lane writes its bits
+        {   const uintptr_t lo = (uintptr_t)payload, hi = lo + cs, alo = (lo + 3) & ~(uintptr_t)3, ahi = hi & ~(uintptr_t)3;
+            if (alo <= ahi) {
+                if (lane < alo - lo) payload[lane] = 0;
+                for (uintptr_t q = alo + 4 * lane; q < ahi; q += 256) *(u32*)q = 0;
+                if (lane < hi - ahi) ((u8*)ahi)[lane] = 0;
+            } else if (lane < cs) payload[lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");               // the zeros are in place before any lane ORs into them (same wave, same L2:
+        __builtin_amdgcn_s_waitcnt(0);                                        // no device-wide write-back needed -- an agent-scope fence costs 3 ms here)
+        if (mine) {
+            U16Sink k; k.open(payload, excl);
+            x = start;
+            walk(j0, j1, [&](u32 sym) { u32 nb; const u32 low = step(x, sym, nb); k.put(low, nb); });
+            if (lane == lastLane) { k.put(x & (ts - 1u), tl); k.put(1u, 1u); }
+            k.close();
+        }
+    }
+    if (lane == 0) { a.results[b] = result; a.meta[b].state = U16_DONE; }
+}
+
+// FSE_compressU16_usingCTable (:150-200) + the verdicts of FSE_compressU16 (:245-255) as the reference loops, one lane per block: short
+// blocks (and whatever the wave kernel above leaves)
 __global__ void k_u16_encode(U16CArgs a)
 {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.nBlocks) return;
     const U16Meta m = a.meta[b];
-    if (m.state == 0) return;
+    if (m.state != 1) return;
     const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
     const size_t n = a.srcSizes ? a.srcSizes[b] : a.uniformSrcSize;
     const u16* const st = a.stateTables + (b << U16_MAXTL);
@@ -307,6 +431,8 @@ __global__ void k_u16_decode(U16DArgs a)
         state = (c & 0xFFFFu) + low;
         return (u16)(c >> 20);
     };
+    // (Measured: walking the bulk with a lazily refilled window instead of a reload per symbol is SLOWER, 15.1 vs 12.1 ms per 25k blocks --
+    // the kernel is bound by the random 4-byte table reads, 26 GB of 64-byte sectors per 25k blocks, not by the chain's length.)
     while (r.reload() < BR_COMPLETED && op < cap) out[op++] = step();
     size_t result;
     if (!(r.at == 0 && r.used == 64)) result = FERR(corruption_detected);   // BIT_endOfDStream
@@ -322,7 +448,10 @@ hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_u16_cprep, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
-    if (!a.countsOut) hipLaunchKernelGGL(k_u16_encode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    if (!a.countsOut) {
+        hipLaunchKernelGGL(k_u16_encode_wave, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_u16_encode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s)
