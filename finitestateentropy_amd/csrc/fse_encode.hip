@@ -174,8 +174,8 @@ hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s)
     const size_t ldsBytes = FSE_ENC_LDS;
     {   const hipError_t e = ensure_dyn_lds((const void*)k_fse_encode, (int)ldsBytes); if (e != hipSuccess) return e; }
     fse_encode_geometry(a.maxTableLog, &a.slotU32, &a.G);
-    // 32-bit lane offsets inside a group
-    if (a.nBlocks > 1 && ((a.src.stride > 0x3FFFFFFu) || (a.dstStride > 0x3FFFFFFu))) return hipErrorInvalidValue;
+    // 32-bit lane offsets inside a group: blocks of 64 MB and more get a group each
+    if (a.nBlocks > 1 && ((a.src.stride > 0x3FFFFFFu) || (a.dstStride > 0x3FFFFFFu))) a.G = 1;
     if (a.dstCapacity > 0x7FFFFFF0u) a.dstCapacity = 0x7FFFFFF0u;   // blocks are < 2 GiB on this path (see kernel)
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
     probe_before(PK_FSE_ENCODE, s);
