@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
         a.meta[b] = m;
         if (m.state == 0) a.results[b] = result;
     }
-    // append my block to its class list: one atomic per class and wave
+    // append my block to the list of its class and size bin: one atomic per list and wave
+    if (cls >= 0) { const size_t bin = view_size(a.csrc, b) >> FSE_DBIN_LOG; cls = cls * FSE_DBINS + (int)(bin < FSE_DBINS - 1 ? bin : FSE_DBINS - 1); }
     const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
     for (int c = 0; c < FSE_DCLS_COUNT; ++c) {
         const unsigned long long mask = __ballot(cls == c);
         if (!mask) continue;                                               // uniform
@@ -227,9 +227,9 @@ hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
     // the builds are latency-bound single-wave workgroups: their LDS footprint (sized by the largest table of the launch)
     // decides how many run per CU, so the tableLog <= 11 class gets a launch of its own
     const u32 capA = a.maxLog < FSE_DEC_FAST_MAXLOG ? capTs : (1u << FSE_DEC_FAST_MAXLOG);
-    hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capA), s, a, capTs, (int)FSE_DCLS_REV11, 1, capA);
+    hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capA), s, a, capTs, (int)FSE_DCLS_REV11 * FSE_DBINS, (int)FSE_DBINS, capA);
     if (a.maxLog > FSE_DEC_FAST_MAXLOG)
-        hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capTs), s, a, capTs, (int)FSE_DCLS_REV12, 2, capTs);
+        hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capTs), s, a, capTs, (int)FSE_DCLS_REV12 * FSE_DBINS, 2 * (int)FSE_DBINS, capTs);
     probe_after(PK_FSE_DPREP, s);
     return hipGetLastError();
 }

@@ -77,7 +77,11 @@ inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
 //   FSE_DCLS_PLAIN : tableLog 12 with a symbol owning more than half the table (some nbBits == 0: rev(newState) then needs 12 bits)
 //                    -> cells newState | nbBits << 12, the register-window loop
 // Each class has its own list of block indices (dense workgroups) and its own launch; see fse_decode.hip.
-enum { FSE_DCLS_REV11 = 0, FSE_DCLS_REV12 = 1, FSE_DCLS_PLAIN = 2, FSE_DCLS_COUNT = 3 };
+// Inside a class the blocks are binned by compressed size (FSE_DBINS bins of FSE_DBIN_BYTES): a workgroup lasts as long as its slowest
+// block, and how fast a block decodes follows its input rate -- a mixed batch (BASELINE config 5: P02 / P14 / P80 interleaved) otherwise
+// runs every workgroup at the pace of its P02 blocks.  List index = class * FSE_DBINS + bin.
+enum { FSE_DCLS_REV11 = 0, FSE_DCLS_REV12 = 1, FSE_DCLS_PLAIN = 2, FSE_DCLS_KINDS = 3, FSE_DBINS = 4, FSE_DCLS_COUNT = FSE_DCLS_KINDS * FSE_DBINS };
+#define FSE_DBIN_LOG 13          // 8 KiB of compressed bytes per bin (the last bin is open-ended)
 struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
     BlockView csrc;
     unsigned maxLog;
@@ -86,7 +90,7 @@ struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCo
     u8* symtab;                  // symbol of the cell at the same index
     s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
     FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1 | class << 2
-    u32* lists;                  // FSE_DCLS_COUNT lists of block indices, `nBlocks` entries apart
+    u32* lists;                  // FSE_DCLS_COUNT lists (class x size bin) of block indices, `nBlocks` entries apart
     u32* counts;                 // their lengths (zeroed by the launcher)
     size_t* results;
     size_t nBlocks;
@@ -102,8 +106,8 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     const FseMeta* meta;         // nullptr for the plain usingDTable batch
     unsigned maxTableLog;        // global table slots hold 1 << maxTableLog cells
     unsigned ldsLog;             // LDS table slots hold 1 << ldsLog cells (set by the launcher from the class)
-    const u32* list;             // block indices of this launch's class and their number (device memory), or nullptr: all blocks
-    const u32* count;
+    const u32* list;             // one-shot path: the class's FSE_DBINS lists of block indices (nBlocks entries apart) and their
+    const u32* count;            // FSE_DBINS lengths, in device memory (fse_dec_block, fse_decode.hip); nullptr: all blocks in order
     int G;
     unsigned slotU32;
     size_t nBlocks;
