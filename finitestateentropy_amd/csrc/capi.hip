@@ -225,7 +225,7 @@ extern "C" int FSEHIP_FSE_compress_usingCTable_batch(void* d_dst, size_t dstStri
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
     a.src = mkview(d_src, srcStride, d_sizes, uniformSize);
     a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr;
-    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks; a.list = nullptr; a.count = nullptr;
     return (int)launch_fse_encode_auto(a, (hipStream_t)stream);
 }
 
@@ -256,7 +256,7 @@ static FseCWs fse_cws(unsigned tableLog)
     w.maxTl = tl;
     w.ctU32 = FSEHIP_FSE_CTABLE_SIZE_U32(tl, 255);
     w.ts = (size_t)1 << tl;
-    w.perBlock = 1024 + 4 + 8 + sizeof(FseMeta) + 4 * w.ctU32 + w.ts;
+    w.perBlock = 1024 + 4 + 8 + sizeof(FseMeta) + 4 * w.ctU32 + w.ts + FSE_EBINS * sizeof(u32);
     return w;
 }
 #define WS_SLACK 2048
@@ -298,6 +298,8 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     size_t* hres = (size_t*)carve(chunk * 8);
     FseMeta* meta = (FseMeta*)carve(chunk * sizeof(FseMeta));
     u32* ctables = (u32*)carve(chunk * 4 * w.ctU32);
+    u32* encLists = (u32*)carve(chunk * FSE_EBINS * sizeof(u32));
+    u32* encCounts = (u32*)carve(FSE_EBINS * sizeof(u32));
     if ((size_t)(p - (u8*)d_workspace) > workspaceBytes) {
         // alignment slack exhausted: shrink the chunk by one (WS_SLACK covers 5 x 256 of padding)
         return (int)hipErrorInvalidValue;
@@ -320,7 +322,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
         FseEncArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
         e.src = src; e.ctables = ctables; e.ctStrideU32 = w.ctU32; e.meta = meta;
-        e.maxTableLog = w.maxTl; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
+        e.maxTableLog = w.maxTl; e.G = 0; e.slotU32 = 0; e.nBlocks = nb; e.list = encLists; e.count = encCounts;
         CK(launch_fse_encode_auto(e, s));
     }
     return 0;

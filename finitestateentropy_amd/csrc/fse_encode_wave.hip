@@ -242,11 +242,20 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     const u32 slot = wv * WV_BPW + part;
     u32* const lds = ldsAll + slot * slotWords;
     const u32 ldsOff = wv_lds_addr(ldsAll) + slot * slotWords * 4u;         // absolute LDS byte address of this block's slot
-    const size_t b = ((size_t)blockIdx.x * FSE_WV_WAVES + wv) * WV_BPW + part;
+    const size_t pos = ((size_t)blockIdx.x * FSE_WV_WAVES + wv) * WV_BPW + part;
 
     // ---- per-block set-up; `on` = this block is (still) being encoded by its lanes.  Everything below is uniform per block,
     //      the blocks of a wave diverge freely; wave-wide shuffles are only read inside a block's own lanes.
-    bool on = b < a.nBlocks;
+    //      One-shot path: entry `pos` of the pace-bin lists taken one after the other (internal.h), so that the two blocks of a wave are
+    //      of a kind and the wave does not wait for a slowly mixing block next to a fast one.
+    size_t b = pos;
+    bool on = pos < a.nBlocks;
+    if (a.list) {
+        size_t q = pos; int i = 0;
+        for (; i < FSE_EBINS; ++i) { const u32 c = a.count[i]; if (q < c) break; q -= c; }
+        on = i < FSE_EBINS;
+        b = on ? (size_t)a.list[(size_t)i * a.nBlocks + q] : 0;
+    }
     u32 hdr = 0;
     if (on && a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) on = false; else hdr = a.meta[b].hdrSize; }
     const u32* const gct = a.ctables + (on ? b : 0) * a.ctStrideU32;
@@ -409,6 +418,33 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     }
     ETIMING(T4 = __builtin_readcyclecounter(); if (hl == 0 && b < 4096) { unsigned long long* t = g_encTiming + 8 * b; t[0] = T1 - T0; t[1] = T2 - T1; t[2] = T3 - T2; t[3] = T4 - T3; t[4] = rounds; t[5] = nBad0; t[6] = firstBad; })
     if (on && hl == 0) a.results[b] = result;
+}
+
+// the FSE_ENC_PAR blocks by pace bin: 64 blocks per wave, one atomic per bin and wave
+__global__ __launch_bounds__(64) void k_fse_enc_lists(FseEncArgs a)
+{
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const u32 lane = threadIdx.x;
+    int bin = -1;
+    if (b < a.nBlocks && a.meta[b].state == FSE_ENC_PAR) { const u32 p = a.meta[b].pace; bin = (int)(p < FSE_EBINS ? p : FSE_EBINS - 1); }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c = 0; c < FSE_EBINS; ++c) {
+        const unsigned long long mask = __ballot(bin == c);
+        if (!mask) continue;                                               // uniform
+        const int leader = __builtin_ctzll(mask);
+        u32 base = 0;
+        if ((int)lane == leader) base = atomicAdd(&a.count[c], (u32)__builtin_popcountll(mask));
+        base = (u32)__shfl((int)base, leader, WAVE);
+        if (bin == c) a.list[(size_t)c * a.nBlocks + base + (u32)__builtin_popcountll(mask & below)] = (u32)b;
+    }
+}
+hipError_t launch_fse_enc_lists(const FseEncArgs& a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(a.count, 0, FSE_EBINS * sizeof(u32), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fse_enc_lists, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s)

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a, u32 capTs)
     const size_t b = blockIdx.x;
     const u32 lane = threadIdx.x;
     const size_t n = view_size(a.src, b);
-    FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+    FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0; m.pace = 0;
     // early outs (fse_compress.c:647-655), uniform
     const size_t top = a.histResults[b];
     size_t result = 0; bool go = false;
@@ -67,6 +67,12 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a, u32 capTs)
     int top1 = nn[0] > nn[1] ? nn[0] : nn[1]; top1 = nn[2] > top1 ? nn[2] : top1; top1 = nn[3] > top1 ? nn[3] : top1;
     top1 = wave_max_i32(top1);
     m.state = ((u32)top1 * 64u > (63u << tl)) ? FSE_ENC_LANE : FSE_ENC_PAR;
+    {   // pace bin for the encoder's block order (internal.h): tableSize / symbols in use = the merging time of two encoder states
+        u32 present = (nn[0] != 0) + (nn[1] != 0) + (nn[2] != 0) + (nn[3] != 0);
+        present = wg_sum<64>(present);
+        const u32 mix = (1u << tl) / (present ? present : 1u);
+        m.pace = mix < 64u ? 0u : mix < 128u ? 1u : mix < 256u ? 2u : 3u;
+    }
     m.tableLog = tl; m.maxSV = maxSV;
     if (lane == 0) a.meta[b] = m;
     // ---- FSE_buildCTable: the table is written straight to global memory, symbolTT entries coalesced, stateTable entries as
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
     const u32 lane = threadIdx.x;
     int cls = -1;                                                          // decoder class of my block (-1: none / finished here)
     if (b < a.nBlocks) {
-        FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+        FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0; m.pace = 0; m.pace = 0;
         const u8* const in = view_ptr(a.csrc, b);
         const size_t cSize = view_size(a.csrc, b);
         size_t result = 0;

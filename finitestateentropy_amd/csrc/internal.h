@@ -21,6 +21,7 @@ struct FseMeta {
     u32 hdrSize;    // bytes of NCount header in front of the payload
     u32 tableLog;
     u32 maxSV;
+    u32 pace;       // compress side: how slowly the encoder states mix with this table (bin 0 .. FSE_EBINS-1 of tableSize / symbols in use)
 };
 
 struct FseCPrepArgs {            // glue g1-g4 (compress side): lib/fse_compress.c:632-677 minus the hot loops
@@ -49,13 +50,18 @@ struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per b
     unsigned slotU32;            // LDS words per table slot
     size_t nBlocks;
     unsigned onlyState;          // with meta: 0 = every prepared block, else only blocks whose meta.state equals it
-};
+    u32* list; u32* count;       // wave kernel, one-shot path: FSE_EBINS lists of the FSE_ENC_PAR blocks by pace (nBlocks entries apart) and their
+};                               // lengths (device memory, filled by launch_fse_encode_auto), or nullptr: blocks in order
+// A wave of the encoder carries two blocks and lasts as long as the slower one; how long a block takes follows its table (few symbols:
+// the speculated states merge slowly, more repair rounds).  The blocks are therefore walked in order of their pace bin.
+enum { FSE_EBINS = 4 };
 // meta.state on the compress side: 0 = finished by the prepare kernel, FSE_ENC_PAR / FSE_ENC_LANE = table ready, preferred kernel
 enum { FSE_ENC_PAR = 1, FSE_ENC_LANE = 2 };
 __host__ __device__ inline bool fse_enc_skip(unsigned state, unsigned onlyState) { return state == 0 || (onlyState != 0 && state != onlyState); }
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
 size_t fse_encode_blocks_per_round(unsigned maxTableLog);
-hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s);  // block-parallel variant (one wave per block, streaming I/O)
+hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s);
+hipError_t launch_fse_enc_lists(const FseEncArgs& a, hipStream_t s);     // fills a.list / a.count from meta (state == FSE_ENC_PAR, pace)  // block-parallel variant (one wave per block, streaming I/O)
 // picks the wave-per-block kernel for uniformly sized blocks of >= 2 KiB, the lane-per-block kernel otherwise (both exact)
 // With prepare-kernel metadata the choice is per block (k_fse_cprep marks extremely skewed tables FSE_ENC_LANE, the wave
 // kernel hands over blocks it cannot write word-wise): both kernels are launched and each one skips the other's blocks.
@@ -63,9 +69,10 @@ inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
 {
     a.onlyState = 0;
     if (a.src.sizes || a.src.uniform < 2048 || a.dstCapacity > 0x7FFFFFF0u) return launch_fse_encode(a, s);
-    if (!a.meta) return launch_fse_encode_wave(a, s);
+    if (!a.meta) { a.list = nullptr; a.count = nullptr; return launch_fse_encode_wave(a, s); }
     a.onlyState = FSE_ENC_PAR;
-    hipError_t e = launch_fse_encode_wave(a, s);
+    hipError_t e = a.list ? launch_fse_enc_lists(a, s) : hipSuccess;
+    if (e == hipSuccess) e = launch_fse_encode_wave(a, s);
     if (e != hipSuccess) return e;
     a.onlyState = FSE_ENC_LANE;
     return launch_fse_encode(a, s);
