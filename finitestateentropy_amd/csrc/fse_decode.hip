@@ -370,21 +370,6 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
 // Entry `pos` of a launch's block list.  The one-shot path hands over a class's FSE_DBINS size-bin lists (internal.h), walked one
 // after the other as if they were one list sorted by compressed size: a workgroup lasts as long as its slowest block, and the pace
 // of a block follows its input rate.
-DEV size_t fse_dec_total(const FseDecArgs& a)
-{
-    if (!a.count) return a.nBlocks;
-    size_t t = 0;
-    for (int i = 0; i < FSE_DBINS; ++i) t += a.count[i];
-    return t;
-}
-DEV size_t fse_dec_block(const FseDecArgs& a, size_t pos)
-{
-    if (!a.list) return pos;
-    int i = 0;
-    for (; i < FSE_DBINS - 1; ++i) { const u32 n = a.count[i]; if (pos < n) break; pos -= n; }
-    return a.list[(size_t)i * a.nBlocks + pos];
-}
-
 // LDS: G tables A[2^ldsLog] (u16) on table-size aligned addresses | DecCtl[G] | per block: state ring
 // (FSE_DEC_RING x 8 B), input ring (256 + 16 B) | two flag words
 template <bool FAST>
@@ -394,8 +379,20 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // slot g of this workgroup = entry first + g of the launch's block list (or simply block first + g)
     const size_t first = (size_t)blockIdx.x * a.G;
-    const size_t nTot = fse_dec_total(a);
+    // The one-shot path hands over a class's FSE_DBINS size-bin lists (internal.h), walked one after the other as if they were one
+    // list sorted by compressed size.  Their lengths come in one 16-byte load; where the workgroup's first slot falls is uniform, and
+    // its other slots are nearly always in the same bin.
+    static_assert(FSE_DBINS == 4, "the bin lengths are read as one uint4");
+    uint4 cn = make_uint4((u32)a.nBlocks, 0, 0, 0);
+    if (a.count) cn = *(const uint4*)a.count;
+    const size_t nTot = (size_t)cn.x + cn.y + cn.z + cn.w;
     if (first >= nTot) return;                                   // uniform: the grid is sized for the worst case
+    auto slotBlock = [&](size_t g) -> size_t {                   // block of slot g of this workgroup (first + g < nTot)
+        if (!a.list) return first + g;
+        size_t q = first + g; size_t i = 0;
+        if (q >= cn.x) { q -= cn.x; i = 1; if (q >= cn.y) { q -= cn.y; i = 2; if (q >= cn.z) { q -= cn.z; i = 3; } } }
+        return a.list[i * a.nBlocks + q];
+    };
     u8* const lds8 = (u8*)lds;
     const u32 tabStride = 2u << a.ldsLog;                        // bytes per LDS table slot
     DecCtl* const ctlAll = (DecCtl*)(lds8 + (size_t)a.G * tabStride);
@@ -426,18 +423,18 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
                 const u32 idx = tid + k * FSE_DEC_THREADS;
                 if (idx < nvec) {
                     const size_t sl = first + (idx >> vptLog);
-                    const size_t bi = fse_dec_block(a, sl);
+                    const size_t bi = slotBlock(sl - first);
                     buf[k] = ((const uint4*)(a.atab + (bi << a.maxTableLog)))[idx & ((1u << vptLog) - 1u)];
                 }
             }
 #pragma unroll
             for (u32 k = 0; k < MAXV; ++k) { const u32 idx = tid + k * FSE_DEC_THREADS; if (idx < nvec) dstv[idx] = buf[k]; }
             if (!FAST) for (size_t g = 0; g < nTab; ++g) {                 // a cell with nbBits == 0 needs a counter > tableSize/2
-                const u32 st = a.meta[fse_dec_block(a, first + g)].state; anyNb0 |= st != 0 && !(st & 2u); }
+                const u32 st = a.meta[slotBlock(g)].state; anyNb0 |= st != 0 && !(st & 2u); }
         }
         else for (int g = 0; g < a.G; ++g) {
             if (first + g >= nTot) break;
-            const size_t b = fse_dec_block(a, first + g);
+            const size_t b = slotBlock(g);
             if (a.meta && a.meta[b].state == 0) continue;
             if (FAST) __builtin_trap();                          // the bit-reversed loop takes k_fse_dbuild tables only (launch_fse_decode)
             const u32* t = a.dtables + b * a.dtStrideU32;
@@ -467,7 +464,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     const int gsl = lane >> 1;
     const u32 half = (u32)lane & 1u, maskB = half ? ~0u : 0u;
     const bool inRange = gsl < a.G && first + (size_t)gsl < nTot;
-    const size_t b = inRange ? fse_dec_block(a, first + (size_t)gsl) : 0;
+    const size_t b = inRange ? slotBlock((size_t)gsl) : 0;
     bool owner = wave == 0 && inRange;
     u32 hdr = 0;
     if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
@@ -653,7 +650,7 @@ hipError_t launch_fse_decode_classes(FseDecArgs a, const u32* lists, const u32* 
     if (a.nBlocks == 0) return hipSuccess;
     probe_before(PK_FSE_DECODE, s);
     hipError_t e = hipSuccess;
-    for (int c = 0; c < FSE_DCLS_KINDS && e == hipSuccess; ++c) {              // the class's FSE_DBINS lists = one launch (fse_dec_block)
+    for (int c = 0; c < FSE_DCLS_KINDS && e == hipSuccess; ++c) {              // the class's FSE_DBINS lists = one launch (slotBlock in k_fse_decode)
         if (c != FSE_DCLS_REV11 && a.maxTableLog <= FSE_DEC_FAST_MAXLOG) break;      // those classes need tableLog 12
         a.list = lists + (size_t)c * FSE_DBINS * a.nBlocks; a.count = counts + c * FSE_DBINS;
         a.ldsLog = c == FSE_DCLS_REV11 ? (a.maxTableLog < FSE_DEC_FAST_MAXLOG ? a.maxTableLog : FSE_DEC_FAST_MAXLOG) : a.maxTableLog;

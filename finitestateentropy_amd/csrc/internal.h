@@ -114,7 +114,7 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     unsigned maxTableLog;        // global table slots hold 1 << maxTableLog cells
     unsigned ldsLog;             // LDS table slots hold 1 << ldsLog cells (set by the launcher from the class)
     const u32* list;             // one-shot path: the class's FSE_DBINS lists of block indices (nBlocks entries apart) and their
-    const u32* count;            // FSE_DBINS lengths, in device memory (fse_dec_block, fse_decode.hip); nullptr: all blocks in order
+    const u32* count;            // FSE_DBINS lengths, in device memory (slotBlock, fse_decode.hip); nullptr: all blocks in order
     int G;
     unsigned slotU32;
     size_t nBlocks;
