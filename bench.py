@@ -285,6 +285,9 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_block": round(alg, 1),
            "blocks_per_launch": round(blocks_per_launch, 1), "avg_launch_ms": round(dom_ms / dom_launches, 4)}
+    if dom.endswith("decode"):    # the decoders run one launch per class of blocks; HIP events bracket the group
+        out["note"] = ("avg_launch_ms brackets the kernel's launches of one step (one per decoder class: launches over classes without blocks "
+                       "return in microseconds and show up as extra calls in rocprofv3's table; profiles/*_pmc.md lists the per-pass totals)")
     if by_size:   # cross-check of `traffic`: the L2's memory-side requests counted by request size (exact bytes, profiles/*_pmc.md)
         out["traffic_by_request_size"] = {"read_bytes_per_block": by_size["read"], "write_bytes_per_block": by_size["write"]}
     return out

@@ -91,6 +91,25 @@ def main():
         if rb is not None:
             rec["request_size_bytes_per_block"] = {"read": round(rb / (nblocks * passes), 1), "write": round(wb / (nblocks * passes), 1)}
         json.dump(rec, open("profiles/traffic_%s.json" % k, "w"))
+    # kernel-trace run (scripts/profile.sh: bench.py --steps 5 --warmup 2 = 7 passes): durations per pass, the figure bench.py's
+    # kernel_ms_per_step / roofline.avg_launch_ms report from HIP events.  A kernel that is launched once per decoder class shows
+    # more calls than passes in rocprofv3's table -- the launches over classes without blocks return at once (a few microseconds)
+    # and halve its "AverageNs"; the per-pass total is what agrees with the bench.
+    trace_passes = 7
+    stats = {}
+    for r in csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_stats.csv"))):
+        k = r["Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]
+        k = k.split("<")[0]
+        if k.startswith("k_") and k != "k_probagen":
+            a = stats.setdefault(k, [0, 0.0, 0.0])
+            a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"]); a[2] = max(a[2], float(r["MaxNs"]))
+    lines += ["", "Kernel trace (`%s_kernel_stats.csv`, %d passes): per-pass totals = what `bench.py` reports per step." % (tag, trace_passes), "",
+              "| kernel (all template instances) | calls | calls per pass | ms per pass | longest launch ms |", "|---|---|---|---|---|"]
+    for k in sorted(stats, key=lambda k: -stats[k][1]):
+        c, tot, mx = stats[k]
+        lines.append("| %s | %d | %.1f | %.3f | %.3f |" % (k, c, c / trace_passes, tot / trace_passes / 1e6, mx / 1e6))
     open("profiles/%s_pmc.md" % tag, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
