@@ -12,14 +12,17 @@ every block is independent, programs/bench.c:353-364).  The other configurations
 the same JSON line:
     cfg3_p80_fse        configs[2]  Proba80, FSE
     cfg4_p14_huf        configs[3]  Proba14, Huff0 4-stream
-    cfg5_mixed_shard    configs[4]  mixed {P02,P14,P80} (block g: P[g mod 3], seed g+1), FSE + Huff0 on every block,
-                                    125k blocks per rank (1M on 8 GPUs); for N>1 both the compute-only time (every rank
-                                    generates its shard) and the with-comm time (rank 0 holds the corpus: RCCL scatter,
-                                    code, RCCL gather) are reported
+    cfg5_mixed_1M       configs[4] AS NAMED: the fixed 1M-block mixed {P02,P14,P80} corpus (block g: P[g mod 3], seed g+1),
+                                    FSE + Huff0 on every block, rank r codes shard_range(1M, r, N) -> "scaling": "strong"
+                                    (N = 1: the whole corpus on one GPU).  Compute-only (every rank generates its shard) and,
+                                    for N > 1, with-comm (rank 0 holds the corpus: grouped RCCL scatter, code, grouped RCCL
+                                    gather; communicators warmed by one untimed pass, then >= 3 timed passes)
+    cfg5_mixed_shard    the same mix at 125k blocks per rank whatever N ("scaling": "weak"; 1M blocks on 8 GPUs)
     fse_tl12 / huf_tl12 the tableLog `fse -b` asks for (programs/bench.c:113)
     fse_maxlog11        the headline decoded with the FSE_decompress_wksp(maxLog = 11) hint
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE in the environment: bench.py starts the
+                                                            N ranks itself through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `value` = uncompressed MiB that went through encode AND decode per second
@@ -60,13 +63,36 @@ def parse():
     ap.add_argument("--table-log", type=int, default=11)
     ap.add_argument("--max-log", type=int, default=12, help="FSE decode limit: 12 = FSE_decompress (lib/fse_decompress.c:279-283)")
     ap.add_argument("--no-configs", action="store_true", help="headline only (skip configs 3/4/5 and the tableLog-12 variants)")
-    ap.add_argument("--config-steps", type=int, default=3)
-    ap.add_argument("--cfg5-blocks", type=int, default=125000, help="blocks per GPU of config 5 (1M / 8)")
+    ap.add_argument("--configs", default="", help="comma-separated subset of the `configs` keys to run (default: all)")
+    ap.add_argument("--config-steps", type=int, default=0, help="steps of the `configs` entries (0 = the headline's --steps / --warmup)")
+    ap.add_argument("--cfg5-blocks", type=int, default=125000, help="blocks per GPU of the weak-scaling config-5 record (1M / 8)")
+    ap.add_argument("--cfg5-total", type=int, default=1000000, help="blocks of the fixed config-5 corpus (strong scaling; BASELINE configs[4])")
+    ap.add_argument("--comm-passes", type=int, default=3, help="timed passes of the with-comm variant (after one untimed pass)")
     ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
+    ap.add_argument("--parity-blocks", type=int, default=8192, help="strided blocks whose encoder bytes are compared with the CPU reference (untimed)")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pinned-host H2D + kernels + D2H figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=32768)
     ap.add_argument("--cpu-seconds", type=float, default=1.0, help="minimum timed seconds per direction and repetition")
     return ap.parse_args()
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    (one rank per GPU, rendezvous on 127.0.0.1).  Under a launcher the world it made must be the one asked for."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            sys.exit("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def host_threads():
@@ -151,7 +177,7 @@ class Codec:
             self.hip.huf_decompress_batch(self.dst, self.res, BLOCK, dst=self.out, results=self.dres, workspace=self.ws_d)
 
 
-def check_parity(cd, rank, n_check=1024):
+def check_parity(cd, rank, n_check=8192):
     """untimed gates: round trip on every block; encoder bytes and return values against the compiled reference (or the
     oracle when oracle/_ref is absent) on a strided sample across the whole batch"""
     nb = cd.src.shape[0]
@@ -167,7 +193,7 @@ def check_parity(cd, rank, n_check=1024):
         return parity + "(checker unavailable)"
     idx = torch.arange(0, nb, max(1, nb // n_check), device=cd.src.device)[:n_check]
     host = cd.src[idx].cpu().numpy()
-    _, ores, odst = lib.compress_batch(0 if cd.name == "fse" else 1, host, table_log=cd.tl)
+    _, ores, odst = lib.compress_batch(0 if cd.name == "fse" else 1, host, table_log=cd.tl, nthreads=host_threads())
     rh, dh = cd.res[idx].cpu().numpy(), cd.dst[idx].cpu().numpy()
     assert (rh == ores.astype(np.int64)).all(), "%s encode sizes differ from the CPU %s" % (cd.name, lib.kind)
     for b in range(len(rh)):
@@ -228,14 +254,14 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
                         "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
 
 
-def run_case(hip, codecs, steps, warmup, barrier, rank, check=True):
-    """time `steps` steps (each: encode + decode of every codec in `codecs`), bracketed by barrier + synchronize.
-    Returns the raw timings of this rank and the per-kernel probe."""
+def run_case(hip, codecs, steps, warmup, barrier, rank, check=True, n_check=8192):
+    """time `steps` steps (each: encode + decode of every codec in `codecs`), bracketed by barrier + synchronize, with the
+    kernel probe OFF; then the same steps once more with every launch of the library bracketed by HIP events on its stream
+    (FSEHIP_probe_*) for the per-kernel table and the roofline.  Returns the raw timings of this rank and the per-kernel probe."""
     for _ in range(warmup):
         for cd in codecs:
             cd.encode(); cd.decode()
     barrier()
-    hip.lib.FSEHIP_probe_begin()
     nev = 2 * len(codecs) * steps + 1
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     t0 = time.perf_counter()
@@ -247,6 +273,14 @@ def run_case(hip, codecs, steps, warmup, barrier, rank, check=True):
             cd.decode(); ev[k].record(); k += 1
     barrier()
     elapsed = time.perf_counter() - t0
+    # probe pass (not part of `value`)
+    hip.lib.FSEHIP_probe_begin()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        for cd in codecs:
+            cd.encode(); cd.decode()
+    barrier()
+    probe_elapsed = time.perf_counter() - t1
     ms = (C.c_double * 16)(); launches = (C.c_uint * 16)()
     hip.lib.FSEHIP_probe_collect(ms, launches)
     enc_s = {cd.name: 0.0 for cd in codecs}; dec_s = {cd.name: 0.0 for cd in codecs}
@@ -256,12 +290,108 @@ def run_case(hip, codecs, steps, warmup, barrier, rank, check=True):
             enc_s[cd.name] += ev[k - 1].elapsed_time(ev[k]) / 1e3; k += 1
             dec_s[cd.name] += ev[k - 1].elapsed_time(ev[k]) / 1e3; k += 1
     per = {KERNEL_NAMES[i]: (ms[i], launches[i]) for i in range(len(KERNEL_NAMES)) if launches[i]}
-    out = {"elapsed": elapsed, "enc_s": enc_s, "dec_s": dec_s, "per": per, "parity": {}, "csize": {}}
+    out = {"elapsed": elapsed, "probe_elapsed": probe_elapsed, "enc_s": enc_s, "dec_s": dec_s, "per": per, "parity": {}, "csize": {}}
     for cd in codecs:
         out["csize"][cd.name] = float(cd.res.sum().item()) / cd.src.shape[0]
         if check:
-            out["parity"][cd.name] = check_parity(cd, rank)
+            out["parity"][cd.name] = check_parity(cd, rank, n_check)
     return out
+
+
+def host_inclusive(hip, cd, chunks=8):
+    """SURVEY 8(d) "report kernel-only and end-to-end (incl. H2D/D2H) separately" (protocol: programs/bench.c:349-371 times the
+    call on host buffers): the headline batch with source and results in PINNED host memory -- per chunk H2D, the batched
+    one-shot call, D2H of the fixed-stride result slots and sizes -- chunks pipelined over three streams (copy engines of both
+    directions and the kernels overlap).  Never `value`."""
+    nb = cd.src.shape[0]
+    try:
+        h_src = torch.empty((nb, BLOCK), dtype=torch.uint8, pin_memory=True)
+        h_cmp = torch.empty((nb, cd.cap), dtype=torch.uint8, pin_memory=True)
+        h_res = torch.empty(nb, dtype=torch.int64, pin_memory=True)
+        h_out = torch.empty((nb, BLOCK), dtype=torch.uint8, pin_memory=True)
+    except RuntimeError as e:
+        return {"error": "pinned host allocation failed: %r" % (e,)}
+    h_src.copy_(cd.src); torch.cuda.synchronize()
+    dev = cd.src.device
+    d_src, d_cmp, d_res, d_out, d_dres = torch.empty_like(cd.src), cd.dst, cd.res, cd.out, cd.dres
+    s_in, s_k, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    edges = [nb * i // chunks for i in range(chunks + 1)]
+
+    def pipeline(stage_in, kernels, stage_out):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(chunks):
+            lo, hi = edges[i], edges[i + 1]
+            with torch.cuda.stream(s_in):
+                stage_in(lo, hi); e1 = torch.cuda.Event(); e1.record()
+            with torch.cuda.stream(s_k):
+                s_k.wait_event(e1); kernels(lo, hi); e2 = torch.cuda.Event(); e2.record()
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(e2); stage_out(lo, hi)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def enc_in(lo, hi): d_src[lo:hi].copy_(h_src[lo:hi], non_blocking=True)
+    def enc_out(lo, hi): h_cmp[lo:hi].copy_(d_cmp[lo:hi], non_blocking=True); h_res[lo:hi].copy_(d_res[lo:hi], non_blocking=True)
+    def dec_in(lo, hi): d_cmp[lo:hi].copy_(h_cmp[lo:hi], non_blocking=True); d_res[lo:hi].copy_(h_res[lo:hi], non_blocking=True)
+    def dec_out(lo, hi): h_out[lo:hi].copy_(d_out[lo:hi], non_blocking=True)
+    if cd.name == "fse":
+        def enc_k(lo, hi): hip.fse_compress_batch(d_src[lo:hi], cd.tl, dst=d_cmp[lo:hi], results=d_res[lo:hi], workspace=cd.ws_c)
+        def dec_k(lo, hi): hip.fse_decompress_batch(d_cmp[lo:hi], d_res[lo:hi], BLOCK, max_log=cd.max_log, dst=d_out[lo:hi], results=d_dres[lo:hi], workspace=cd.ws_d)
+    else:
+        def enc_k(lo, hi): hip.huf_compress_batch(d_src[lo:hi], cd.tl, dst=d_cmp[lo:hi], results=d_res[lo:hi], workspace=cd.ws_c)
+        def dec_k(lo, hi): hip.huf_decompress_batch(d_cmp[lo:hi], d_res[lo:hi], BLOCK, dst=d_out[lo:hi], results=d_dres[lo:hi], workspace=cd.ws_d)
+    best_e = best_d = None
+    for _ in range(3):
+        te = pipeline(enc_in, enc_k, enc_out)
+        td = pipeline(dec_in, dec_k, dec_out)
+        best_e = te if best_e is None else min(best_e, te); best_d = td if best_d is None else min(best_d, td)
+    ok = bool((h_out == h_src).all()) and bool((h_res > 1).all())
+    total = nb * BLOCK
+    used = float(h_res.sum().item())
+    return {"encode_GBps": round(total / best_e / 1e9, 2), "decode_GBps": round(total / best_d / 1e9, 2),
+            "value": round(total / 2.0 ** 20 / (best_e + best_d), 1), "unit": "MiB/s of uncompressed data, host buffer to host buffer",
+            "encode_ms": round(best_e * 1e3, 2), "decode_ms": round(best_d * 1e3, 2), "roundtrip_ok": ok,
+            "pcie_bytes": {"encode": total + nb * (cd.cap + 8), "decode": nb * (cd.cap + 8) + total, "compressed_bytes_used": used},
+            "what": "%d blocks in pinned host memory, %d chunks pipelined over three streams: H2D, %s_compress2 / %s_decompress batch call, D2H of "
+                    "the fixed-stride result slots (%d B per block, as programs/bench.c:514-516 sizes them) and sizes; best of 3"
+                    % (nb, chunks, cd.name.upper(), cd.name.upper(), cd.cap)}
+
+
+def secondary_roofline(hip, cd, dev_info):
+    """The bound that actually holds for k_fse_decode: blocks resident per CU (LDS capacity) x one 4-symbol iteration
+    of the chain per T cycles.  T is measured by the kernel's own cycle counters (s_memtime in the decoder wave around every phase of
+    16 iterations; one extra, untimed decode pass with the counters switched on), the model rate follows from it, and achieved / model
+    says how much is lost outside the chain (tail of the last round of workgroups, set-up and literal tails, waits on the service waves)."""
+    L = hip.lib
+    if not hasattr(L, "FSEHIP_debug_decodeTiming"):
+        return None
+    buf = (C.c_ulonglong * 16)()
+    L.FSEHIP_debug_decodeTiming(1, None)
+    cd.decode(); torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); cd.decode(); ev1.record(); torch.cuda.synchronize()
+    L.FSEHIP_debug_decodeTiming(0, buf)
+    t_run, t_wait, n_run, n_wait, n_wg, s_busy, s_idle, n_srv, clock_khz, blocks_per_wg, wgs_per_cu = [int(buf[i]) for i in range(11)]
+    if n_run == 0:
+        return None
+    nb = cd.src.shape[0]
+    cyc_iter = t_run / (n_run * 16.0)
+    cus = dev_info["cus"]
+    resident = blocks_per_wg * wgs_per_cu
+    clock = clock_khz * 1e3
+    model_blocks_per_s = cus * resident / (BLOCK / 4.0 * cyc_iter / clock)
+    ms_timed = ev0.elapsed_time(ev1)
+    achieved = nb / (ms_timed * 1e-3)
+    return {"bound": "chain latency x LDS-resident blocks", "kernel": "k_fse_decode",
+            "resident_blocks_per_cu": resident, "cycles_per_iteration": round(cyc_iter, 1), "symbols_per_iteration": 4,
+            "decoder_wave_wait_frac": round(t_wait / max(t_run + t_wait, 1), 4),
+            "service_wave_busy_frac": round(s_busy / max(s_busy + s_idle, 1), 4),
+            "clock_GHz": round(clock / 1e9, 3),
+            "model_GBps": round(model_blocks_per_s * BLOCK / 1e9, 1), "achieved_GBps": round(achieved * BLOCK / 1e9, 1),
+            "frac": round(achieved / model_blocks_per_s, 4),
+            "note": "model = CUs x resident blocks x 4 symbols / cycles_per_iteration x clock (output bytes); measured with the in-kernel counters on "
+                    "(pass of %.2f ms; they cost a few per cent), clock = the device's maximum engine clock" % ms_timed}
 
 
 def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
@@ -293,13 +423,13 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     return out
 
 
-def summarize(r, codecs, nb, steps, world, reduce_max):
+def summarize(r, codecs, nb, steps, world, reduce_max, total_blocks=None):
     """per-configuration record from the raw timings (max over ranks)"""
     names = [cd.name for cd in codecs]
     vals = [r["elapsed"]] + [r["enc_s"][n] for n in names] + [r["dec_s"][n] for n in names]
     vals = reduce_max(vals)
     elapsed = vals[0]
-    total_bytes = world * nb * BLOCK * steps
+    total_bytes = (total_blocks if total_blocks is not None else world * nb) * BLOCK * steps       # strong scaling: the shards add up to the corpus
     rec = {"value": round(total_bytes / 2.0 ** 20 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "blocks_per_gpu": nb}
     for i, n in enumerate(names):
         rec["%s_encode_GBps" % n] = round(total_bytes / vals[1 + i] / 1e9, 2)
@@ -315,10 +445,11 @@ def summarize(r, codecs, nb, steps, world, reduce_max):
 
 def main():
     args = parse()
+    launch_ranks_if_needed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # (FSEHIP_BENCH_BACKEND=gloo lets several ranks share one GPU for a smoke test of the N>1 path; the driver's runs use RCCL)
+    # (FSEHIP_BENCH_BACKEND=gloo lets several ranks share one GPU for a test of the N>1 path; the driver's runs use RCCL)
     backend = os.environ.get("FSEHIP_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
@@ -334,6 +465,7 @@ def main():
     from finitestateentropy_amd.api import FseHip, fse_compress_bound, huf_compress_bound
     hip = FseHip()
     dev = torch.device("cuda", local_rank)
+    sharing = max(1, (world + max(torch.cuda.device_count(), 1) - 1) // max(torch.cuda.device_count(), 1))   # ranks per GPU (1 under the driver)
 
     def barrier():
         torch.cuda.synchronize()
@@ -344,12 +476,38 @@ def main():
     def reduce_max(values):
         return shard.max_over_ranks(values, dev, world)
 
+    wanted = set(k for k in args.configs.split(",") if k)
+
+    def want(key):
+        return not args.no_configs and (not wanted or key in wanted)
+
     nb = args.blocks
-    nmax = nb if args.no_configs else max(nb, args.cfg5_blocks)
+    cs = args.config_steps or args.steps
+    cw = 1 if args.config_steps else args.warmup
+    per_block_pool = {"fse": fse_compress_bound(BLOCK) + 8 + BLOCK + 8, "huf": huf_compress_bound(BLOCK) + 8 + BLOCK + 8}
+    pool_codecs = ("fse", "huf") if (args.codec == "both" or not args.no_configs) else (args.codec,)
+    per_block = BLOCK + sum(per_block_pool[n] for n in pool_codecs)
+    # config 5 as named: the corpus is fixed, rank r codes shard_range(total, r, world).  Everything of a rank's shard stays resident
+    # (source, both codecs' slots, both outputs: 165 KB per block -> 165 GB for the whole corpus on one GPU of 288 GB); if the
+    # device cannot hold that (ranks sharing a GPU in a test, a smaller part) the corpus is cut and the record says so.
+    lo5, hi5 = shard.shard_range(args.cfg5_total, rank, world)
+    n5s = hi5 - lo5
+    corpus_note = None
+    if want("cfg5_mixed_1M"):
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        budget = int(free_b * 0.70 / sharing) - (8 << 30)
+        fit = max(budget // per_block, 1024)
+        fit = int(reduce_max([-float(fit)])[0] * -1)                      # the smallest budget of all ranks
+        if n5s > fit:
+            total_fit = fit * world
+            corpus_note = "corpus cut from %d to %d blocks: %d blocks per rank is what fits the device memory free at start" % (args.cfg5_total, total_fit, fit)
+            args.cfg5_total = total_fit
+            lo5, hi5 = shard.shard_range(args.cfg5_total, rank, world)
+            n5s = hi5 - lo5
+    nmax = max([nb] + ([args.cfg5_blocks] if want("cfg5_mixed_shard") else []) + ([n5s] if want("cfg5_mixed_1M") else []))
     # device pools shared by every configuration (views are taken per case)
     pools = {}
-    want = ("fse", "huf") if (args.codec == "both" or not args.no_configs) else (args.codec,)
-    for n in want:
+    for n in pool_codecs:
         cap = fse_compress_bound(BLOCK) if n == "fse" else huf_compress_bound(BLOCK)
         pools["dst_" + n] = torch.empty(nmax * cap, dtype=torch.uint8, device=dev)
         pools["res_" + n] = torch.empty(nmax, dtype=torch.int64, device=dev)
@@ -358,10 +516,10 @@ def main():
     srcpool = torch.empty(nmax * BLOCK, dtype=torch.uint8, device=dev)
 
     def gen(proba, n, first_block):
-        """rank-local shard of the conceptual global corpus: global block g = first_block + row, seed g + 1"""
+        """rank-local shard of the conceptual global corpus, generated in place: global block g = first_block + row, seed g + 1"""
         view = srcpool[:n * BLOCK].view(n, BLOCK)
         if proba == "mixed":
-            view.copy_(hip.probagen_mixed(MIX, n, BLOCK, first_block=first_block, device=dev))
+            hip.probagen_mixed(MIX, n, BLOCK, first_block=first_block, out=view)
         else:
             hip.probagen_batch(proba, n, BLOCK, first_seed=1 + first_block, out=view)
         return view
@@ -371,11 +529,26 @@ def main():
     src = gen(head_proba, nb, rank * nb)
     head_names = ("fse", "huf") if args.codec == "both" else (args.codec,)
     codecs = [Codec(hip, n, src, pools, args.table_log, args.max_log) for n in head_names]
-    r = run_case(hip, codecs, args.steps, args.warmup, barrier, rank)
+    r = run_case(hip, codecs, args.steps, args.warmup, barrier, rank, n_check=args.parity_blocks)
     head, vals = summarize(r, codecs, nb, args.steps, world, reduce_max)
     elapsed = vals[0]
     dom_codec = max(head_names, key=lambda n: max(r["per"].get(k, (0, 0))[0] for k in HOT[n]))
     head_roof = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, args.steps, traffic_tag="")
+    head_roof["measured_over"] = ("%d steps repeated with the event probe on, directly after the timed region (%.3f ms per step with the probe, %.3f without)"
+                                  % (args.steps, r["probe_elapsed"] / args.steps * 1e3, r["elapsed"] / args.steps * 1e3))
+    if rank == 0 and dom_codec == "fse":
+        try:
+            sec = secondary_roofline(hip, codecs[head_names.index("fse")], hip.device_info())
+            if sec:
+                head_roof["secondary"] = sec
+        except Exception as e:
+            head_roof["secondary"] = {"error": repr(e)}
+    host_inc = None
+    if world == 1 and not args.no_host_inclusive and head_proba != "mixed":
+        try:
+            host_inc = host_inclusive(hip, codecs[0])
+        except Exception as e:
+            host_inc = {"error": repr(e)}
     cpu_sample = None
     if world == 1 and not args.no_cpu_baseline and head_proba != "mixed":
         cpu_sample = src[:min(args.cpu_sample_blocks, nb)].cpu().numpy()
@@ -383,47 +556,50 @@ def main():
 
     configs = {}
     if not args.no_configs:
-        cs = args.config_steps
 
-        def case(key, proba, names, n, table_log=args.table_log, max_log=args.max_log, desc=""):
-            s = gen(proba, n, rank * n)
+        def case(key, proba, names, n, first_block, table_log=args.table_log, max_log=args.max_log, desc="", total=None):
+            s = gen(proba, n, first_block)
             cds = [Codec(hip, nm, s, pools, table_log, max_log) for nm in names]
-            rr = run_case(hip, cds, cs, 1, barrier, rank)
-            rec, _ = summarize(rr, cds, n, cs, world, reduce_max)
+            rr = run_case(hip, cds, cs, cw, barrier, rank, n_check=args.parity_blocks)
+            rec, _ = summarize(rr, cds, n, cs, world, reduce_max, total_blocks=total)
             rec["workload"] = desc
             configs[key] = rec
             return s, cds
 
-        case("fse_maxlog11", args.proba, ("fse",), nb, max_log=max(args.table_log, 9),
-             desc="headline workload decoded with FSE_decompress_wksp(maxLog = 11) (caller promises tableLog <= 11)")
-        case("cfg3_p80_fse", 80, ("fse",), nb, desc="BASELINE configs[2]: probagen Proba80, %d x 32KB blocks per GPU, FSE encode+decode" % nb)
-        case("cfg4_p14_huf", 14, ("huf",), nb, desc="BASELINE configs[3]: probagen Proba14, %d x 32KB blocks per GPU, Huff0 4-stream encode + HUF_decompress" % nb)
-        case("fse_tl12", 14, ("fse",), nb, table_log=12, desc="Proba14, FSE with tableLog 12 (what `fse -b` requests, programs/bench.c:113)")
-        case("huf_tl12", 2, ("huf",), nb, table_log=12, desc="Proba02 (256 symbols), Huff0 with tableLog 12 (HUF_TABLELOG_MAX)")
-        n5 = args.cfg5_blocks
-        s5, cds5 = case("cfg5_mixed_shard", "mixed", ("fse", "huf"), n5,
-                        desc="BASELINE configs[4]: probagen mixed {P02,P14,P80} (block g: P[g mod 3], seed g+1), %d x 32KB blocks per GPU "
-                             "(%d in all), FSE and Huff0 round trip of every block, sharded by contiguous block ranges; compute-only "
-                             "(each rank generates its shard, no collective)" % (n5, n5 * world))
-        configs["cfg5_mixed_shard"]["value_note"] = "value counts each block once per step although it goes through both codecs"
-        if world > 1:
-            # with-comm variant: rank 0 holds the whole corpus; RCCL scatter of the raw blocks, FSE + Huff0 round trip on every rank,
-            # RCCL gather of the compressed slots and sizes of both codecs (finitestateentropy_amd/shard.py, star over xGMI)
-            n_total = n5 * world
-            corpus = hip.probagen_mixed(MIX, n_total, BLOCK, first_block=0, device=dev) if rank == 0 else None
-            barrier()
-            t0 = time.perf_counter()
-            mine, gathered = shard.sharded_codec_job(corpus, n_total, BLOCK, rank, world, dev, cds5)
-            barrier()
-            t_comm = reduce_max([time.perf_counter() - t0])[0]
-            ok = shard.sharded_job_ok(mine, gathered, cds5, n_total, BLOCK, rank, world)
-            configs["cfg5_mixed_shard"]["with_comm"] = {
-                "value": round(n_total * BLOCK / 2.0 ** 20 / t_comm, 1), "ms": round(t_comm * 1e3, 2), "roundtrip_ok": bool(ok),
-                "what": "rank 0 holds %d blocks: scatter (point-to-point per peer) + FSE and Huff0 encode+decode + gather of both "
-                        "codecs' fixed-stride compressed slots and sizes; one pass, untimed warm-up = the compute-only run above" % n_total}
-            del corpus, gathered
-        del s5, cds5
-        if hasattr(hip, "fse_compress_u16_batch"):
+        if want("fse_maxlog11"):
+            case("fse_maxlog11", args.proba, ("fse",), nb, rank * nb, max_log=max(args.table_log, 9),
+                 desc="headline workload decoded with FSE_decompress_wksp(maxLog = 11) (caller promises tableLog <= 11)")
+        if want("cfg3_p80_fse"):
+            case("cfg3_p80_fse", 80, ("fse",), nb, rank * nb, desc="BASELINE configs[2]: probagen Proba80, %d x 32KB blocks per GPU, FSE encode+decode" % nb)
+        if want("cfg4_p14_huf"):
+            case("cfg4_p14_huf", 14, ("huf",), nb, rank * nb, desc="BASELINE configs[3]: probagen Proba14, %d x 32KB blocks per GPU, Huff0 4-stream encode + HUF_decompress" % nb)
+        if want("fse_tl12"):
+            case("fse_tl12", 14, ("fse",), nb, rank * nb, table_log=12, desc="Proba14, FSE with tableLog 12 (what `fse -b` requests, programs/bench.c:113)")
+        if want("huf_tl12"):
+            case("huf_tl12", 2, ("huf",), nb, rank * nb, table_log=12, desc="Proba02 (256 symbols), Huff0 with tableLog 12 (HUF_TABLELOG_MAX)")
+        if want("cfg5_mixed_shard"):
+            n5 = args.cfg5_blocks
+            s5, cds5 = case("cfg5_mixed_shard", "mixed", ("fse", "huf"), n5, rank * n5,
+                            desc="BASELINE configs[4]'s mix at a fixed %d x 32KB blocks per GPU (%d in all): probagen mixed {P02,P14,P80} (block g: P[g mod 3], "
+                                 "seed g+1), FSE and Huff0 round trip of every block, contiguous block ranges, no collective" % (n5, n5 * world))
+            configs["cfg5_mixed_shard"]["scaling"] = "weak"
+            configs["cfg5_mixed_shard"]["value_note"] = "value counts each block once per step although it goes through both codecs"
+            del s5, cds5
+        if want("cfg5_mixed_1M"):
+            total = args.cfg5_total
+            s5, cds5 = case("cfg5_mixed_1M", "mixed", ("fse", "huf"), n5s, lo5, total=total,
+                            desc="BASELINE configs[4] as named: probagen mixed {P02,P14,P80} (block g: P[g mod 3], seed g+1), %d x 32KB blocks in all, "
+                                 "FSE and Huff0 round trip of every block, rank r codes shard_range(%d, r, %d) (this run: %d blocks per GPU); compute-only "
+                                 "(each rank generates its shard, no collective)" % (total, total, world, n5s))
+            rec5 = configs["cfg5_mixed_1M"]
+            rec5["scaling"] = "strong"; rec5["corpus_blocks"] = total
+            rec5["value_note"] = "value counts each block once per step although it goes through both codecs"
+            if corpus_note:
+                rec5["corpus_note"] = corpus_note
+            if world > 1:
+                rec5["with_comm"] = with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, barrier, reduce_max, sharing)
+            del s5, cds5
+        if want("fse_u16") and hasattr(hip, "fse_compress_u16_batch"):
             configs["fse_u16"] = u16_case(hip, dev, args.u16_blocks, cs, barrier, reduce_max, world, rank)
 
     if rank != 0:
@@ -449,6 +625,8 @@ def main():
     if len(head_names) > 1:
         for n in head_names[1:]:
             line["%s_encode_GBps" % n] = head["%s_encode_GBps" % n]; line["%s_decode_GBps" % n] = head["%s_decode_GBps" % n]
+    if host_inc is not None:
+        line["host_inclusive"] = host_inc
     if configs:
         line["configs"] = configs
     if cpu_sample is not None:
@@ -457,8 +635,70 @@ def main():
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
             line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": host_threads(), "kind": "unavailable", "sample": repr(e)}
     print(json.dumps(line))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, barrier, reduce_max, sharing):
+    """config 5 with the corpus on ONE rank (north_star: "RCCL broadcast/gather over xGMI only for the block scatter/gather"): rank 0
+    holds the `total` blocks; grouped scatter of the raw blocks, FSE + Huff0 round trip of every rank's shard, grouped gather of
+    both codecs' fixed-stride compressed slots and sizes (finitestateentropy_amd/shard.py: one ncclGroup per direction, a star
+    over the root's xGMI links).  One untimed pass first (RCCL creates its communicators and channels on first use), then
+    `--comm-passes` timed passes, each bracketed by barriers, max over ranks."""
+    lo, hi = shard.shard_range(total, rank, world)
+    n = hi - lo
+    corpus, gather_out = None, None
+    need = total * (BLOCK + sum(cd.cap + 8 for cd in cds5))
+    ok_mem = True
+    if rank == 0:
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        ok_mem = need < free_b * 0.85 / sharing
+    ok_mem = reduce_max([0.0 if ok_mem else 1.0])[0] == 0.0
+    if not ok_mem:
+        return {"value": None, "error": "the root cannot hold the corpus and the gathered slots (%d bytes) beside its shard" % need}
+    if rank == 0:
+        corpus = torch.empty((total, BLOCK), dtype=torch.uint8, device=dev)
+        hip.probagen_mixed(MIX, total, BLOCK, first_block=0, out=corpus)
+        gather_out = [(torch.empty((total, cd.cap), dtype=torch.uint8, device=dev), torch.empty(total, dtype=torch.int64, device=dev)) for cd in cds5]
+    shard_out = srcpool[:n * BLOCK].view(n, BLOCK)
+    times, phases = [], []
+    ok = True
+    for p in range(args.comm_passes + 1):
+        marks = []
+
+        def mark(name):
+            torch.cuda.synchronize(); marks.append((name, time.perf_counter()))
+        barrier()
+        t0 = time.perf_counter()
+        mine, gathered = shard.sharded_codec_job(corpus, total, BLOCK, rank, world, dev, cds5, shard_out=shard_out, gather_out=gather_out, mark=mark)
+        barrier()
+        t = reduce_max([time.perf_counter() - t0])[0]
+        if p == 0:
+            ok = shard.sharded_job_ok(mine, gathered, cds5, total, BLOCK, rank, world)
+            continue
+        times.append(t)
+        prev = t0; ph = {}
+        for name, tm in marks:
+            ph[name] = tm - prev; prev = tm
+        keys = sorted(ph)
+        mx = reduce_max([ph[k] for k in keys])
+        phases.append(dict(zip(keys, mx)))
+    okv = reduce_max([0.0 if ok else 1.0])[0] == 0.0
+    mean = sum(times) / len(times)
+    avg_ph = {k: round(sum(p_[k] for p_ in phases) / len(phases) * 1e3, 2) for k in phases[0]}
+    scatter_bytes = (total - n) * BLOCK if rank == 0 else 0
+    gather_bytes = (total - n) * sum(cd.cap + 8 for cd in cds5) if rank == 0 else 0
+    rec = {"value": round(total * BLOCK / 2.0 ** 20 / mean, 1), "unit": "MiB/s of uncompressed data (each block counted once; it goes through both codecs)",
+           "ms": round(mean * 1e3, 2), "best_ms": round(min(times) * 1e3, 2), "passes": len(times), "roundtrip_ok": bool(okv),
+           "phase_ms": avg_ph,
+           "root_link_GBps": {"scatter": round(scatter_bytes / max(avg_ph.get("1_scatter", 0) * 1e-3, 1e-9) / 1e9, 1) if scatter_bytes else None,
+                              "gather": round(gather_bytes / max(avg_ph.get("3_gather", 0) * 1e-3, 1e-9) / 1e9, 1) if gather_bytes else None},
+           "what": "rank 0 holds %d blocks: grouped scatter (one transfer per peer) + FSE and Huff0 encode+decode of every shard + grouped gather of both "
+                   "codecs' fixed-stride compressed slots and sizes; 1 untimed pass (communicator set-up), then %d timed passes; value from their mean; "
+                   "phase_ms = max over ranks of each phase, measured with a device synchronize between phases" % (total, len(times))}
+    del corpus, gather_out
+    return rec
 
 
 if __name__ == "__main__":

@@ -106,10 +106,11 @@ class FseHip:
                                                  table.ctypes.data_as(VP), C.c_uint32(first_seed & 0xFFFFFFFF), C.c_uint32(seed_step), _stream()), "probagen_batch")
         return out
 
-    def probagen_mixed(self, probas, n_blocks, block_size=32768, first_block=0, device="cuda"):
+    def probagen_mixed(self, probas, n_blocks, block_size=32768, first_block=0, device="cuda", out=None):
         """BASELINE config 5 corpus: global block g (= first_block + row) is drawn from distribution probas[g mod len(probas)]
-        with seed g + 1 -- one strided generator call per distribution."""
-        out = torch.empty((n_blocks, block_size), dtype=torch.uint8, device=device)
+        with seed g + 1 -- one strided generator call per distribution (into `out` if given)."""
+        if out is None:
+            out = torch.empty((n_blocks, block_size), dtype=torch.uint8, device=device)
         k = len(probas)
         for j in range(k):
             r0 = (j - first_block) % k                       # first row whose global index is congruent to j
@@ -272,6 +273,19 @@ def _huf_methods():
                "HUF_compress4X_usingCTable_batch")
         return dst, res
 
+    def huf_compress1x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
+        """HUF_compress1X_usingCTable over a batch (lib/huf.h:290): one stream per block"""
+        n = _blocks(src, "src").shape[0]
+        cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
+        stride = 0 if shared_table else ctables.stride(0)
+        _check(self.lib.FSEHIP_HUF_compress1X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
+                                                                ps, uni, _ptr(ctables), SZ(stride), SZ(n), _stream()),
+               "HUF_compress1X_usingCTable_batch")
+        return dst, res
+
     def huf_decompress4x_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
         """HUF_decompress4X_usingDTable over a batch: X1 (tableType 0) and X2 (tableType 1) tables, chosen per block"""
         return self.huf_decompress4x1_using_dtable_batch(csrc, csizes, dtables, dst_sizes, max_table_log, shared_table, _fn="FSEHIP_HUF_decompress4X_usingDTable_batch")
@@ -311,7 +325,7 @@ def _huf_methods():
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_HUF_decompress4X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
 
-    for f in (huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch,
+    for f in (huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
               huf_decompress4x1_using_dtable_batch, huf_decompress4x_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
               huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable):
         setattr(FseHip, f.__name__, f)

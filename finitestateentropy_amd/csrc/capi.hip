@@ -180,7 +180,8 @@ extern "C" int FSEHIP_probagen_batch_ex(void* d_dst, size_t dstStride, size_t bl
 // block b (include/fsehip.h): the batch call itself still succeeds.
 //   mode 0 (FSE_compress2, lib/fse_compress.c:691): every block gets `code`;
 //   mode 1 (HUF_compress_internal, lib/huf_compress.c:654-660): srcSize 0 or dstCapacity 0 -> 0, srcSize > HUF_BLOCKSIZE_MAX ->
-//          srcSize_wrong come first, then `code`.
+//          srcSize_wrong come first, then `code`;
+//   mode 2 (FSE_compress_wksp, lib/fse_compress.c:646-650): srcSize <= 1 -> 0 comes first, then `code`.
 __global__ void k_batch_arg_error(size_t* results, const size_t* sizes, size_t uniform, size_t dstCapacity, size_t nBlocks, size_t code, int mode)
 {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,6 +192,7 @@ __global__ void k_batch_arg_error(size_t* results, const size_t* sizes, size_t u
         if (n == 0 || dstCapacity == 0) r = 0;
         else if (n > FSEHIP_HUF_BLOCKSIZE_MAX) r = FERR(srcSize_wrong);
     }
+    if (mode == 2) { const size_t n = sizes ? sizes[b] : uniform; if (n <= 1) r = 0; }
     results[b] = r;
 }
 static int batch_arg_error(size_t* d_results, const size_t* d_sizes, size_t uniform, size_t dstCapacity, size_t nBlocks, size_t code, int mode, hipStream_t s)
@@ -256,7 +258,7 @@ static FseCWs fse_cws(unsigned tableLog)
     w.maxTl = tl;
     w.ctU32 = FSEHIP_FSE_CTABLE_SIZE_U32(tl, 255);
     w.ts = (size_t)1 << tl;
-    w.perBlock = 1024 + 4 + 8 + sizeof(FseMeta) + 4 * w.ctU32 + w.ts + FSE_EBINS * sizeof(u32);
+    w.perBlock = 1024 + 4 + 8 + sizeof(FseMeta) + 4 * w.ctU32 + FSE_EBINS * sizeof(u32);
     return w;
 }
 #define WS_SLACK 2048
@@ -285,12 +287,23 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     if (nBlocks == 0) return 0;
     if (tableLog > FSEHIP_FSE_MAX_TABLELOG)                                       // FSE_compress2 -> tableLog_tooLarge for every block (fse_compress.c:691)
         return batch_arg_error(d_results, nullptr, 0, dstCapacity, nBlocks, FSEHIP_ERROR(tableLog_tooLarge), 0, s);
+    if (maxSymbolValue > 255 && tableLog != 0) {
+        // FSE_compress2 carves its histogram scratch out of a fixed workspace behind a CTable sized from the REQUESTED maxSymbolValue
+        // (lib/fse_compress.c:640-642,680-686): a request above 255 at tableLog 12 leaves the histogram less than HIST_WKSP_SIZE and
+        // HIST_count_wksp refuses (lib/hist.c:168) -- after the srcSize <= 1 early-out.  Where the table still fits, the histogram
+        // clamps the limit to 255 (lib/hist.c:169-172) and the call behaves as with 255; beyond the workspace the reference is undefined.
+        const size_t wksp = 4 * (size_t)FSEHIP_FSE_CTABLE_SIZE_U32(FSEHIP_FSE_MAX_TABLELOG, 255) + ((size_t)1 << FSEHIP_FSE_MAX_TABLELOG);
+        const size_t ctBytes = 4 * (1 + ((size_t)1 << (tableLog - 1)) + 2 * ((size_t)maxSymbolValue + 1));
+        if (ctBytes <= wksp && wksp - ctBytes < 4096)
+            return batch_arg_error(d_results, d_sizes, uniformSize, dstCapacity, nBlocks, FSEHIP_ERROR(workSpace_tooSmall), 2, s);
+    }
     const FseCWs w = fse_cws(tableLog);
     if (workspaceBytes < w.perBlock + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / w.perBlock;
     if (chunk >= nBlocks) chunk = nBlocks;
     else chunk = round_chunk(chunk, fse_encode_blocks_per_round(w.maxTl));
     // carve the workspace
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
     unsigned* counts = (unsigned*)carve(chunk * 1024);
@@ -301,7 +314,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     u32* encLists = (u32*)carve(chunk * FSE_EBINS * sizeof(u32));
     u32* encCounts = (u32*)carve(FSE_EBINS * sizeof(u32));
     if ((size_t)(p - (u8*)d_workspace) > workspaceBytes) {
-        // alignment slack exhausted: shrink the chunk by one (WS_SLACK covers 5 x 256 of padding)
+        // alignment slack exhausted (WS_SLACK covers the 256-byte padding of the seven regions)
         return (int)hipErrorInvalidValue;
     }
     unsigned msv = maxSymbolValue ? maxSymbolValue : 255;        // fse_compress.c:648
@@ -352,6 +365,7 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     size_t chunk = (workspaceBytes - WS_SLACK) / per;
     if (chunk >= nBlocks) chunk = nBlocks;
     else chunk = round_chunk(chunk, fse_decode_blocks_per_round(maxLog));
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // the decoder reads its bin lengths with one 16-byte load
     u8* p = (u8*)d_workspace;
     FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
     s16* norms = (s16*)p; p += align_up(chunk * 512, 256);
@@ -487,7 +501,20 @@ extern "C" int FSEHIP_HUF_compress4X_usingCTable_batch(void* d_dst, size_t dstSt
     HufEncArgs a;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
     a.src = mkview(d_src, srcStride, d_sizes, uniformSize);
-    a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr; a.streams = 4; a.nBlocks = nBlocks;
+    a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr; a.streams = 4; a.split1X = 0; a.nBlocks = nBlocks;
+    return (int)launch_huf_encode(a, (hipStream_t)stream);
+}
+
+// HUF_compress1X_usingCTable over a batch (lib/huf.h:290, body lib/huf_compress.c:457-502): one stream per block
+extern "C" int FSEHIP_HUF_compress1X_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                       const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                                       const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
+                                                       size_t nBlocks, void* stream)
+{
+    HufEncArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
+    a.src = mkview(d_src, srcStride, d_sizes, uniformSize);
+    a.ctables = d_ctables; a.ctStrideU32 = ctableStrideU32; a.meta = nullptr; a.streams = 1; a.split1X = 1; a.nBlocks = nBlocks;
     return (int)launch_huf_encode(a, (hipStream_t)stream);
 }
 
@@ -545,6 +572,7 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
     if (workspaceBytes < HUF_CWS_PER_BLOCK + HUF_CWS_NODE_PAD + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK - HUF_CWS_NODE_PAD) / HUF_CWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
     unsigned* counts = (unsigned*)carve(chunk * 1024);
@@ -568,7 +596,7 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
         CK(launch_huf_cprep(c, s, nodes));
         HufEncArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
-        e.src = src; e.ctables = ctables; e.ctStrideU32 = 256; e.meta = meta; e.streams = 4; e.nBlocks = nb;
+        e.src = src; e.ctables = ctables; e.ctStrideU32 = 256; e.meta = meta; e.streams = 4; e.split1X = 0; e.nBlocks = nb;
         CK(launch_huf_encode(e, s));
     }
     return 0;
@@ -591,6 +619,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
     if (workspaceBytes < HUF_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / HUF_DWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     const size_t dtU32 = FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1);      // 2-byte cells: 2^tableLog cells = 2^(tableLog-1) words
     HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
@@ -630,7 +659,7 @@ static size_t huf_using_ctable_host(int streams, void* dst, size_t dstSize, cons
     HufEncArgs a;
     a.dst = (u8*)ddst.p; a.dstStride = dstSize; a.dstCapacity = dstSize; a.results = (size_t*)dres.p;
     a.src = mkview(dsrc.p, srcSize, nullptr, srcSize);
-    a.ctables = (const u32*)dct.p; a.ctStrideU32 = 0; a.meta = nullptr; a.streams = streams; a.nBlocks = 1;
+    a.ctables = (const u32*)dct.p; a.ctStrideU32 = 0; a.meta = nullptr; a.streams = streams; a.split1X = 0; a.nBlocks = 1;
     HK(launch_huf_encode(a, nullptr));
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
@@ -751,6 +780,7 @@ extern "C" int FSEHIP_FSE_compressU16_batch(void* d_dst, size_t dstStride, size_
     if (workspaceBytes < U16_CWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / U16_CWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     u16* stateTables = (u16*)p; p += align_up(chunk * ((size_t)2 << FSEHIP_FSEU16_MAX_TABLELOG), 256);
     u32* symTT = (u32*)p; p += align_up(chunk * 8 * (FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1), 256);
@@ -777,6 +807,7 @@ extern "C" int FSEHIP_FSE_decompressU16_batch(unsigned short* d_dst, size_t dstS
     if (workspaceBytes < U16_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / U16_DWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     u32* cells = (u32*)p; p += align_up(chunk * ((size_t)4 << FSEHIP_FSEU16_MAX_TABLELOG), 256);
     U16Meta* meta = (U16Meta*)p;
@@ -827,6 +858,8 @@ extern "C" size_t FSEHIP_FSE_decompressU16(unsigned short* dst, size_t dstCapaci
     DevBuf dsrc, ddst, dws, dres;
     HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstCapacity * 2)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    // the device buffer starts as a copy of the caller's: what the decoder does not write stays what it was, as with the reference
+    if (dstCapacity) HK(hipMemcpy(ddst.p, dst, dstCapacity * 2, hipMemcpyHostToDevice));
     HK((hipError_t)FSEHIP_FSE_decompressU16_batch((unsigned short*)ddst.p, dstCapacity * 2, dstCapacity, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
                                                   1, dws.p, wsBytes, nullptr));
     size_t r = 0;

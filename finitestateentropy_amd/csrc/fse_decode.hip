@@ -61,13 +61,14 @@
 #endif
 #define FSE_MAXG (4 * FSE_SRV_WAVES)              // blocks per workgroup at most (FSE_SRV_WAVES x FSE_SRV_G; the LDS holds 16 with 4 KiB tables)
 
-#ifdef FSE_DEC_TIMING       // development aid: per-workgroup cycle accounting of the decoder and service waves
-__device__ unsigned long long g_decTiming[4096 * 8];
-extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_decTiming), sizeof(g_decTiming)); }
-#define TIMING(x) x
-#else
-#define TIMING(x)
-#endif
+// Cycle accounting of the decoder and service waves (bench.py's `roofline.secondary`): the TIMED instantiation of the kernel brackets
+// every round of its phase loop with s_memtime and adds its totals to g_decTiming when the workgroup ends.  Off by default: the
+// launcher picks the TIMED kernel only between FSEHIP_debug_decodeTiming(1, ..) and (0, ..).
+//   [0] cycles of decoder-wave rounds in which some lane pair ran a phase, [1] cycles of rounds in which none could, [2] / [3] their
+//   numbers, [4] workgroups, [5] / [6] busy / idle cycles of the first service wave of every workgroup, [7] service rounds that did work
+__device__ unsigned long long g_decTiming[16];
+static bool g_decTimingOn = false;
+#define TIMING(...) do { if constexpr (TIMED) { __VA_ARGS__ } } while (0)
 struct BulkState { u32 s, q, bq; };     // this lane's state (cell address) and the pair's bit cursor
 
 // The decoder lanes keep their states as absolute LDS byte addresses of the table cells.
@@ -221,6 +222,7 @@ DEV void fse_ring_put(u32* rg, int off, u32 w)
 // to ring offset (Stop - 4 - o) mod FSE_IN_RING (Stop = payload size rounded up to 4).  Either way ring byte x <-> payload
 // byte is a bijection on windows of FSE_IN_RING aligned-dword bytes, so the validLo protocol is the same.
 DEV void fse_ring_put_rev(u32* rg, int Sg, int off, u32 w) { fse_ring_put(rg, ((Sg + 3) & ~3) - 4 - off, __brev(w)); }
+template <bool TIMED>
 DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev)
 {
     const u32 symShift = a.atab ? 0u : 2u;
@@ -262,7 +264,9 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
     u32 yq[FSE_SRV_G][4];
 #pragma unroll
     for (int l = 0; l < FSE_SRV_G; ++l) { yq[l][0] = yq[l][1] = yq[l][2] = yq[l][3] = 0; }
-    TIMING(unsigned long long sBusy = 0; unsigned long long sIdle = 0; unsigned long long nBusy = 0; unsigned long long sA = __builtin_readcyclecounter();)
+    unsigned long long sBusy = 0, sIdle = 0, nBusy = 0, sA = 0;
+    (void)sBusy; (void)sIdle; (void)nBusy; (void)sA;
+    TIMING(sA = __builtin_readcyclecounter(););
     for (;;) {
         // snapshot of the decoder's progress (the finished flag is read before the iteration count it guards)
         u32 pp = 0x80000000u, it = flushed;
@@ -278,7 +282,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         if (!(fm | rm)) {
             if (!__any(live)) break;
             __builtin_amdgcn_s_sleep(4);
-            TIMING({ const unsigned long long sB = __builtin_readcyclecounter(); sIdle += sB - sA; sA = sB; })
+            TIMING(const unsigned long long sB = __builtin_readcyclecounter(); sIdle += sB - sA; sA = sB;);
             continue;
         }
         // (1) request the next input chunk of every block that is about to need it
@@ -323,9 +327,9 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             }
         }
         if (wantFlush) { fpos += it - flushed; fpos = fpos >= FSE_DEC_RING ? fpos - FSE_DEC_RING : fpos; flushed = it; }
-        TIMING({ const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy; })
+        TIMING(const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy;);
     }
-    TIMING(if (lane == 0 && g0 == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[4] = sBusy; t[5] = sIdle; t[6] = nBusy; })
+    TIMING(if (lane == 0 && g0 == 0) { atomicAdd(&g_decTiming[5], sBusy); atomicAdd(&g_decTiming[6], sIdle); atomicAdd(&g_decTiming[7], nBusy); });
 }
 
 // cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
@@ -372,7 +376,7 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
 // of a block follows its input rate.
 // LDS: G tables A[2^ldsLog] (u16) on table-size aligned addresses | DecCtl[G] | per block: state ring
 // (FSE_DEC_RING x 8 B), input ring (256 + 16 B) | two flag words
-template <bool FAST>
+template <bool FAST, bool TIMED>
 __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -541,12 +545,14 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
     }
     __syncthreads();
-    if (wave >= 1) { fse_decode_service(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G, FAST); return; }
+    if (wave >= 1) { fse_decode_service<TIMED>(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G, FAST); return; }
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
     const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
-    TIMING(unsigned long long tRun = 0; unsigned long long tWait = 0; unsigned long long nRun = 0; unsigned long long nWait = 0; unsigned long long tA = __builtin_readcyclecounter();)
+    unsigned long long tRun = 0, tWait = 0, nRun = 0, nWait = 0, tA = 0;
+    (void)tRun; (void)tWait; (void)nRun; (void)nWait; (void)tA;
+    TIMING(tA = __builtin_readcyclecounter(););
     // The service's progress words are read one round ahead: the loads issued here are consumed at the top of the next
     // round, so their LDS round trip hides under this round's phase.  Stale values are conservative (srvFlushed only grows,
     // srvValidLo only falls); LDS operations of one wave execute in order, so the ring reads of a phase cannot overtake
@@ -580,10 +586,10 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
                 ctl_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
             }
         }
-        TIMING({ const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB; })
+        TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB;);
         if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
     }
-    TIMING(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* t = g_decTiming + 8 * blockIdx.x; t[0] = tRun; t[1] = tWait; t[2] = nRun; t[3] = nWait; })
+    TIMING(if (lane == 0) { atomicAdd(&g_decTiming[0], tRun); atomicAdd(&g_decTiming[1], tWait); atomicAdd(&g_decTiming[2], nRun); atomicAdd(&g_decTiming[3], nWait); atomicAdd(&g_decTiming[4], 1ull); });
     const u32 sOther = dpp_swap(bs.s);               // (all lanes of the wave are still here)
     if (!owner || half) return;
     op = 4 * (long)iters;
@@ -620,16 +626,44 @@ size_t fse_decode_blocks_per_round(unsigned maxTableLog)
 static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
 {
     const size_t ldsBytes = FSE_DEC_LDS;
-    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true>, (int)ldsBytes);
-        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false>, (int)ldsBytes);
+    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true, false>, (int)ldsBytes);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false, false>, (int)ldsBytes);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<true, true>, (int)ldsBytes);
         if (e != hipSuccess) return e;
     }
     fse_decode_geometry(a.ldsLog, ldsBytes, &a.slotU32, &a.G);
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
-    if (rev) hipLaunchKernelGGL(k_fse_decode<true>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
-    else     hipLaunchKernelGGL(k_fse_decode<false>, dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    if (rev && g_decTimingOn) hipLaunchKernelGGL((k_fse_decode<true, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    else if (rev) hipLaunchKernelGGL((k_fse_decode<true, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    else          hipLaunchKernelGGL((k_fse_decode<false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     return hipGetLastError();
+}
+
+// enable = 1: zero the counters and send the bit-reversed classes through the TIMED kernel; enable = 0: back to the plain kernel and, if
+// out16 is given, the counters (see g_decTiming) plus [8] the device's engine clock in kHz, [9] blocks per workgroup and [10]
+// workgroups per CU of the 4 KiB class.  Synchronises the device; a measurement aid for bench.py, not part of the codec API.
+extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decodeTiming(int enable, unsigned long long* out16)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    if (enable) {
+        unsigned long long zero[16] = { 0 };
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_decTiming), zero, sizeof(zero));
+        g_decTimingOn = e == hipSuccess;
+        return (int)e;
+    }
+    g_decTimingOn = false;
+    if (!out16) return 0;
+    e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_decTiming), sizeof(g_decTiming));
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, khz = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
+    unsigned slot; int G;
+    fse_decode_geometry(FSE_DEC_FAST_MAXLOG, FSE_DEC_LDS, &slot, &G);
+    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G; out16[10] = 2;
+    return 0;
 }
 
 // caller-built reference-layout DTables (FSE_decompress_usingDTable over a batch): staged as plain cells

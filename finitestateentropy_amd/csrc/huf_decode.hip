@@ -407,13 +407,16 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
 // lock step.  This is an acceptance path, not a throughput path: one lane walks one block with the reference's reader state
 // (BitReader) and its loop structure, the table stays in global memory.
 struct X2Stream { BitReader r; u8* op; };
+// (a cell's length field is 1 or 2 in any table HUF_readDTableX2 builds; the low two bits keep the advance of a damaged caller table
+//  within what the two bytes just stored cover, so the cursors cannot run away from the segment checks of :850-853)
 DEV void x2_cell(X2Stream& s, const u32* cells, u32 dtLog)                               // HUF_decodeSymbolX2, :663-670
 {
     const u32 v = (u32)((s.r.win << (s.r.used & 63u)) >> ((64u - dtLog) & 63u));
     const u32 c = cells[v];
     s.op[0] = (u8)c; s.op[1] = (u8)(c >> 8);
     s.r.used += (c >> 16) & 0xFFu;
-    s.op += c >> 24;
+    const u32 len = c >> 24;
+    s.op += len > 2u ? 2u : len;
 }
 DEV int x2_reload_fast(BitReader& r)                                                     // BIT_reloadDStreamFast, bitstream.h:400-409
 {
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_x2(HufDecArgs a)
     size_t result;
     do {
         if (dtLog > a.maxTableLog) { result = FERR(tableLog_tooLarge); break; }
+        if (dtLog < 1) { result = FERR(corruption_detected); break; }                    // no table has tableLog 0 (the look-up would shift by 64)
         if (cSize < 10) { result = FERR(corruption_detected); break; }                   // :758
         const size_t l1 = ld16(in), l2 = ld16(in + 2), l3 = ld16(in + 4), l4 = cSize - (l1 + l2 + l3 + 6);
         if (l4 > cSize) { result = FERR(corruption_detected); break; }                   // :795

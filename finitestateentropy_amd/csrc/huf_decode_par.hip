@@ -39,6 +39,7 @@
 #ifndef HPAR_WARM
 #define HPAR_WARM 128u                // warm-up bits in front of a range
 #endif
+#define HPAR_MAX_REPAIR 8u            // repair rounds per stream before the block is handed to the serial decoder
 #define HPAR_NEAR 48u                 // four symbols consume at most 48 bits: closer than this to a limit the lane steps by symbols
 
 typedef const __attribute__((address_space(3))) u16* hpar_lds_u16;
@@ -237,14 +238,18 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
         u32 E = S;
         u32 n = hpar_run(arr, E, cHi, tabOff, mask2);
         HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
-        // ---- verify / repair
-        for (;;) {
+        // ---- verify / repair.  A code that never falls into step (say 256 equal weights: every code 8 bits, a lane dropped off the
+        //      byte grid stays off it) gains one exact lane per round -- the serial walk at the price of a wave.  Real data needs
+        //      0..2 rounds; beyond HPAR_MAX_REPAIR the block is the serial decoder's (crafted input cannot pin a wave to a block).
+        for (u32 round = 0;; ++round) {
             const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
             const bool bad = lane > 0 && S != prevE;
             if (!__any(bad)) break;
+            if (round == HPAR_MAX_REPAIR) { good = false; break; }              // uniform
             HST(++stRounds; stBad += __builtin_popcountll(__ballot(bad));)
             if (bad) { S = prevE; E = S; n = hpar_run(arr, E, cHi, tabOff, mask2); }
         }
+        if (!good) break;
         HST({ const unsigned long long tB = __builtin_readcyclecounter(); tRep += tB - tA; tA = tB; })
         // ---- verdict for this stream
         u32 incl = n;

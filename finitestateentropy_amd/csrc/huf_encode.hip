@@ -158,9 +158,19 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     for (u32 i = tid; i < 256; i += blockDim.x) ct[i] = gct[i];
     __syncthreads();
 
+    // 1X over a batch: the single stream is the plain concatenation of the codes in emission order (last symbol first), so the four
+    // waves of the workgroup take a quarter of the symbols each -- wave w the emission range [w*q, (w+1)*q) -- and the bit counts of
+    // pass 1 place their pieces (the single-block host call keeps one wave)
+    const bool split1 = streams == 1 && blockDim.x == HUF_ENC_THREADS;
     const u32 segSize = streams == 4 ? (n + 3) / 4 : n;
-    const u32 myStart = wave * segSize;
-    const u32 myLen = (int)wave < streams ? (streams == 4 && wave == 3 ? n - 3 * segSize : segSize) : 0;
+    u32 myStart = wave * segSize;
+    u32 myLen = (int)wave < streams ? (streams == 4 && wave == 3 ? n - 3 * segSize : segSize) : 0;
+    if (split1) {
+        const u32 q = (((n + 3) / 4) + 15u) & ~15u;
+        const u32 e0 = wave * q;
+        myLen = e0 < n ? (n - e0 < q ? n - e0 : q) : 0;
+        myStart = n - e0 - myLen;
+    }
 
     const u8* const seg = src + myStart;
     HeTile tile0;
@@ -209,9 +219,11 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
             cur = nxt;
         }
         bits = wave_sum_u32(bits);
-        if (lane == 0 && (int)wave < streams) sh[wave] = bits;
+        if (lane == 0 && ((int)wave < streams || split1)) sh[wave] = bits;
     }
     __syncthreads();
+    const u32 bitsBefore = split1 ? (wave > 0 ? sh[0] : 0) + (wave > 1 ? sh[1] : 0) + (wave > 2 ? sh[2] : 0) : 0;   // bits of the waves in front of mine
+    const u32 streamBits = split1 ? sh[0] + sh[1] + sh[2] + sh[3] : 0;
 
     // ---- layout + verdict (uniform)
     size_t op = streams == 4 ? 6 : 0;
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     for (int k = 0; k < streams; ++k) {
         const size_t capk = cap - op;                    // oend - op
         if (capk <= 8) { fail = true; break; }           // dstSize < 8 / BIT_initCStream (bitstream.h:191)
-        const size_t tot = (size_t)sh[k] + 1;            // + end mark
+        const size_t tot = (size_t)(split1 ? streamBits : sh[k]) + 1;            // + end mark
         if ((tot >> 3) >= capk - 8) { fail = true; break; }   // BIT_closeCStream overflow rule
         start[k] = op; ssize[k] = (tot + 7) >> 3;
         op += ssize[k];
@@ -262,8 +274,9 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
         for (size_t i = tid; i < total; i += blockDim.x) dst[i] = 0;
     }
     __syncthreads();
-    if ((int)wave < streams) {
-        const u64 base = 8 * ((u64)lead + start[wave]);
+    if ((int)wave < streams || split1) {
+        const u64 base = 8 * ((u64)lead + start[split1 ? 0 : wave]) + bitsBefore;
+        const u32 markAt = split1 ? streamBits - bitsBefore : sh[wave];          // the end mark follows the stream's last bit (written by its first wave)
         if (inLds) {                                     // separate call sites keep the LDS / global address spaces visible
             u64 pos = base;
             HeTile cur = tile0;
@@ -274,8 +287,8 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
                 pos = he_emit_tile<false>(img, pos, cur, myLen, j0, ct, lane);
                 cur = nxt;
             }
-            if (lane == 0) {                             // end mark, then the jump table entry of this stream
-                or_bits<false>(img, base + sh[wave], 1, 1);
+            if (lane == 0 && (!split1 || wave == 0)) {   // end mark, then the jump table entry of this stream
+                or_bits<false>(img, base + markAt, 1, 1);
                 if (streams == 4 && wave < 3) or_bits<false>(img, 8 * ((u64)lead + 2 * wave), ssize[wave], 16);
             }
         } else {
@@ -289,8 +302,8 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
                 pos = he_emit_tile<true>(g, pos, cur, myLen, j0, ct, lane);
                 cur = nxt;
             }
-            if (lane == 0) {
-                or_bits<true>(g, base + sh[wave], 1, 1);
+            if (lane == 0 && (!split1 || wave == 0)) {
+                or_bits<true>(g, base + markAt, 1, 1);
                 if (streams == 4 && wave < 3) or_bits<true>(g, 8 * ((u64)lead + 2 * wave), ssize[wave], 16);
             }
         }
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     if (tid == 0) a.results[b] = result;
 }
 
+// streams == 1 with a.nBlocks > 1 or a.split1X: four waves per block (see split1 in the kernel)
 hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
@@ -317,7 +331,7 @@ hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s)
     if (img > maxLds - 1100) img = maxLds - 1100;
     img = (img + 15) & ~(size_t)15;
     const size_t ldsBytes = (256 + 8) * 4 + img;
-    const unsigned threads = a.streams == 4 ? HUF_ENC_THREADS : 64;
+    const unsigned threads = (a.streams == 4 || a.split1X) ? HUF_ENC_THREADS : 64;
     probe_before(PK_HUF_ENCODE, s);
     hipLaunchKernelGGL(k_huf_encode, dim3((unsigned)a.nBlocks), dim3(threads), ldsBytes, s, a, (u32)img);
     probe_after(PK_HUF_ENCODE, s);

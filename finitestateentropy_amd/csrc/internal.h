@@ -152,6 +152,7 @@ struct HufEncArgs {              // a4: HUF_compress4X_usingCTable (streams = 4)
     const u32* ctables; size_t ctStrideU32;
     const HufMeta* meta;
     int streams;
+    int split1X;                 // streams == 1: four waves per block, a quarter of the symbols each (the batched 1X call)
     size_t nBlocks;
 };
 hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s);

@@ -19,17 +19,28 @@ def _staged(group=None):
     return dist.get_backend(group) == "gloo"
 
 
-def _isend(t, dst, group=None):
-    return dist.isend(t.cpu() if (t.is_cuda and _staged(group)) else t, dst=dst, group=group)
-
-
-def _recv_into(t, src, group=None):
-    if t.is_cuda and _staged(group):
-        h = torch.empty(t.shape, dtype=t.dtype)
-        dist.recv(h, src=src, group=group)
+def _grouped(ops, group=None):
+    """Issue a list of (kind, tensor, peer) transfers as ONE group and wait for all of them: `dist.batch_isend_irecv` is
+    ncclGroupStart ... ncclGroupEnd on RCCL, so a root's transfers to / from its peers are in flight together and its
+    xGMI links run concurrently instead of one after the other.  Transfers between one pair of ranks match in list order on both
+    sides.  Device tensors on a gloo group are staged through host memory (tests / two ranks sharing a GPU)."""
+    if not ops:
+        return
+    stage = _staged(group)
+    p2p, landing = [], []
+    for kind, t, peer in ops:
+        if kind == "send":
+            p2p.append(dist.P2POp(dist.isend, t.cpu() if (t.is_cuda and stage) else t, peer, group))
+        elif t.is_cuda and stage:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            landing.append((t, h))
+            p2p.append(dist.P2POp(dist.irecv, h, peer, group))
+        else:
+            p2p.append(dist.P2POp(dist.irecv, t, peer, group))
+    for q in dist.batch_isend_irecv(p2p):
+        q.wait()
+    for t, h in landing:
         t.copy_(h)
-    else:
-        dist.recv(t, src=src, group=group)
 
 
 def shard_range(n_blocks, rank, world):
@@ -39,54 +50,54 @@ def shard_range(n_blocks, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def scatter_blocks(blocks_root, n_blocks, block_bytes, rank, world, device, root=0, group=None):
-    """Root holds (n_blocks, block_bytes) uint8; every rank receives its shard_range rows."""
+def scatter_blocks(blocks_root, n_blocks, block_bytes, rank, world, device, root=0, group=None, out=None):
+    """Root holds (n_blocks, block_bytes) uint8; every rank receives its shard_range rows (into `out` if given).  The root's
+    sends to all peers form one group (one transfer per peer, rows of a contiguous range are contiguous memory)."""
     lo, hi = shard_range(n_blocks, rank, world)
-    mine = torch.empty((hi - lo, block_bytes), dtype=torch.uint8, device=device)
+    mine = out if out is not None else torch.empty((hi - lo, block_bytes), dtype=torch.uint8, device=device)
+    assert mine.shape == (hi - lo, block_bytes) and mine.is_contiguous()
     if world == 1:
         mine.copy_(blocks_root[lo:hi])
         return mine
     if rank == root:
-        reqs = []
+        ops = []
         for r in range(world):
             rlo, rhi = shard_range(n_blocks, r, world)
             if r == root:
                 mine.copy_(blocks_root[rlo:rhi])
             elif rhi > rlo:
-                reqs.append(_isend(blocks_root[rlo:rhi].contiguous(), r, group))
-        for q in reqs:
-            q.wait()
+                ops.append(("send", blocks_root[rlo:rhi].contiguous(), r))
+        _grouped(ops, group)
     elif hi > lo:
-        _recv_into(mine, root, group)
+        _grouped([("recv", mine, root)], group)
     return mine
 
 
-def gather_blocks(slots_mine, sizes_mine, n_blocks, rank, world, root=0, group=None):
-    """Fixed-stride result slots (rows, stride) + per-block result values -> root gets (n_blocks, stride) and sizes.
+def gather_blocks(slots_mine, sizes_mine, n_blocks, rank, world, root=0, group=None, out=None):
+    """Fixed-stride result slots (rows, stride) + per-block result values -> root gets (n_blocks, stride) and sizes (in `out` =
+    (slots, sizes) if given).  All transfers of the root -- two per peer, slots then sizes -- form one group.
     Non-root ranks return (None, None)."""
     stride = slots_mine.shape[1]
     if world == 1:
         return slots_mine, sizes_mine
     if rank == root:
-        out = torch.empty((n_blocks, stride), dtype=slots_mine.dtype, device=slots_mine.device)
-        sizes = torch.empty(n_blocks, dtype=sizes_mine.dtype, device=sizes_mine.device)
-        reqs = []
+        if out is not None:
+            slots, sizes = out
+        else:
+            slots = torch.empty((n_blocks, stride), dtype=slots_mine.dtype, device=slots_mine.device)
+            sizes = torch.empty(n_blocks, dtype=sizes_mine.dtype, device=sizes_mine.device)
+        ops = []
         for r in range(world):
             rlo, rhi = shard_range(n_blocks, r, world)
             if r == root:
-                out[rlo:rhi].copy_(slots_mine); sizes[rlo:rhi].copy_(sizes_mine)
+                slots[rlo:rhi].copy_(slots_mine); sizes[rlo:rhi].copy_(sizes_mine)
             elif rhi > rlo:
-                if slots_mine.is_cuda and _staged(group):
-                    _recv_into(out[rlo:rhi], r, group); _recv_into(sizes[rlo:rhi], r, group)
-                else:
-                    reqs.append(dist.irecv(out[rlo:rhi], src=r, group=group))
-                    reqs.append(dist.irecv(sizes[rlo:rhi], src=r, group=group))
-        for q in reqs:
-            q.wait()
-        return out, sizes
+                ops.append(("recv", slots[rlo:rhi], r))
+                ops.append(("recv", sizes[rlo:rhi], r))
+        _grouped(ops, group)
+        return slots, sizes
     if slots_mine.shape[0]:
-        _isend(slots_mine.contiguous(), root, group).wait()
-        _isend(sizes_mine.contiguous(), root, group).wait()
+        _grouped([("send", slots_mine.contiguous(), root), ("send", sizes_mine.contiguous(), root)], group)
     return None, None
 
 
@@ -109,17 +120,25 @@ def sharded_roundtrip(blocks_root, n_blocks, block_bytes, rank, world, device, c
     return g_slots, g_sizes, g_back, g_res
 
 
-def sharded_codec_job(corpus_root, n_blocks, block_bytes, rank, world, device, codecs, root=0):
+def sharded_codec_job(corpus_root, n_blocks, block_bytes, rank, world, device, codecs, root=0, shard_out=None, gather_out=None, mark=None):
     """BASELINE config 5 with the corpus on one rank (bench.py's with-comm variant): scatter the raw blocks, run every codec's
     encode + decode on the rank's shard, gather every codec's compressed slots and sizes on the root.
     `codecs`: objects with .src (set here), .encode(), .decode(), .dst (rows, stride), .res, .out, .dres.
-    Returns (my shard, [(slots, sizes) per codec on the root, (None, None) elsewhere])."""
-    mine = scatter_blocks(corpus_root, n_blocks, block_bytes, rank, world, device, root)
+    `shard_out` / `gather_out` (one (slots, sizes) pair per codec, root only): preallocated landing buffers, so that a timed pass
+    does not allocate; `mark(name)` is called after each phase (bench.py's per-phase clock).  Returns (my shard, [(slots, sizes) per codec on the root, (None, None) elsewhere])."""
+    mine = scatter_blocks(corpus_root, n_blocks, block_bytes, rank, world, device, root, out=shard_out)
+    if mark:
+        mark("1_scatter")
     for cd in codecs:
         cd.src = mine
         cd.encode()
         cd.decode()
-    gathered = [gather_blocks(cd.dst, cd.res, n_blocks, rank, world, root) for cd in codecs]
+    if mark:
+        mark("2_codecs")
+    gathered = [gather_blocks(cd.dst, cd.res, n_blocks, rank, world, root, out=(gather_out[i] if gather_out is not None else None))
+                for i, cd in enumerate(codecs)]
+    if mark:
+        mark("3_gather")
     return mine, gathered
 
 

@@ -95,8 +95,9 @@ FSEHIP_API size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const voi
 /* lib/huf.h:290, :190 */
 FSEHIP_API size_t FSEHIP_HUF_compress1X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable);
 FSEHIP_API size_t FSEHIP_HUF_compress4X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable);
-/* lib/huf.h:275-277 (tableType 0 = X1 cells; an X2 table (tableType 1) is rejected with GENERIC,
- * exactly as HUF_decompress4X1_usingDTable does, lib/huf_decompress.c:411-412) */
+/* lib/huf.h:275-277.  HUF_decompress4X_usingDTable dispatches on the table type like lib/huf_decompress.c:980-997: tableType 0 = X1
+ * (single-symbol) cells, tableType 1 = X2 (double-symbol) cells from the reference's HUF_readDTableX2 -- both accepted.
+ * HUF_decompress4X1_usingDTable rejects an X2 table with GENERIC exactly as the reference does (lib/huf_decompress.c:411-412). */
 FSEHIP_API size_t FSEHIP_HUF_decompress4X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
 FSEHIP_API size_t FSEHIP_HUF_decompress4X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
 /* lib/huf.h:66, :95, :82 */
@@ -133,7 +134,8 @@ FSEHIP_API int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstSt
 /* One-shot block API over a batch: FSE_compress2 (histogram, normalisation, NCount header, CTable,
  * payload) and FSE_decompress_wksp(maxLog) entirely on the device.  d_workspace/workspaceBytes: scratch,
  * at least FSEHIP_*_workspaceSize(1,...) bytes; larger workspaces process more blocks per pass (the
- * *_workspaceSize(nBlocks, ...) value never needs to be exceeded). */
+ * *_workspaceSize(nBlocks, ...) value never needs to be exceeded).  Every d_workspace of this header must be
+ * 256-byte aligned (hipMalloc'ed memory is); a misaligned one is refused with hipErrorInvalidValue. */
 FSEHIP_API size_t FSEHIP_FSE_compress_batch_workspaceSize(size_t nBlocks, unsigned tableLog);
 FSEHIP_API int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
                                          const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
@@ -149,6 +151,11 @@ FSEHIP_API int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
  * HUF_compress2 / HUF_decompress (4X1 decoder) over a batch.  For the one-shot decoder d_dstSizes (or
  * uniformDstSize) is the exact regenerated size of each block, as HUF_decompress requires. */
 FSEHIP_API int FSEHIP_HUF_compress4X_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                       const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                                       const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
+                                                       size_t nBlocks, void* stream);
+/* HUF_compress1X_usingCTable over a batch (lib/huf.h:290; lib/huf_compress.c:457-502): one stream per block, no jump table */
+FSEHIP_API int FSEHIP_HUF_compress1X_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
                                                        const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
                                                        const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
                                                        size_t nBlocks, void* stream);
@@ -231,6 +238,12 @@ FSEHIP_API int FSEHIP_FSE_decompressU16_batch(unsigned short* d_dst, size_t dstS
  * 8 huf_decode, 9 fse_encode_wave [wave per block]), the summed duration in milliseconds and the number of launches.  Arrays hold 16 entries. */
 FSEHIP_API int FSEHIP_probe_begin(void);
 FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
+/* Cycle accounting inside the FSE decoder (the bound that actually holds for it is chain latency x LDS-resident blocks, not HBM):
+ * between (1, NULL) and (0, out16) the one-shot FSE decompressor runs an instrumented instantiation of its hot-loop kernel.
+ * out16: [0] cycles of decoder-wave rounds that ran a phase of 16 iterations (4 symbols each), [1] cycles of rounds that waited,
+ * [2] / [3] their numbers, [4] workgroups, [5] / [6] busy / idle cycles of one service wave per workgroup, [7] its working rounds,
+ * [8] engine clock in kHz, [9] blocks per workgroup, [10] workgroups per CU.  Synchronises the device; for benchmarks only. */
+FSEHIP_API int FSEHIP_debug_decodeTiming(int enable, unsigned long long* out16);
 
 /* build / device info: returns 0 and fills the fields when a gfx950 device is current */
 typedef struct { int deviceOrdinal; int computeUnits; int ldsBytesPerCU; int wavefrontSize; char archName[64]; } FSEHIP_DeviceInfo;

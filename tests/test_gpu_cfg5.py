@@ -1,0 +1,88 @@
+"""BASELINE configs[4] (the mixed {P02, P14, P80} corpus, FSE + Huff0 on every block) against the compiled reference, and the N > 1
+path of bench.py itself (two ranks on the one GPU of the test box, gloo through host memory standing in for RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MIX = (2, 14, 80)
+
+
+def test_cfg5_mixed_shard_vs_reference(hip, checker):
+    """One GPU's shard of config 5 at full size (125k x 32 KB, block g drawn from P[g mod 3] with seed g + 1): both codecs' sizes and
+    bytes against the compiled reference on a 1,024-block strided sample across the whole shard, every block round-trips, FSE decoded
+    at the reference's default limit (maxLog 12); the shard starts at an odd global block so that the mix is not phase-aligned."""
+    n, first = 125000, 125000 * 3 + 1
+    src = hip.probagen_mixed(MIX, n, 32768, first_block=first)
+    # the generator rule itself: three blocks of the shard against the CPU generator
+    for row in (0, 1, 2, n - 1):
+        g = first + row
+        assert (src[row].cpu().numpy() == checker.probagen_batch(MIX[g % 3], 1, 32768, g + 1)[0]).all(), row
+    idx = torch.arange(0, n, n // 1024, device=src.device)[:1024]
+    host = src[idx].cpu().numpy()
+    for codec in (0, 1):
+        if codec == 0:
+            dst, res = hip.fse_compress_batch(src, table_log=11)
+            out, dres = hip.fse_decompress_batch(dst, res, 32768, max_log=12)
+        else:
+            dst, res = hip.huf_compress_batch(src, table_log=11)
+            out, dres = hip.huf_decompress_batch(dst, res, 32768)
+        assert int((res > 1).sum()) == n and int((res < 32768).sum()) == n
+        assert int((dres == 32768).sum()) == n
+        assert torch.equal(out, src)
+        _, ores, odst = checker.compress_batch(codec, host, table_log=11)
+        rh, dh = res[idx].cpu().numpy(), dst[idx].cpu().numpy()
+        assert (rh == ores.astype(np.int64)).all(), codec
+        for k in range(len(rh)):
+            assert (dh[k][:rh[k]] == odst[k][:rh[k]]).all(), (codec, int(idx[k]))
+        del dst, res, out, dres
+
+
+def _run_bench(extra, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_start_from_gpus_flag():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself, reports n_gpus == 2, codes the fixed corpus of
+    config 5 as two shards (strong scaling) and round-trips the with-comm variant (scatter, both codecs, gather)."""
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "4096", "--cfg5-blocks", "3000", "--cfg5-total", "8001",
+                       "--configs", "cfg5_mixed_shard,cfg5_mixed_1M", "--no-cpu-baseline", "--no-host-inclusive", "--comm-passes", "2",
+                       "--parity-blocks", "512"],
+                      env={"FSEHIP_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    weak, strong = line["configs"]["cfg5_mixed_shard"], line["configs"]["cfg5_mixed_1M"]
+    assert weak["scaling"] == "weak" and weak["blocks_per_gpu"] == 3000
+    assert strong["scaling"] == "strong" and strong["corpus_blocks"] == 8001 and strong["blocks_per_gpu"] == 4001
+    assert "reference-bytes" in strong["parity"] or "port-bytes" in strong["parity"]
+    wc = strong["with_comm"]
+    assert wc["roundtrip_ok"] is True and wc["passes"] == 2 and wc["value"] > 0
+    assert set(wc["phase_ms"]) == {"1_scatter", "2_codecs", "3_gather"}
+
+
+def test_bench_one_gpu_line_has_the_contract_fields():
+    line = _run_bench(["--steps", "2", "--warmup", "1", "--blocks", "8192", "--configs", "cfg5_mixed_1M", "--cfg5-total", "9000",
+                       "--no-cpu-baseline", "--parity-blocks", "256"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["dtype"] == "u8"
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and roof["kernel"].startswith("k_fse")
+    sec = roof["secondary"]
+    assert sec["resident_blocks_per_cu"] >= 16 and 100 < sec["cycles_per_iteration"] < 2000 and 0 < sec["frac"] <= 1.2
+    hi = line["host_inclusive"]
+    assert hi["roundtrip_ok"] is True and hi["encode_GBps"] > 0 and hi["decode_GBps"] > 0
+    assert line["configs"]["cfg5_mixed_1M"]["corpus_blocks"] == 9000 and line["configs"]["cfg5_mixed_1M"]["scaling"] == "strong"

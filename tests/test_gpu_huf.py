@@ -289,3 +289,84 @@ def test_huf_x2_tables_accepted(hip, ref):
             assert rg == r, (size, trial, rg, r)
             if not is_error(r):
                 assert (og[:r] == exp[:r]).all()
+
+
+@pytest.mark.parametrize("size", [1, 7, 8, 12, 100, 1001, 4097, 32767, 32768, 65536, 131072])
+def test_huf_1x_using_ctable_batch(hip, oracle, size):
+    """HUF_compress1X_usingCTable over a batch (lib/huf.h:290, lib/huf_compress.c:457-502): bytes and return values against the
+    reference for every block, with the capacity sweep of the 4X test (dstSize < 8 -> 0, BIT_closeCStream's overflow rule)."""
+    for req in (11, 12, 6):
+        blocks = mixed_blocks(oracle, 20, size, seed=5 * req + 1)
+        keep, cts = [], []
+        for b in range(20):
+            t = _huf_tables(oracle, blocks[b], req)
+            if t is None:
+                continue
+            keep.append(b); cts.append(t[1])
+        if not keep:
+            continue
+        src = torch.from_numpy(blocks[keep]).cuda()
+        d_ct = torch.from_numpy(np.stack(cts).view(np.int32)).cuda()
+        c0 = oracle.huf_compress1x_using_ctable(blocks[keep[0]], cts[0])[0]
+        for cap in [huf_compress_bound(size), 0, 7, 8, 9, 16] + ([c0 - 1, c0, c0 + 7, c0 + 8, c0 + 9] if c0 else []):
+            if cap < 0:
+                continue
+            dst, res = hip.huf_compress1x_using_ctable_batch(src, d_ct, dst_capacity=cap)
+            dst, res = dst.cpu().numpy(), res.cpu().numpy()
+            for i, b in enumerate(keep):
+                r, out = oracle.huf_compress1x_using_ctable(blocks[b], cts[i], cap)
+                assert res[i] == s64(r), (size, req, cap, b, res[i], r)
+                if r:
+                    assert (dst[i][:r] == out[:r]).all(), (size, req, cap, b)
+        # ragged sizes and one shared table
+        if size >= 100:
+            sizes = np.array([max(1, size - 37 * i) for i in range(len(keep))], np.int64)
+            dst, res = hip.huf_compress1x_using_ctable_batch(src, d_ct, sizes=torch.from_numpy(sizes).cuda())
+            dst, res = dst.cpu().numpy(), res.cpu().numpy()
+            for i, b in enumerate(keep):
+                r, out = oracle.huf_compress1x_using_ctable(blocks[b][:sizes[i]], cts[i], huf_compress_bound(size))
+                assert res[i] == s64(r) and (dst[i][:r] == out[:r]).all(), (size, req, b)
+
+
+def test_huf_1x_full_size(hip, oracle):
+    """north_star names HUF_compress1X_usingCTable: 20k x 32 KB Proba14 blocks with one shared table; every block against the
+    reference on a strided sample, all sizes plausible"""
+    n = 20000
+    src = hip.probagen_batch(14, n, 32768, first_seed=1)
+    host0 = src[0].cpu().numpy()
+    t = _huf_tables(oracle, host0, 11)
+    d_ct = torch.from_numpy(t[1].view(np.int32)).cuda().view(1, -1)
+    dst, res = hip.huf_compress1x_using_ctable_batch(src, d_ct, shared_table=True)
+    assert int((res > 16000).sum()) == n and int((res < 18500).sum()) == n
+    idx = np.arange(0, n, n // 64)
+    hs, hd, hr = src[idx].cpu().numpy(), dst[idx].cpu().numpy(), res[idx].cpu().numpy()
+    for k in range(len(idx)):
+        r, out = oracle.huf_compress1x_using_ctable(hs[k], t[1])
+        assert hr[k] == r and (hd[k][:r] == out[:r]).all(), int(idx[k])
+
+
+def test_oneshot_batch_argument_errors(hip, oracle):
+    """INTEGRATION: bad one-shot arguments are PER-BLOCK results, exactly what FSE_compress2 / HUF_compress2 return for that block
+    (lib/fse_compress.c:691; lib/huf_compress.c:654-660 in the reference's order of checks)"""
+    blocks = mixed_blocks(oracle, 12, 4096, seed=3)
+    src = torch.from_numpy(blocks).cuda()
+    sizes = torch.tensor([4096, 0, 4096, 1, 2, 4096, 100, 4096, 0, 4096, 4096, 7], dtype=torch.int64, device="cuda")
+    hs = sizes.cpu().numpy()
+    for tl, msv in ((13, 255), (14, 100), (12, 256), (12, 300), (11, 256), (9, 700), (11, 255)):     # (within what the reference defines)
+        _, res = hip.fse_compress_batch(src, table_log=tl, max_symbol_value=msv, sizes=sizes)
+        res = res.cpu().numpy()
+        for b in range(12):
+            r, _ = oracle.fse_compress2(blocks[b][:hs[b]], msv, tl)
+            assert res[b] == s64(r), ("fse", tl, msv, b, res[b], r)
+    for tl, msv in ((13, 255), (12, 256), (13, 256), (14, 300), (11, 255)):
+        for cap in (huf_compress_bound(4096), 0):
+            _, res = hip.huf_compress_batch(src, table_log=tl, max_symbol_value=msv, sizes=sizes, dst_capacity=cap)
+            res = res.cpu().numpy()
+            for b in range(12):
+                r, _ = oracle.huf_compress2(blocks[b][:hs[b]], msv, tl, cap)
+                assert res[b] == s64(r), ("huf", tl, msv, cap, b, res[b], r)
+    # a block beyond HUF_BLOCKSIZE_MAX meets srcSize_wrong before the table-log check
+    big = torch.zeros((2, 131073), dtype=torch.uint8, device="cuda")
+    _, res = hip.huf_compress_batch(big, table_log=13)
+    r, _ = oracle.huf_compress2(np.zeros(131073, np.uint8), 255, 13)
+    assert res.cpu().numpy()[0] == s64(r)
