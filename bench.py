@@ -368,30 +368,46 @@ def secondary_roofline(hip, cd, dev_info):
         return None
     buf = (C.c_ulonglong * 16)()
     L.FSEHIP_debug_decodeTiming(1, None)
+    L.FSEHIP_probe_begin()
     cd.decode(); torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(); cd.decode(); ev1.record(); torch.cuda.synchronize()
+    pms = (C.c_double * 16)(); pl = (C.c_uint * 16)()
+    L.FSEHIP_probe_collect(pms, pl)
     L.FSEHIP_debug_decodeTiming(0, buf)
-    t_run, t_wait, n_run, n_wait, n_wg, s_busy, s_idle, n_srv, clock_khz, blocks_per_wg, wgs_per_cu = [int(buf[i]) for i in range(11)]
+    t_run, t_wait, n_run, n_wait, n_wg, s_busy, s_idle, n_srv, clock_khz, blocks_per_wg, n_fin = [int(buf[i]) for i in range(11)]
+    life_cyc, life_ticks, setup_cyc, tail_cyc, t_fin = [int(buf[i]) for i in range(11, 16)]
+    wgs_per_cu = 2
     if n_run == 0:
         return None
     nb = cd.src.shape[0]
     cyc_iter = t_run / (n_run * 16.0)
     cus = dev_info["cus"]
     resident = blocks_per_wg * wgs_per_cu
-    clock = clock_khz * 1e3
+    nominal = clock_khz * 1e3
+    clock = life_cyc / life_ticks * 1e8 if life_ticks else nominal          # s_memtime cycles per tick of the constant 100 MHz clock
     model_blocks_per_s = cus * resident / (BLOCK / 4.0 * cyc_iter / clock)
-    ms_timed = ev0.elapsed_time(ev1)
+    ms_timed = pms[KERNEL_NAMES.index("k_fse_decode")]               # the instrumented kernel's own duration in that pass
     achieved = nb / (ms_timed * 1e-3)
+    slots = cus * wgs_per_cu
+    slot_busy = (life_ticks / 1e8) / (ms_timed * 1e-3 * slots) if life_ticks else None
     return {"bound": "chain latency x LDS-resident blocks", "kernel": "k_fse_decode",
             "resident_blocks_per_cu": resident, "cycles_per_iteration": round(cyc_iter, 1), "symbols_per_iteration": 4,
-            "decoder_wave_wait_frac": round(t_wait / max(t_run + t_wait, 1), 4),
-            "service_wave_busy_frac": round(s_busy / max(s_busy + s_idle, 1), 4),
-            "clock_GHz": round(clock / 1e9, 3),
+            "clock_GHz": round(clock / 1e9, 3), "nominal_clock_GHz": round(nominal / 1e9, 3),
             "model_GBps": round(model_blocks_per_s * BLOCK / 1e9, 1), "achieved_GBps": round(achieved * BLOCK / 1e9, 1),
             "frac": round(achieved / model_blocks_per_s, 4),
-            "note": "model = CUs x resident blocks x 4 symbols / cycles_per_iteration x clock (output bytes); measured with the in-kernel counters on "
-                    "(pass of %.2f ms; they cost a few per cent), clock = the device's maximum engine clock" % ms_timed}
+            "where_the_rest_goes": {
+                "workgroup_slots_occupied": round(slot_busy, 4) if slot_busy else None,
+                "workgroup_time_in_phases": round((t_run + t_wait) / max(life_cyc, 1), 4),
+                "workgroup_time_in_finishing_phases": round(t_fin / max(life_cyc, 1), 4),
+                "finishing_rounds_per_workgroup": round(n_fin / max(n_wg, 1), 1), "cycles_per_finishing_round": round(t_fin / max(n_fin, 1), 1),
+                "workgroup_time_setup": round(setup_cyc / max(life_cyc, 1), 4),
+                "workgroup_time_literal_tail": round(tail_cyc / max(life_cyc, 1), 4),
+                "decoder_wave_wait_frac": round(t_wait / max(t_run + t_wait, 1), 4),
+                "service_wave_busy_frac": round(s_busy / max(s_busy + s_idle, 1), 4)},
+            "note": "model = CUs x resident blocks x 4 symbols / cycles_per_iteration x clock (output bytes); cycles from s_memtime in the decoder wave around "
+                    "every phase of 16 iterations, clock = those cycles per tick of the constant 100 MHz counter over the workgroups' lifetimes; one untimed "
+                    "decode pass of %.2f ms with the counters on (FSEHIP_debug_decodeTiming; they cost a few per cent).  frac ~ slots occupied x time in "
+                    "phases: the rest is the idle tail of the last round of workgroups, table staging / reader set-up and the literal tails" % ms_timed}
+
 
 
 def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):

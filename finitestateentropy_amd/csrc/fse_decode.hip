@@ -56,6 +56,7 @@
 #define FSE_IN_LANES (FSE_IN_CHUNK / 4)
 #define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so reads of 2 dwords never wrap
 #define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
+#define FSE_FINISH_EVERY 2       // ... and per finishing phase of the bit-reversed loop (a ring slot pair holds two iterations)
 #ifndef FSE_SRV_WAVES
 #define FSE_SRV_WAVES 4
 #endif
@@ -65,7 +66,10 @@
 // every round of its phase loop with s_memtime and adds its totals to g_decTiming when the workgroup ends.  Off by default: the
 // launcher picks the TIMED kernel only between FSEHIP_debug_decodeTiming(1, ..) and (0, ..).
 //   [0] cycles of decoder-wave rounds in which some lane pair ran a phase, [1] cycles of rounds in which none could, [2] / [3] their
-//   numbers, [4] workgroups, [5] / [6] busy / idle cycles of the first service wave of every workgroup, [7] service rounds that did work
+//   numbers, [4] workgroups, [5] / [6] busy / idle cycles of the first service wave of every workgroup, [7] service rounds that did work,
+//   [11] lifetime of the workgroups' decoder waves in cycles and [12] in ticks of the constant 100 MHz clock (their ratio is the engine
+//   clock the kernel really ran at), [13] cycles from kernel entry to the first phase (table staging, reader set-up, first ring fill),
+//   [14] cycles from the last phase to the end (literal tail), [15] / [10] cycles / number of rounds that ran finishing phases only
 __device__ unsigned long long g_decTiming[16];
 static bool g_decTimingOn = false;
 #define TIMING(...) do { if constexpr (TIMED) { __VA_ARGS__ } } while (0)
@@ -153,13 +157,17 @@ DEV u32 dpp_swap_add(u32 v, u32 w) { return dpp_swap(v) + w; }
 // instruction selection helpers: keep the shapes the instruction count above relies on
 DEV u32 lshl_or(u32 v, u32 sh, u32 o) { u32 r; __asm__("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(sh), "v"(o)); return r; }   // (v << sh[4:0]) | o
 DEV u32 ring_dword(u32 P) { u32 r; __asm__("v_bfe_u32 %0, %1, 5, %2" : "=v"(r) : "v"(P), "n"(FSE_IN_RING_LOG - 2)); return r; }              // (P >> 5) mod ring dwords
-DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
+// PheadRef: the cursor at the head of the phase's LAST iteration (the reference's reader state between two loop-head reloads is
+// fixed by the bits unread at the last reload and the bits unread now: k_fse_decode rebuilds it from the two).
+template <int NITER>
+DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
 {
     u32 s = sMine, P = Pref;
     u32 prev = 0;
     __asm__ volatile("" : "+v"(myIn));                           // one register: the three window reads then differ by their immediate offsets
 #pragma unroll 8
-    for (int it = 0; it < FSE_CHECK_EVERY; ++it) {
+    for (int it = 0; it < NITER; ++it) {
+        if (it == NITER - 1) PheadRef = P;
         const u32 c = lds_cell(s);                               // lane A: state 1's cell, lane B: state 2's
         const lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (ring_dword(P) << 2));
         const u32 d0 = wp[0], d1 = wp[1], d2 = wp[2];
@@ -381,6 +389,9 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long tBorn = 0, wBorn = 0;
+    (void)tBorn; (void)wBorn;
+    TIMING(tBorn = __builtin_readcyclecounter(); wBorn = wall_clock64(););
     // slot g of this workgroup = entry first + g of the launch's block list (or simply block first + g)
     const size_t first = (size_t)blockIdx.x * a.G;
     // The one-shot path hands over a class's FSE_DBINS size-bin lists (internal.h), walked one after the other as if they were one
@@ -514,7 +525,24 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // (>= 16 output groups left and the window stays >= 24 bytes above the stream start: at >= 24 + 16*6), so the
     // 16 iterations of a phase run without any per-iteration bookkeeping; whatever is left goes to the literal tail.
     // Bulk state uses p = at+1, u = used+8 (u in [8,16) after a reload), so no shift amount is ever 0 or 32.
-    bool can = owner && r.at >= 24 + 6 * FSE_CHECK_EVERY + 8 && (omax - 3 - op + 3) / 4 >= FSE_CHECK_EVERY && S < (1ull << 28) && !((badMask >> gsl) & 1u);
+    // Which iterations may the bulk loop take?  A loop-head reload of the reference (lib/bitstream.h:400-439) that does not clamp leaves
+    // ptr = ceil(B/8) - 8 and bitsConsumed = 8*(ptr+8) - B, B = the bits unread at that moment, on the fast path (:405-409) and on
+    // the slow one (:428-438) alike.  With B' the bits unread at the PREVIOUS reload, it returns "unfinished" -- the loop of
+    // lib/fse_decompress.c:201 goes on -- iff the ptr it starts from is not the stream start (ceil(B'/8) - 8 >= 1: B' >= 65) and
+    // it need not clamp (ceil(B/8) >= 8: B >= 57); B >= 65 at every loop head is sufficient.  One iteration takes at most
+    // 4 * tableLog <= 48 bits, so a phase of N iterations is the reference's loop, iteration for iteration, if B >= 65 + 48*(N-1)
+    // at its start (and N groups of four bytes fit the output).  The bit-reversed loop runs phases of FSE_CHECK_EVERY iterations
+    // while it can and then FINISHING phases of two (FSE_FINISH_EVERY) down to B < 113: the literal path is left with the last
+    // two or three iterations and the reference's end game.  Between two reloads the reader state is (ptr of the last reload,
+    // bitsConsumed counted from it): rebuilt below from the cursor at the head of the last iteration and the cursor now.
+    // (The plain-cell loop keeps its coarser rule: window at least 24 bytes above the stream start.)
+    // unread bits of the payload after the two state reads (a stream of a few bytes has been read beyond its end by now: negative)
+    const bool bulkOk = owner && S < (1ull << 28) && !((badMask >> gsl) & 1u);
+    const int Bstart = bulkOk ? (int)(8u * ((u32)r.at + 8u)) - (int)r.used : 0;
+    const long groups0 = (omax - 3 - op + 3) / 4;
+    bool can = bulkOk && (FAST ? Bstart >= 65 + 48 * (FSE_CHECK_EVERY - 1) : r.at >= 24 + 6 * FSE_CHECK_EVERY + 8) && groups0 >= FSE_CHECK_EVERY;
+    bool can2 = FAST && bulkOk && Bstart >= 65 + 48 * (FSE_FINISH_EVERY - 1) && groups0 >= FSE_FINISH_EVERY;
+    const bool everBulk = can || can2;
     BulkState bs; bs.q = 0; bs.bq = 0;
     {   const u32 st = half ? s2 : s1;                                           // my state as a cell address
         bs.s = tabOff + 2u * (FAST ? __brev(st) >> (32u - (tl ? tl : 1u)) : st); }
@@ -527,7 +555,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     long groups = 0;
     u32 iters = 0;
     int validLo = 0;                                 // ring holds stream bytes [validLo, validLo + FSE_IN_RING)
-    if (can) {
+    if (everBulk) {
         const u32 B = 8u * ((u32)r.at + 8u + inA) - r.used;      // unread bits = bits [0, B) counted from the aligned base
         bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u; P = R8 - B;
         groups = (omax - 3 - op + 3) >> 2;
@@ -538,7 +566,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     }
     DecCtl* const ctl = ctlAll + (gsl < a.G ? gsl : 0);
     if (wave == 0 && gsl < a.G && half == 0) {
-        ctl->pubIters = 0; ctl->pubPofs = can ? bs.q + 8u : 0x80000000u;
+        ctl->pubIters = 0; ctl->pubPofs = everBulk ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S + inA : 0);
         const unsigned long long ib = (unsigned long long)(uintptr_t)(in - inA), ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)syms;
@@ -550,9 +578,11 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
     const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
-    unsigned long long tRun = 0, tWait = 0, nRun = 0, nWait = 0, tA = 0;
-    (void)tRun; (void)tWait; (void)nRun; (void)nWait; (void)tA;
+    unsigned long long tRun = 0, tWait = 0, nRun = 0, nWait = 0, tA = 0, tFin = 0, nFin = 0;
+    (void)tRun; (void)tWait; (void)nRun; (void)nWait; (void)tA; (void)tFin; (void)nFin;
     TIMING(tA = __builtin_readcyclecounter(););
+    const unsigned long long tBulk0 = tA;
+    (void)tBulk0;
     // The service's progress words are read one round ahead: the loads issued here are consumed at the top of the next
     // round, so their LDS round trip hides under this round's phase.  Stale values are conservative (srvFlushed only grows,
     // srvValidLo only falls); LDS operations of one wave execute in order, so the ring reads of a phase cannot overtake
@@ -560,42 +590,86 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     u32 rpos = 0;                                    // iters modulo the ring size
     u32 flNext = ctl_peek(&ctl->srvFlushed);
     int vloNext = ctl_peek(&ctl->srvValidLo);
-    while (__any(can)) {
+    const u32 inA8 = 8u * inA;
+    u32 Phead = P;                                   // bit-reversed loop: cursor at the head of the last iteration taken
+    while (__any(can)) {                             // ---- phases of FSE_CHECK_EVERY iterations
         const u32 fl = flNext;
         const int vlo = vloNext;
         flNext = ctl_peek(&ctl->srvFlushed);
         vloNext = ctl_peek(&ctl->srvValidLo);
-        // room for 16 more records, and the lowest byte this phase can read (p - 6*16 - 16) is in the ring
-        // (bit-reversed loop: 16 iterations of at most 44 bits, three window dwords below the last one -> 92 bytes below q + 8)
-        const bool ready = can && (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((int)bs.q - (FAST ? 84 : 6 * FSE_CHECK_EVERY + 8) >= vlo);
+        // room for 16 more records, and the lowest byte this phase can read is in the ring: its last iteration starts at most
+        // 15 * 48 bits further down (23 dwords) and reads the three dwords from there -> 92 bytes below q (plain loop: 6 bytes per
+        // iteration and a window of 8).  Nothing below the stream start is ever consumed: once the ring reaches down to it
+        // (validLo <= 0) the phase may run.
+        const int lowest = (int)bs.q - (FAST ? 92 : 6 * FSE_CHECK_EVERY + 8);
+        const bool ready = can && (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((lowest > 0 ? lowest : 0) >= vlo);
         if (ready) {
             uint2* const ring = myRing + rpos;                               // 16 consecutive slots: a phase never wraps
             rpos = rpos + FSE_CHECK_EVERY == FSE_DEC_RING ? 0u : rpos + FSE_CHECK_EVERY;
             if (FAST) {
-                fse_bulk_phase_rev(bs.s, P, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+                fse_bulk_phase_rev<FSE_CHECK_EVERY>(bs.s, P, Phead, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
                 const u32 B = R8 - P;
                 bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
             }
             else if (nb0) fse_bulk_phase<true>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
             else          fse_bulk_phase<false>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
             iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
-            // the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
-            can = bs.q >= 24u + 6u * FSE_CHECK_EVERY + 4u && groups >= FSE_CHECK_EVERY;     // (+4: q counts from the aligned base)
+            if (FAST) {
+                const u32 Bp = R8 - P - inA8;                                 // unread bits of the payload proper
+                can = Bp >= 65u + 48u * (FSE_CHECK_EVERY - 1) && groups >= FSE_CHECK_EVERY;
+                can2 = Bp >= 65u + 48u * (FSE_FINISH_EVERY - 1) && groups >= FSE_FINISH_EVERY;
+            }
+            // plain loop: the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
+            else can = bs.q >= 24u + 6u * FSE_CHECK_EVERY + 4u && groups >= FSE_CHECK_EVERY;     // (+4: q counts from the aligned base)
             if (half == 0) {
                 ctl_store(&ctl->pubIters, iters);
-                ctl_store(&ctl->pubPofs, can ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+                ctl_store(&ctl->pubPofs, (can | can2) ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
             }
         }
         TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB;);
         if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
     }
-    TIMING(if (lane == 0) { atomicAdd(&g_decTiming[0], tRun); atomicAdd(&g_decTiming[1], tWait); atomicAdd(&g_decTiming[2], nRun); atomicAdd(&g_decTiming[3], nWait); atomicAdd(&g_decTiming[4], 1ull); });
+    if (FAST) while (__any(can2)) {                  // ---- finishing phases of FSE_FINISH_EVERY iterations (every lane is through with the long ones)
+        const u32 fl = flNext;
+        const int vlo = vloNext;
+        flNext = ctl_peek(&ctl->srvFlushed);
+        vloNext = ctl_peek(&ctl->srvValidLo);
+        const int lowest = (int)bs.q - 8;                                    // the second iteration's window starts at most two dwords further down
+        const bool ready = can2 && (iters + FSE_FINISH_EVERY - fl <= FSE_DEC_RING) && ((lowest > 0 ? lowest : 0) >= vlo);
+        if (ready) {
+            uint2* const ring = myRing + rpos;
+            rpos = rpos + FSE_FINISH_EVERY == FSE_DEC_RING ? 0u : rpos + FSE_FINISH_EVERY;
+            fse_bulk_phase_rev<FSE_FINISH_EVERY>(bs.s, P, Phead, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+            const u32 B = R8 - P;
+            bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
+            iters += FSE_FINISH_EVERY; groups -= FSE_FINISH_EVERY;
+            can2 = B - inA8 >= 65u + 48u * (FSE_FINISH_EVERY - 1) && groups >= FSE_FINISH_EVERY;
+            if (half == 0) {
+                ctl_store(&ctl->pubIters, iters);
+                ctl_store(&ctl->pubPofs, can2 ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+            }
+        }
+        TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tFin += tB - tA; ++nFin; } else { tWait += tB - tA; ++nWait; } tA = tB;);
+        if (!__any(ready)) __builtin_amdgcn_s_sleep(1);
+    }
+    TIMING(if (lane == 0) { atomicAdd(&g_decTiming[0], tRun); atomicAdd(&g_decTiming[1], tWait); atomicAdd(&g_decTiming[2], nRun); atomicAdd(&g_decTiming[3], nWait); atomicAdd(&g_decTiming[4], 1ull);
+                            atomicAdd(&g_decTiming[13], tBulk0 - tBorn); atomicAdd(&g_decTiming[15], tFin); atomicAdd(&g_decTiming[10], nFin); });
     const u32 sOther = dpp_swap(bs.s);               // (all lanes of the wave are still here)
-    if (!owner || half) return;
+    const unsigned long long tBulk1 = tA;
+    (void)tBulk1;
+    if (!owner || half) {
+        // (lane 1 leaves here at once: the wave itself lives until its even lanes are through their tails, so the wave's lifetime is
+        //  taken by lane 0, below, when it has a block; workgroups whose slot 0 is empty are rare and not counted)
+        return;
+    }
     op = 4 * (long)iters;
-    if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container) after a reload
+    if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container)
         const u32 B = 8u * (bs.q + 8u) + bs.bq - 8u * inA;      // back to bits of the payload proper
-        r.at = (size_t)((B + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s - tabOff) >> 1; s2 = (sOther - tabOff) >> 1;
+        // bit-reversed loop: ptr is where the reload at the head of the last iteration put it (B there >= 65), bitsConsumed counts from it
+        // (up to 7 + 48); plain loop: the state after a reload (it stops where every reload is still the fast one, and a reload of a
+        // reloaded reader changes nothing)
+        const u32 Bh = FAST ? R8 - Phead - 8u * inA : B;
+        r.at = (size_t)((Bh + 7u) >> 3) - 8; r.used = 8u * ((u32)r.at + 8u) - B; r.win = ldg64u(in + r.at); s1 = (bs.s - tabOff) >> 1; s2 = (sOther - tabOff) >> 1;
         if (FAST) { s1 = __brev(s1) >> (32u - tl); s2 = __brev(s2) >> (32u - tl); }
     }
 
@@ -605,6 +679,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     else if (compact) result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
     else         result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
+    TIMING(if (lane == 0) { const unsigned long long tE = __builtin_readcyclecounter(); atomicAdd(&g_decTiming[11], tE - tBorn); atomicAdd(&g_decTiming[12], wall_clock64() - wBorn);
+                            atomicAdd(&g_decTiming[14], tE - tBulk1); });
 }
 
 static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)
@@ -662,7 +738,7 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decodeTiming(
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
     unsigned slot; int G;
     fse_decode_geometry(FSE_DEC_FAST_MAXLOG, FSE_DEC_LDS, &slot, &G);
-    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G; out16[10] = 2;
+    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G;
     return 0;
 }
 
