@@ -375,7 +375,7 @@ def secondary_roofline(hip, cd, dev_info):
     L.FSEHIP_debug_decodeTiming(0, buf)
     t_run, t_wait, n_run, n_wait, n_wg, s_busy, s_idle, n_srv, clock_khz, blocks_per_wg, n_fin = [int(buf[i]) for i in range(11)]
     life_cyc, life_ticks, setup_cyc, tail_cyc, t_fin = [int(buf[i]) for i in range(11, 16)]
-    wgs_per_cu = 2
+    wgs_per_cu, dec_waves = max((blocks_per_wg >> 32) & 0xFF, 1), max(blocks_per_wg >> 40, 1); blocks_per_wg &= 0xFFFFFFFF
     if n_run == 0:
         return None
     nb = cd.src.shape[0]
@@ -387,7 +387,7 @@ def secondary_roofline(hip, cd, dev_info):
     model_blocks_per_s = cus * resident / (BLOCK / 4.0 * cyc_iter / clock)
     ms_timed = pms[KERNEL_NAMES.index("k_fse_decode")]               # the instrumented kernel's own duration in that pass
     achieved = nb / (ms_timed * 1e-3)
-    slots = cus * wgs_per_cu
+    slots = cus * wgs_per_cu * dec_waves                                   # decoder waves resident on the device (each reports its lifetime)
     slot_busy = (life_ticks / 1e8) / (ms_timed * 1e-3 * slots) if life_ticks else None
     return {"bound": "chain latency x LDS-resident blocks", "kernel": "k_fse_decode",
             "resident_blocks_per_cu": resident, "cycles_per_iteration": round(cyc_iter, 1), "symbols_per_iteration": 4,

@@ -57,10 +57,21 @@
 #define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so reads of 2 dwords never wrap
 #define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
 #define FSE_FINISH_EVERY 2       // ... and per finishing phase of the bit-reversed loop (a ring slot pair holds two iterations)
-#ifndef FSE_SRV_WAVES
-#define FSE_SRV_WAVES 4
+// Workgroup geometry.  A CU's LDS (160 KB) is what bounds the blocks in flight; ONE workgroup per CU over all of it holds 33 blocks
+// with 4 KiB tables (4944 bytes each) where two workgroups of 80 KB hold 2 x 16.  FSE_DEC_WAVES decoder waves share the lane pairs
+// (17 + 16), FSE_SRV_WAVES service waves look after four blocks each.  (FSE_DEC_LDS_KB 80 / FSE_DEC_WAVES 1 / FSE_SRV_WAVES 4 is the
+// earlier two-workgroups-per-CU layout, kept buildable for A/B runs: make B=variants/wg80 EXTRA="-DFSE_DEC_LDS_KB=80 ...".)
+#ifndef FSE_DEC_LDS_KB
+#define FSE_DEC_LDS_KB 160
 #endif
-#define FSE_MAXG (4 * FSE_SRV_WAVES)              // blocks per workgroup at most (FSE_SRV_WAVES x FSE_SRV_G; the LDS holds 16 with 4 KiB tables)
+#ifndef FSE_DEC_WAVES
+#define FSE_DEC_WAVES 2
+#endif
+#ifndef FSE_SRV_WAVES
+#define FSE_SRV_WAVES 9
+#endif
+#define FSE_MAXG (4 * FSE_SRV_WAVES)              // blocks per workgroup at most (FSE_SRV_WAVES x FSE_SRV_G)
+#define FSE_WGS_PER_CU (160 / FSE_DEC_LDS_KB)
 
 // Cycle accounting of the decoder and service waves (bench.py's `roofline.secondary`): the TIMED instantiation of the kernel brackets
 // every round of its phase loop with s_memtime and adds its totals to g_decTiming when the workgroup ends.  Off by default: the
@@ -199,7 +210,7 @@ struct DecCtl {
     int S32;
     u32 inLo, inHi, outLo, outHi, symLo, symHi;
 };
-#define FSE_DEC_THREADS (64 * (1 + FSE_SRV_WAVES))     // wave 0 decodes, the others serve
+#define FSE_DEC_THREADS (64 * (FSE_DEC_WAVES + FSE_SRV_WAVES))     // waves 0 .. FSE_DEC_WAVES-1 decode, the others serve
 
 DEV u32 ctl_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -428,10 +439,25 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             // its LDS image.  Every load is issued before the first store (a lone copy loop would pay the memory latency once
             // per table).
             const size_t nTab = nTot - first < (size_t)a.G ? nTot - first : (size_t)a.G;
+            if (tabStride >= 1024u) {
+                // LDS-DMA: a wave instruction moves 64 x 16 bytes from per-lane global addresses to 1 KiB of consecutive LDS -- no
+                // registers, no LDS store pass; the pieces of all tables are dealt round the waves of the workgroup and are in
+                // flight together (drained by the s_waitcnt vmcnt(0) in front of the barrier below)
+                const u32 ppt = tabStride >> 10;                                 // 1 KiB pieces per table
+                const u32 nPieces = (u32)nTab * ppt;
+                for (u32 p = (u32)wave; p < nPieces; p += FSE_DEC_THREADS / 64) {
+                    const u32 g = p / ppt, k = p - g * ppt;
+                    const size_t bi = slotBlock(g);
+                    const u8* const src = (const u8*)(a.atab + (bi << a.maxTableLog)) + 1024u * k + 16u * (u32)lane;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds8 + 1024u * p), 16, 0, 0);
+                }
+            }
+            else {
             uint4* const dstv = (uint4*)lds8;
             const u32 vptLog = a.ldsLog - 3u;                            // 16-byte vectors per table: tabStride / 16
             const u32 nvec = (u32)nTab << vptLog;
-            constexpr u32 MAXV = (80u * 1024u / 16u + FSE_DEC_THREADS - 1) / FSE_DEC_THREADS;
+            constexpr u32 MAXV = (FSE_MAXG * 512u / 16u + FSE_DEC_THREADS - 1) / FSE_DEC_THREADS;      // (tables of 512 bytes at most here)
             uint4 buf[MAXV];
 #pragma unroll
             for (u32 k = 0; k < MAXV; ++k) {
@@ -444,6 +470,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             }
 #pragma unroll
             for (u32 k = 0; k < MAXV; ++k) { const u32 idx = tid + k * FSE_DEC_THREADS; if (idx < nvec) dstv[idx] = buf[k]; }
+            }
             if (!FAST) for (size_t g = 0; g < nTab; ++g) {                 // a cell with nbBits == 0 needs a counter > tableSize/2
                 const u32 st = a.meta[slotBlock(g)].state; anyNb0 |= st != 0 && !(st & 2u); }
         }
@@ -470,17 +497,21 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         if (badBits) atomicOr(&flagsSh[0], badBits);
         if (anyNb0) atomicOr(&flagsSh[1], 1u);
     }
+    __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the LDS-DMA pieces have landed (lgkmcnt / expcnt fields left at their maxima)
     __syncthreads();
     const u32 badMask = flagsSh[0];
     const bool nb0 = flagsSh[1] != 0;
 
     // ---- per-block set-up by the decoder wave: lanes 2g and 2g+1 walk block first+g together and both run this set-up
     //      (identical values in both; only the even lane publishes, finishes the block and writes its result)
-    const int gsl = lane >> 1;
+    //      (decoder wave w takes the slots [w * ppw, (w+1) * ppw))
+    const int ppw = (a.G + FSE_DEC_WAVES - 1) / FSE_DEC_WAVES;
+    const bool decWave = wave < FSE_DEC_WAVES;
+    const int gsl = (decWave ? wave * ppw : 0) + (lane >> 1);
     const u32 half = (u32)lane & 1u, maskB = half ? ~0u : 0u;
-    const bool inRange = gsl < a.G && first + (size_t)gsl < nTot;
+    const bool inRange = (lane >> 1) < ppw && gsl < a.G && first + (size_t)gsl < nTot;
     const size_t b = inRange ? slotBlock((size_t)gsl) : 0;
-    bool owner = wave == 0 && inRange;
+    bool owner = decWave && inRange;
     u32 hdr = 0;
     if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
     u32 tl = 0; bool fast = false;
@@ -565,7 +596,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         validLo = (((int)bs.q + 8 - 112 - c0) & ~(FSE_IN_CHUNK - 1)) + c0;   // the ring then reaches from below q - 104 up to above q + 12
     }
     DecCtl* const ctl = ctlAll + (gsl < a.G ? gsl : 0);
-    if (wave == 0 && gsl < a.G && half == 0) {
+    if (decWave && (lane >> 1) < ppw && gsl < a.G && half == 0) {
         ctl->pubIters = 0; ctl->pubPofs = everBulk ? bs.q + 8u : 0x80000000u;
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S + inA : 0);
@@ -573,7 +604,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
     }
     __syncthreads();
-    if (wave >= 1) { fse_decode_service<TIMED>(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - 1) * FSE_SRV_G, FAST); return; }
+    if (!decWave) { fse_decode_service<TIMED>(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - FSE_DEC_WAVES) * FSE_SRV_G, FAST); return; }
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
@@ -690,13 +721,13 @@ static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slot
     if (g > FSE_MAXG) g = FSE_MAXG;
     *G = g;
 }
-#define FSE_DEC_LDS (80 * 1024)   // two workgroups per CU (measured: 2 x 80 KiB are co-resident on gfx950)
+#define FSE_DEC_LDS (FSE_DEC_LDS_KB * 1024)
 size_t fse_decode_blocks_per_round(unsigned maxTableLog)
 {
     unsigned slot; int G;
     fse_decode_geometry(maxTableLog < FSE_DEC_FAST_MAXLOG ? maxTableLog : FSE_DEC_FAST_MAXLOG, FSE_DEC_LDS, &slot, &G);   // the common class
     const int cus = dev_props().ok ? dev_props().cus : 256;
-    return (size_t)G * 2 * cus;
+    return (size_t)G * FSE_WGS_PER_CU * cus;
 }
 
 static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
@@ -738,7 +769,7 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decodeTiming(
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
     unsigned slot; int G;
     fse_decode_geometry(FSE_DEC_FAST_MAXLOG, FSE_DEC_LDS, &slot, &G);
-    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G;
+    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G | ((unsigned long long)FSE_WGS_PER_CU << 32) | ((unsigned long long)FSE_DEC_WAVES << 40);
     return 0;
 }
 
