@@ -375,11 +375,13 @@ def secondary_roofline(hip, cd, dev_info):
     L.FSEHIP_debug_decodeTiming(0, buf)
     t_run, t_wait, n_run, n_wait, n_wg, s_busy, s_idle, n_srv, clock_khz, blocks_per_wg, n_fin = [int(buf[i]) for i in range(11)]
     life_cyc, life_ticks, setup_cyc, tail_cyc, t_fin = [int(buf[i]) for i in range(11, 16)]
-    wgs_per_cu, dec_waves = max((blocks_per_wg >> 32) & 0xFF, 1), max(blocks_per_wg >> 40, 1); blocks_per_wg &= 0xFFFFFFFF
+    wgs_per_cu, dec_waves, per_phase = max((blocks_per_wg >> 32) & 0xFF, 1), max((blocks_per_wg >> 40) & 0xFF, 1), max(blocks_per_wg >> 48, 1)
+    blocks_per_wg &= 0xFFFFFFFF
+    t_inner = n_srv
     if n_run == 0:
         return None
     nb = cd.src.shape[0]
-    cyc_iter = t_run / (n_run * 16.0)
+    cyc_iter = t_run / (n_run * float(per_phase))
     cus = dev_info["cus"]
     resident = blocks_per_wg * wgs_per_cu
     nominal = clock_khz * 1e3
@@ -391,6 +393,7 @@ def secondary_roofline(hip, cd, dev_info):
     slot_busy = (life_ticks / 1e8) / (ms_timed * 1e-3 * slots) if life_ticks else None
     return {"bound": "chain latency x LDS-resident blocks", "kernel": "k_fse_decode",
             "resident_blocks_per_cu": resident, "cycles_per_iteration": round(cyc_iter, 1), "symbols_per_iteration": 4,
+            "cycles_per_iteration_inside_the_phase": round(t_inner / (n_run * float(per_phase)), 1), "iterations_per_phase": per_phase,
             "clock_GHz": round(clock / 1e9, 3), "nominal_clock_GHz": round(nominal / 1e9, 3),
             "model_GBps": round(model_blocks_per_s * BLOCK / 1e9, 1), "achieved_GBps": round(achieved * BLOCK / 1e9, 1),
             "frac": round(achieved / model_blocks_per_s, 4),

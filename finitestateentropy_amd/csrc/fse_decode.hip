@@ -55,7 +55,12 @@
 #define FSE_IN_CHUNK 64          // refill granule: one 4-byte load per lane of a 16-lane group (one group per block of a service wave)
 #define FSE_IN_LANES (FSE_IN_CHUNK / 4)
 #define FSE_IN_MIRROR 16         // the first bytes are mirrored behind the ring so reads of 2 dwords never wrap
+#ifndef FSE_CHECK_EVERY
 #define FSE_CHECK_EVERY 16       // bulk iterations per phase (<= 6 bytes consumed per iteration)
+#endif
+#ifndef FSE_PHASE_UNROLL
+#define FSE_PHASE_UNROLL 16      // the phase is straight-line code: with an inner loop the compiler shuffles every loop-carried register of the
+#endif                           // round through copies at each loop header (measured in instructions per round, see DESIGN)
 #define FSE_FINISH_EVERY 2       // ... and per finishing phase of the bit-reversed loop (a ring slot pair holds two iterations)
 // Workgroup geometry.  A CU's LDS (160 KB) is what bounds the blocks in flight; ONE workgroup per CU over all of it holds 33 blocks
 // with 4 KiB tables (4944 bytes each) where two workgroups of 80 KB hold 2 x 16.  FSE_DEC_WAVES decoder waves share the lane pairs
@@ -176,7 +181,7 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
     u32 s = sMine, P = Pref;
     u32 prev = 0;
     __asm__ volatile("" : "+v"(myIn));                           // one register: the three window reads then differ by their immediate offsets
-#pragma unroll 8
+#pragma unroll FSE_PHASE_UNROLL
     for (int it = 0; it < NITER; ++it) {
         if (it == NITER - 1) PheadRef = P;
         const u32 c = lds_cell(s);                               // lane A: state 1's cell, lane B: state 2's
@@ -217,6 +222,12 @@ DEV int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, _
 DEV u32 ctl_peek(const u32* p) { const u32 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __asm__ volatile("" ::: "memory"); return v; }
 DEV int ctl_peek(const int* p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __asm__ volatile("" ::: "memory"); return v; }
 DEV void ctl_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// two neighbouring control words as one LDS access (8-byte aligned pairs of DecCtl): the decoder publishes {pubIters, pubPofs} with ONE
+// release store and reads {srvFlushed, srvValidLo} with one load -- every LDS instruction and every s_waitcnt between two phases is paid
+// by all the chains of the decoder wave
+DEV u64 ctl_load2(const u32* p) { return __hip_atomic_load((const u64*)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV u64 ctl_peek2(const u32* p) { const u64 v = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __asm__ volatile("" ::: "memory"); return v; }
+DEV void ctl_store2(u32* p, u32 lo, u32 hi) { __hip_atomic_store((u64*)p, (u64)lo | ((u64)hi << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- service waves: keep the input rings filled and turn state-ring records into output bytes, so that the decoder
@@ -231,6 +242,7 @@ DEV void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, _
 #define FSE_FLUSH_MIN 32u        // records (of 4 symbols) a block must have before its row is flushed
 #endif
 static_assert(FSE_SRV_WAVES * FSE_SRV_G == FSE_MAXG, "every block of a workgroup has a service wave");
+static_assert((FSE_DEC_RING & (FSE_DEC_RING - 1)) == 0 && FSE_DEC_RING % FSE_CHECK_EVERY == 0, "ring positions wrap by masking; a phase never wraps");
 DEV void fse_ring_put(u32* rg, int off, u32 w)
 {
     const u32 j = (u32)off & (FSE_IN_RING - 1);
@@ -289,7 +301,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
     for (;;) {
         // snapshot of the decoder's progress (the finished flag is read before the iteration count it guards)
         u32 pp = 0x80000000u, it = flushed;
-        if (live) { pp = ctl_load(&ctl->pubPofs); it = ctl_load(&ctl->pubIters); }
+        if (live) { const u64 pub = ctl_load2(&ctl->pubIters); it = (u32)pub; pp = (u32)(pub >> 32); }     // (published together: the count is final when the flag is set)
         const bool fin = (pp >> 31) != 0;
         const int P = (int)(pp & 0x7FFFFFFFu);               // byte offset of the topmost dword the decoder still reads
         const u32 avail = it - flushed;
@@ -348,7 +360,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         if (wantFlush) { fpos += it - flushed; fpos = fpos >= FSE_DEC_RING ? fpos - FSE_DEC_RING : fpos; flushed = it; }
         TIMING(const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy;);
     }
-    TIMING(if (lane == 0 && g0 == 0) { atomicAdd(&g_decTiming[5], sBusy); atomicAdd(&g_decTiming[6], sIdle); atomicAdd(&g_decTiming[7], nBusy); });
+    TIMING(if (lane == 0 && g0 == 0) { atomicAdd(&g_decTiming[5], sBusy); atomicAdd(&g_decTiming[6], sIdle); });
 }
 
 // cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
@@ -609,8 +621,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
     const u32 myIn = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + inOff);   // absolute LDS address of my input ring
-    unsigned long long tRun = 0, tWait = 0, nRun = 0, nWait = 0, tA = 0, tFin = 0, nFin = 0;
-    (void)tRun; (void)tWait; (void)nRun; (void)nWait; (void)tA; (void)tFin; (void)nFin;
+    unsigned long long tRun = 0, tWait = 0, nRun = 0, nWait = 0, tA = 0, tFin = 0, nFin = 0, tInner = 0;
+    (void)tRun; (void)tWait; (void)nRun; (void)nWait; (void)tA; (void)tFin; (void)nFin; (void)tInner;
     TIMING(tA = __builtin_readcyclecounter(););
     const unsigned long long tBulk0 = tA;
     (void)tBulk0;
@@ -619,72 +631,69 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // srvValidLo only falls); LDS operations of one wave execute in order, so the ring reads of a phase cannot overtake
     // the progress loads they depend on (the compiler is held back by the barrier in ctl_peek).
     u32 rpos = 0;                                    // iters modulo the ring size
-    u32 flNext = ctl_peek(&ctl->srvFlushed);
-    int vloNext = ctl_peek(&ctl->srvValidLo);
+    u64 srvNext = ctl_peek2(&ctl->srvFlushed);       // {srvFlushed, srvValidLo}
     const u32 inA8 = 8u * inA;
     u32 Phead = P;                                   // bit-reversed loop: cursor at the head of the last iteration taken
+    // Everything between two phases is paid by all chains of the wave (a wave issues an instruction per ~8 cycles whatever it
+    // does), so the round is kept short: one LDS load, one LDS store, 32-bit counters, one wave vote.
+    int grp = groups > (1 << 30) ? (1 << 30) : (int)groups;                 // groups of four output bytes that fit (beyond 2^30: the literal path goes on)
     while (__any(can)) {                             // ---- phases of FSE_CHECK_EVERY iterations
-        const u32 fl = flNext;
-        const int vlo = vloNext;
-        flNext = ctl_peek(&ctl->srvFlushed);
-        vloNext = ctl_peek(&ctl->srvValidLo);
+        const u32 fl = (u32)srvNext;
+        const int vlo = (int)(u32)(srvNext >> 32);
+        srvNext = ctl_peek2(&ctl->srvFlushed);
         // room for 16 more records, and the lowest byte this phase can read is in the ring: its last iteration starts at most
         // 15 * 48 bits further down (23 dwords) and reads the three dwords from there -> 92 bytes below q (plain loop: 6 bytes per
         // iteration and a window of 8).  Nothing below the stream start is ever consumed: once the ring reaches down to it
         // (validLo <= 0) the phase may run.
-        const int lowest = (int)bs.q - (FAST ? 92 : 6 * FSE_CHECK_EVERY + 8);
-        const bool ready = can && (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) && ((lowest > 0 ? lowest : 0) >= vlo);
+        const int lowest = (int)bs.q - (FAST ? 4 * ((48 * (FSE_CHECK_EVERY - 1) + 31) / 32) : 6 * FSE_CHECK_EVERY + 8);
+        // (bitwise &: ONE divergent branch per round -- the compiler turns && chains into nested branches with a copy of every
+        //  loop-carried register at each level)
+        const bool ready = can & (iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) & ((lowest > 0 ? lowest : 0) >= vlo);
         if (ready) {
             uint2* const ring = myRing + rpos;                               // 16 consecutive slots: a phase never wraps
-            rpos = rpos + FSE_CHECK_EVERY == FSE_DEC_RING ? 0u : rpos + FSE_CHECK_EVERY;
+            rpos = (rpos + FSE_CHECK_EVERY) & (FSE_DEC_RING - 1);
             if (FAST) {
+                unsigned long long tI = 0; (void)tI;
+                TIMING(tI = __builtin_readcyclecounter(););
                 fse_bulk_phase_rev<FSE_CHECK_EVERY>(bs.s, P, Phead, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+                TIMING(tInner += __builtin_readcyclecounter() - tI;);
                 const u32 B = R8 - P;
                 bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
             }
             else if (nb0) fse_bulk_phase<true>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
             else          fse_bulk_phase<false>(bs.s, bs.q, bs.bq, tabOff, myIn, half, maskB, ring);
-            iters += FSE_CHECK_EVERY; groups -= FSE_CHECK_EVERY;
+            iters += FSE_CHECK_EVERY; grp -= FSE_CHECK_EVERY;
             if (FAST) {
                 const u32 Bp = R8 - P - inA8;                                 // unread bits of the payload proper
-                can = Bp >= 65u + 48u * (FSE_CHECK_EVERY - 1) && groups >= FSE_CHECK_EVERY;
-                can2 = Bp >= 65u + 48u * (FSE_FINISH_EVERY - 1) && groups >= FSE_FINISH_EVERY;
+                can = (Bp >= 65u + 48u * (FSE_CHECK_EVERY - 1)) & (grp >= FSE_CHECK_EVERY);
+                can2 = (Bp >= 65u + 48u * (FSE_FINISH_EVERY - 1)) & (grp >= FSE_FINISH_EVERY);
             }
             // plain loop: the reference's ptr offset after its next reload is >= 4*dp - 8 = q: keep 16 more fast reloads certain
-            else can = bs.q >= 24u + 6u * FSE_CHECK_EVERY + 4u && groups >= FSE_CHECK_EVERY;     // (+4: q counts from the aligned base)
-            if (half == 0) {
-                ctl_store(&ctl->pubIters, iters);
-                ctl_store(&ctl->pubPofs, (can | can2) ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
-            }
+            else can = (bs.q >= 24u + 6u * FSE_CHECK_EVERY + 4u) & (grp >= FSE_CHECK_EVERY);     // (+4: q counts from the aligned base)
+            if (half == 0) ctl_store2(&ctl->pubIters, iters, (can | can2) ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
         }
         TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB;);
-        if (!__any(ready)) __builtin_amdgcn_s_sleep(2);
     }
     if (FAST) while (__any(can2)) {                  // ---- finishing phases of FSE_FINISH_EVERY iterations (every lane is through with the long ones)
-        const u32 fl = flNext;
-        const int vlo = vloNext;
-        flNext = ctl_peek(&ctl->srvFlushed);
-        vloNext = ctl_peek(&ctl->srvValidLo);
+        const u32 fl = (u32)srvNext;
+        const int vlo = (int)(u32)(srvNext >> 32);
+        srvNext = ctl_peek2(&ctl->srvFlushed);
         const int lowest = (int)bs.q - 8;                                    // the second iteration's window starts at most two dwords further down
-        const bool ready = can2 && (iters + FSE_FINISH_EVERY - fl <= FSE_DEC_RING) && ((lowest > 0 ? lowest : 0) >= vlo);
+        const bool ready = can2 & (iters + FSE_FINISH_EVERY - fl <= FSE_DEC_RING) & ((lowest > 0 ? lowest : 0) >= vlo);
         if (ready) {
             uint2* const ring = myRing + rpos;
-            rpos = rpos + FSE_FINISH_EVERY == FSE_DEC_RING ? 0u : rpos + FSE_FINISH_EVERY;
+            rpos = (rpos + FSE_FINISH_EVERY) & (FSE_DEC_RING - 1);
             fse_bulk_phase_rev<FSE_FINISH_EVERY>(bs.s, P, Phead, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
             const u32 B = R8 - P;
             bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
-            iters += FSE_FINISH_EVERY; groups -= FSE_FINISH_EVERY;
-            can2 = B - inA8 >= 65u + 48u * (FSE_FINISH_EVERY - 1) && groups >= FSE_FINISH_EVERY;
-            if (half == 0) {
-                ctl_store(&ctl->pubIters, iters);
-                ctl_store(&ctl->pubPofs, can2 ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
-            }
+            iters += FSE_FINISH_EVERY; grp -= FSE_FINISH_EVERY;
+            can2 = (B - inA8 >= 65u + 48u * (FSE_FINISH_EVERY - 1)) & (grp >= FSE_FINISH_EVERY);
+            if (half == 0) ctl_store2(&ctl->pubIters, iters, can2 ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
         }
         TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tFin += tB - tA; ++nFin; } else { tWait += tB - tA; ++nWait; } tA = tB;);
-        if (!__any(ready)) __builtin_amdgcn_s_sleep(1);
     }
     TIMING(if (lane == 0) { atomicAdd(&g_decTiming[0], tRun); atomicAdd(&g_decTiming[1], tWait); atomicAdd(&g_decTiming[2], nRun); atomicAdd(&g_decTiming[3], nWait); atomicAdd(&g_decTiming[4], 1ull);
-                            atomicAdd(&g_decTiming[13], tBulk0 - tBorn); atomicAdd(&g_decTiming[15], tFin); atomicAdd(&g_decTiming[10], nFin); });
+                            atomicAdd(&g_decTiming[13], tBulk0 - tBorn); atomicAdd(&g_decTiming[15], tFin); atomicAdd(&g_decTiming[10], nFin); atomicAdd(&g_decTiming[7], tInner); });
     const u32 sOther = dpp_swap(bs.s);               // (all lanes of the wave are still here)
     const unsigned long long tBulk1 = tA;
     (void)tBulk1;
@@ -769,7 +778,7 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decodeTiming(
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
     unsigned slot; int G;
     fse_decode_geometry(FSE_DEC_FAST_MAXLOG, FSE_DEC_LDS, &slot, &G);
-    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G | ((unsigned long long)FSE_WGS_PER_CU << 32) | ((unsigned long long)FSE_DEC_WAVES << 40);
+    out16[8] = (unsigned long long)khz; out16[9] = (unsigned long long)G | ((unsigned long long)FSE_WGS_PER_CU << 32) | ((unsigned long long)FSE_DEC_WAVES << 40) | ((unsigned long long)FSE_CHECK_EVERY << 48);
     return 0;
 }
 

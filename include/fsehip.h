@@ -241,8 +241,9 @@ FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
 /* Cycle accounting inside the FSE decoder (the bound that actually holds for it is chain latency x LDS-resident blocks, not HBM):
  * between (1, NULL) and (0, out16) the one-shot FSE decompressor runs an instrumented instantiation of its hot-loop kernel.
  * out16: [0] cycles of decoder-wave rounds that ran a phase of 16 iterations (4 symbols each), [1] cycles of rounds that waited,
- * [2] / [3] their numbers, [4] workgroups, [5] / [6] busy / idle cycles of one service wave per workgroup, [7] its working rounds,
- * [8] engine clock in kHz, [9] blocks per workgroup | workgroups per CU << 32 | decoder waves per workgroup << 40, [10] rounds of finishing phases (two iterations) and
+ * [2] / [3] their numbers, [4] workgroups, [5] / [6] busy / idle cycles of one service wave per workgroup, [7] cycles inside the phases proper (without the
+ * bookkeeping between them),
+ * [8] engine clock in kHz, [9] blocks per workgroup | workgroups per CU << 32 | decoder waves per workgroup << 40 | iterations per phase << 48, [10] rounds of finishing phases (two iterations) and
  * [15] their cycles, [11] / [12] lifetime of the decoder waves in cycles / in ticks of the constant 100 MHz clock, [13] cycles before
  * the first phase (set-up), [14] cycles after the last (literal tail).  Synchronises the device; for benchmarks only. */
 FSEHIP_API int FSEHIP_debug_decodeTiming(int enable, unsigned long long* out16);
