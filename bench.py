@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
     ap.add_argument("--parity-blocks", type=int, default=8192, help="strided blocks whose encoder bytes are compared with the CPU reference (untimed)")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pinned-host H2D + kernels + D2H figure")
+    ap.add_argument("--plain", action="store_true", help="profiler runs (scripts/profile.sh): warm-up + timed steps only -- no event-probe pass, no instrumented "
+                                                          "decode pass, no host-inclusive / CPU legs -- so that every kernel is launched exactly warmup + steps times")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=32768)
     ap.add_argument("--cpu-seconds", type=float, default=1.0, help="minimum timed seconds per direction and repetition")
@@ -254,6 +256,9 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
                         "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
 
 
+PLAIN = False          # --plain: see parse()
+
+
 def run_case(hip, codecs, steps, warmup, barrier, rank, check=True, n_check=8192):
     """time `steps` steps (each: encode + decode of every codec in `codecs`), bracketed by barrier + synchronize, with the
     kernel probe OFF; then the same steps once more with every launch of the library bracketed by HIP events on its stream
@@ -274,15 +279,17 @@ def run_case(hip, codecs, steps, warmup, barrier, rank, check=True, n_check=8192
     barrier()
     elapsed = time.perf_counter() - t0
     # probe pass (not part of `value`)
-    hip.lib.FSEHIP_probe_begin()
-    t1 = time.perf_counter()
-    for _ in range(steps):
-        for cd in codecs:
-            cd.encode(); cd.decode()
-    barrier()
-    probe_elapsed = time.perf_counter() - t1
     ms = (C.c_double * 16)(); launches = (C.c_uint * 16)()
-    hip.lib.FSEHIP_probe_collect(ms, launches)
+    probe_elapsed = 0.0
+    if not PLAIN:
+        hip.lib.FSEHIP_probe_begin()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            for cd in codecs:
+                cd.encode(); cd.decode()
+        barrier()
+        probe_elapsed = time.perf_counter() - t1
+        hip.lib.FSEHIP_probe_collect(ms, launches)
     enc_s = {cd.name: 0.0 for cd in codecs}; dec_s = {cd.name: 0.0 for cd in codecs}
     k = 1
     for _ in range(steps):
@@ -415,6 +422,8 @@ def secondary_roofline(hip, cd, dev_info):
 
 def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     hot = [k for k in HOT[codec_name] if k in per]
+    if not hot:                                                   # --plain: no event probe ran
+        return {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     dom = max(hot, key=lambda k: per[k][0])
     dom_ms, dom_launches = per[dom]
     alg = BLOCK + mean_csize                                      # read input once + write output once
@@ -442,7 +451,7 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     return out
 
 
-def summarize(r, codecs, nb, steps, world, reduce_max, total_blocks=None):
+def summarize(r, codecs, nb, steps, world, reduce_max, total_blocks=None, traffic_tag=None):
     """per-configuration record from the raw timings (max over ranks)"""
     names = [cd.name for cd in codecs]
     vals = [r["elapsed"]] + [r["enc_s"][n] for n in names] + [r["dec_s"][n] for n in names]
@@ -456,7 +465,7 @@ def summarize(r, codecs, nb, steps, world, reduce_max, total_blocks=None):
         rec["%s_compressed_bytes_per_block" % n] = round(r["csize"][n], 1)
     rec["kernel_ms_per_step"] = {k: round(v[0] / steps, 3) for k, v in r["per"].items()}
     dom_codec = max(names, key=lambda n: max(r["per"].get(k, (0, 0))[0] for k in HOT[n]))
-    rec["roofline"] = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, steps)
+    rec["roofline"] = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, steps, traffic_tag=traffic_tag)
     if r["parity"]:
         rec["parity"] = "; ".join("%s: %s" % (n, r["parity"][n]) for n in names)
     return rec, vals
@@ -464,6 +473,10 @@ def summarize(r, codecs, nb, steps, world, reduce_max, total_blocks=None):
 
 def main():
     args = parse()
+    global PLAIN
+    PLAIN = args.plain
+    if PLAIN:
+        args.no_host_inclusive = args.no_cpu_baseline = True
     launch_ranks_if_needed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -555,7 +568,7 @@ def main():
     head_roof = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, args.steps, traffic_tag="")
     head_roof["measured_over"] = ("%d steps repeated with the event probe on, directly after the timed region (%.3f ms per step with the probe, %.3f without)"
                                   % (args.steps, r["probe_elapsed"] / args.steps * 1e3, r["elapsed"] / args.steps * 1e3))
-    if rank == 0 and dom_codec == "fse":
+    if rank == 0 and dom_codec == "fse" and not PLAIN:
         try:
             sec = secondary_roofline(hip, codecs[head_names.index("fse")], hip.device_info())
             if sec:

@@ -741,10 +741,14 @@ size_t fse_decode_blocks_per_round(unsigned maxTableLog)
 
 static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
 {
+#ifdef FSE_DEC_LDS12_KB             // A/B aid: another workgroup size for the classes with 8 KiB tables
+    const size_t ldsBytes = a.ldsLog >= 12 ? FSE_DEC_LDS12_KB * 1024 : FSE_DEC_LDS;
+#else
     const size_t ldsBytes = FSE_DEC_LDS;
-    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true, false>, (int)ldsBytes);
-        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false, false>, (int)ldsBytes);
-        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<true, true>, (int)ldsBytes);
+#endif
+    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true, false>, FSE_DEC_LDS);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false, false>, FSE_DEC_LDS);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<true, true>, FSE_DEC_LDS);
         if (e != hipSuccess) return e;
     }
     fse_decode_geometry(a.ldsLog, ldsBytes, &a.slotU32, &a.G);

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         if (first + g >= nTot) break;
         const size_t b = a.list ? (size_t)a.list[first + g] : first + g;
         if (a.meta && a.meta[b].state == 0) continue;
+        if (a.onlyDeclined && a.results[b] != HUF_DECLINED) continue;
         const u32* t = a.dtables + b * a.dtStrideU32;
         const u32 desc = t[0];
         const u32 tl = (desc >> 16) & 0xFFu;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
     const u32 g = (u32)lane >> 2, k = (u32)lane & 3u;
     const bool inRange = (int)g < a.G && first + g < nTot;
     const size_t b = inRange ? (a.list ? (size_t)a.list[first + g] : first + g) : 0;
-    const bool live = wave == 0 && inRange && !(a.meta && a.meta[b].state == 0);
+    const bool live = wave == 0 && inRange && !(a.meta && a.meta[b].state == 0) && !(a.onlyDeclined && a.results[b] != HUF_DECLINED);
 
     size_t ierr = 0;                                 // BIT_initDStream error of my stream (0 = none)
     size_t blockErr = 0;                             // errors detected before any stream is touched
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_x2(HufDecArgs a)
     const u32* const gt = a.dtables + b * a.dtStrideU32;
     const u32 desc = gt[0];
     if (((desc >> 8) & 0xFFu) != 1u) return;                                              // single-symbol table: k_huf_decode's block
+    if (a.onlyDeclined && a.results[b] != HUF_DECLINED) return;                           // decoded by the stream-parallel decoder
     const u32 dtLog = (desc >> 16) & 0xFFu;
     const u32* const cells = gt + 1;
     const u8* const in = view_ptr(a.csrc, b);
@@ -503,13 +505,23 @@ static hipError_t huf_decode_launch(HufDecArgs a, hipStream_t s)
 }
 
 // caller-built tables (HUF_decompress4X1_usingDTable over a batch): one launch, slots sized by the caller's maxTableLog
+// Four-stream blocks go to the stream-parallel decoder first (single-symbol tables as they are, double-symbol tables through the
+// single-symbol cells it derives from them, huf_decode_par.hip); what it declines -- tiny / irregular / corrupt blocks, tables it
+// cannot vouch for -- is marked HUF_DECLINED and taken by the serial kernel (X1) and the literal lock-step kernel (X2) below.
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     a.list = nullptr; a.count = nullptr;
     a.ldsLog = a.maxTableLog > HD_SLOT_LOG ? FSEHIP_HUF_TABLELOG_MAX : HD_SLOT_LOG;
+    a.onlyDeclined = 0;
     probe_before(PK_HUF_DECODE, s);
-    hipError_t e = huf_decode_launch(a, s);
+    hipError_t e = hipSuccess;
+    if (a.streams == 4 && !a.meta) {
+        e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
+        if (e == hipSuccess && a.acceptX2) e = launch_huf_decode_par_x2(a, s);
+        a.onlyDeclined = 1;
+    }
+    if (e == hipSuccess) e = huf_decode_launch(a, s);
     if (e == hipSuccess && a.acceptX2) {                 // HUF_decompress4X_usingDTable: blocks whose table is a double-symbol one
         hipLaunchKernelGGL(k_huf_decode_x2, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
         e = hipGetLastError();

@@ -125,7 +125,9 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hparStats(uns
 #else
 #define HST(...)
 #endif
-template <u32 DATA>
+// X2CAP: the instantiation that can also take double-symbol tables (it holds a whole table in registers while deriving the single-symbol
+// cells: 200 VGPRs).  The one-shot path and single-symbol caller tables use the lean instantiation.
+template <u32 DATA, bool X2CAP>
 __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -134,8 +136,9 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     const size_t nTot = a.count ? (size_t)*a.count : a.nBlocks;
     if (slot >= nTot) return;                                            // uniform
     const size_t b = a.list ? (size_t)a.list[slot] : slot;
-    if (a.meta[b].state == 0) return;                                    // (finished by the prepare kernel)
-    const u32 hdr = a.meta[b].hdrSize;
+    if (a.meta && a.meta[b].state == 0) return;                          // (finished by the prepare kernel)
+    if (a.onlyDeclined && a.results[b] != HUF_DECLINED) return;          // (second launch of the caller-table path: what the lean one left)
+    const u32 hdr = a.meta ? a.meta[b].hdrSize : 0;                      // (caller-built tables: the payload starts the block)
     const u32* const gt = a.dtables + b * a.dtStrideU32;
     const u32 desc = gt[0];
     const u32 dtLog = (desc >> 16) & 0xFFu;
@@ -145,7 +148,10 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     u8* const out = a.dst + b * a.dstStride;
 
     // ---- can this block take the parallel path?  (uniform)  Anything unusual is the serial decoder's business.
-    bool ok = ((desc >> 8) & 0xFFu) == 0 && dtLog >= 1 && dtLog <= a.ldsLog && cSize >= 10 && cSize < (1u << 28) && dstSize >= 64 && dstSize < (1u << 28);
+    const u32 tableType = (desc >> 8) & 0xFFu;                           // 0: single-symbol cells (X1); 1: double-symbol cells (X2), caller-built only
+    if (X2CAP && tableType != 1) return;                                 // (single-symbol tables were the lean launch's)
+    bool ok = (tableType == 0 || (X2CAP && tableType == 1 && a.acceptX2 && !a.meta)) && dtLog >= 1 && dtLog <= a.ldsLog && dtLog <= a.maxTableLog
+              && cSize >= 10 && cSize < (1u << 28) && dstSize >= 64 && dstSize < (1u << 28);
     u32 len[4] = { 0, 0, 0, 0 }, T0[4] = { 0, 0, 0, 0 };
     const u32 seg = (u32)((dstSize + 3) / 4);
     if (ok) {
@@ -165,13 +171,14 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
             sp += len[q];
         }
     }
-    if (!ok) {                                                           // uniform (rare: k_huf_dprep has looked at the jump table)
-        if (lane == 0) fbList[atomicAdd(fbCount, 1u)] = (u32)b;
-        return;
-    }
+    // declined: the serial decoder's block -- on its list (one-shot path) or marked in results[] (caller tables: no workspace)
+    auto decline = [&]() { if (lane == 0) { if (fbList) fbList[atomicAdd(fbCount, 1u)] = (u32)b; else a.results[b] = HUF_DECLINED; } };
+    if (!ok) { decline(); return; }                                      // uniform (rare: k_huf_dprep has looked at the jump table)
 
+    u32* const data = lds + ((size_t)1 << (a.ldsLog - 1));               // the staged stream, behind the table slot
     // ---- stage the table: reference cells {byte, nbBits} -> bit-reversed order, {nbBits, byte}
-    {   const u32 words = 1u << (dtLog - 1);
+    if (tableType == 0) {
+        const u32 words = 1u << (dtLog - 1);
         u16* const s = (u16*)lds;
         for (u32 i = lane; i < words; i += 64) {
             const u32 w = gt[1 + i];
@@ -179,11 +186,84 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
             s[r0] = (u16)(((w >> 8) & 0xFFu) | ((w & 0xFFu) << 8));
             s[r0 | (1u << (dtLog - 1))] = (u16)(((w >> 24) & 0xFFu) | (((w >> 16) & 0xFFu) << 8));
         }
+    } else if constexpr (X2CAP) {
+        // ---- a double-symbol table from the reference's HUF_readDTableX2 (lib/huf_decompress.c:460-640): cell v = {u16 sequence; u8 nbBits;
+        //      u8 length} -- the one or two symbols the next tableLog bits v start with and what they consume together.  A prefix code
+        //      decodes the same symbols one at a time, so the single-symbol cell of v is {first symbol, ITS length}.  That length is not in
+        //      the cell, but the cells beginning with symbol s form one aligned run of 2^(tableLog - len(s)) indices: a histogram of the
+        //      first symbols gives every length.  Everything the equivalence rests on is checked -- runs aligned and contiguous, one-symbol
+        //      cells carrying len(first), two-symbol cells carrying len(first) + len(second) with `second` the first symbol of what
+        //      follows the first code -- and a table that fails any of it goes to the literal lock-step decoder (k_huf_decode_x2).
+        // The table is read ONCE, 64 consecutive cells per step (cell 64k + lane in register k of the lane); the passes below work on the
+        // registers.  Runs are found at their boundaries (a neighbour-lane comparison per cell, an LDS store per run), the second-symbol
+        // check reads the single-symbol cells just staged in LDS instead of gathering from the table in global memory.
+        u32* const cnt = data; u32* const lo = data + 256; u32* const hi = data + 512; u32* const nbs = data + 768;   // (the stream area is idle)
+        const u32 ts = 1u << dtLog;
+        constexpr u32 XK = (1u << FSEHIP_HUF_TABLELOG_MAX) / 64u;
+        u32 cel[XK];
+#pragma unroll
+        for (u32 k = 0; k < XK; ++k) { const u32 i = 64u * k + lane; cel[k] = i < ts ? gt[1 + i] : 0u; }
+        for (u32 i = lane; i < 256; i += 64) { cnt[i] = 0; lo[i] = 0; hi[i] = 0; }
+        __syncthreads();
+        u32 carry = 0;                                                   // first symbol of the cell in front of this step's cells
+#pragma unroll
+        for (u32 k = 0; k < XK; ++k) {
+            const u32 i = 64u * k + lane;
+            const u32 s1 = cel[k] & 0xFFu;
+            const u32 up = (u32)__shfl_up((int)s1, 1, WAVE);
+            const u32 prev = lane ? up : carry;
+            if (i < ts && (i == 0 || s1 != prev)) {                      // a run starts here (and the one of `prev` ended in front of it)
+                atomicAdd(&cnt[s1], 1u); lo[s1] = i;
+                if (i) hi[prev] = i - 1;
+            }
+            if (i == ts - 1) hi[s1] = i;
+            carry = (u32)__shfl((int)s1, 63, WAVE);
+        }
+        __syncthreads();
+        bool bad = false;
+        for (u32 sy = lane; sy < 256; sy += 64) {
+            const u32 runs = cnt[sy];
+            u32 nb = 0xFFu;                                              // no cell starts with this symbol
+            if (runs) {
+                const u32 n = hi[sy] - lo[sy] + 1;
+                if (runs == 1 && (n & (n - 1)) == 0 && (lo[sy] & (n - 1)) == 0 && n < ts) nb = dtLog - hibit32(n);
+                else bad = true;
+            }
+            nbs[sy] = nb;
+        }
+        __syncthreads();
+        u16* const s = (u16*)lds;
+#pragma unroll
+        for (u32 k = 0; k < XK; ++k) {
+            const u32 i = 64u * k + lane;
+            if (i >= ts) continue;
+            const u32 c = cel[k];
+            const u32 s1 = c & 0xFFu, s2 = (c >> 8) & 0xFFu, nbTot = (c >> 16) & 0xFFu, len = c >> 24;
+            const u32 n1 = nbs[s1];
+            if (len == 1) bad |= nbTot != n1;
+            else if (len == 2) bad |= (nbs[s2] == 0xFFu) | (nbTot != n1 + nbs[s2]) | (nbTot > dtLog);
+            else bad = true;
+            s[__brev(i) >> (32u - dtLog)] = (u16)(n1 | (s1 << 8));
+        }
+        __syncthreads();
+        if (!__any(bad)) {                                               // (uniform; the lengths are sane: the shifts below stay inside the table)
+#pragma unroll
+            for (u32 k = 0; k < XK; ++k) {
+                const u32 i = 64u * k + lane;
+                const u32 c = cel[k];
+                if (i >= ts || (c >> 24) != 2u) continue;
+                const u32 n1 = nbs[c & 0xFFu];
+                const u32 j = (i << n1) & (ts - 1);                      // what follows the first code, zero-extended: inside the second symbol's run
+                bad |= (u32)(s[__brev(j) >> (32u - dtLog)] >> 8) != ((c >> 8) & 0xFFu);
+            }
+        }
+        bad = __any(bad);
+        __syncthreads();
+        if (bad) { decline(); return; }                                  // uniform
     }
     const u32 tabOff = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds;
     if (tabOff & ((2u << a.ldsLog) - 1u)) __builtin_trap();               // the cell address is formed with an OR (dynamic LDS starts at 0)
     const u32 mask2 = ((1u << dtLog) - 1u) << 1;
-    u32* const data = lds + ((size_t)1 << (a.ldsLog - 1));               // the staged stream, behind the table slot
     const u32 arr = tabOff + (2u << a.ldsLog);
 
     const u8* sp = in + 6;
@@ -279,7 +359,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
         HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP2 += tB - tA; tA = tB; })
     }
     HST(if (lane == 0 && slot < 4096) { unsigned long long* t = g_hparStats + 8 * slot; t[0] = stRounds; t[1] = stBad; t[2] = tStage; t[3] = tP1; t[4] = tRep; t[5] = tP2; })
-    if (!good) { if (lane == 0) fbList[atomicAdd(fbCount, 1u)] = (u32)b; return; }
+    if (!good) { decline(); return; }
     if (lane == 0) a.results[b] = dstSize;
 }
 
@@ -288,7 +368,15 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
 template <u32 DATA>
 static hipError_t hpar_launch(const HufDecArgs& a, u32* serialList, u32* serialCount, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_huf_decode_par<DATA>, dim3((unsigned)a.nBlocks), dim3(64), ((size_t)2 << a.ldsLog) + DATA, s, a, serialList, serialCount);
+    hipLaunchKernelGGL((k_huf_decode_par<DATA, false>), dim3((unsigned)a.nBlocks), dim3(64), ((size_t)2 << a.ldsLog) + DATA, s, a, serialList, serialCount);
+    return hipGetLastError();
+}
+// caller-built tables, second launch: the blocks with double-symbol tables the lean launch marked HUF_DECLINED
+hipError_t launch_huf_decode_par_x2(HufDecArgs a, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    a.onlyDeclined = 1;
+    hipLaunchKernelGGL((k_huf_decode_par<HPAR_DATA_LARGE, true>), dim3((unsigned)a.nBlocks), dim3(64), ((size_t)2 << a.ldsLog) + HPAR_DATA_LARGE, s, a, (u32*)nullptr, (u32*)nullptr);
     return hipGetLastError();
 }
 

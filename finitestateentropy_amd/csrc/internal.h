@@ -191,14 +191,20 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
     const u32* count;
     int G; unsigned slotU32;
     int streams;                 // 4 (4X1) or 1 (1X1)
-    int acceptX2;                // usingDTable batch only: blocks with a double-symbol table (tableType 1) go to k_huf_decode_x2 instead of failing
+    int acceptX2;                // usingDTable batch only: blocks with a double-symbol table (tableType 1) are decoded instead of failing
+    int onlyDeclined;            // usingDTable batch only: decode just the blocks whose result is HUF_DECLINED (left by the stream-parallel decoder)
     size_t nBlocks;
 };
+// The caller-table batch has no workspace for a list of declined blocks: the stream-parallel decoder marks a block it declines with
+// this value in results[b] (no size_t a decoder returns: sizes are below 2^28 there, error codes above (size_t)-9), and the
+// serial / literal kernels that run afterwards take exactly the marked blocks.
+#define HUF_DECLINED ((size_t)0 - (size_t)0x7000)
 hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s);
 // one-shot path: one launch per class list, the stream-parallel decoder's first; what it declines -- corrupt or irregular blocks --
 // it appends to the serial list of the same tableLog, decoded by the serial kernel afterwards
 hipError_t launch_huf_decode_classes(HufDecArgs a, u32* lists, u32* counts, hipStream_t s);
 hipError_t launch_huf_decode_par(HufDecArgs a, unsigned dataBytes, u32* serialList, u32* serialCount, hipStream_t s);
+hipError_t launch_huf_decode_par_x2(HufDecArgs a, hipStream_t s);     // caller-built double-symbol tables marked HUF_DECLINED by the launch above
 
 // ---- FSE for 16-bit symbols (fse_u16.hip) --------------------------------------------------------------------
 struct U16Meta { u32 state, hdrSize, tableLog, maxSV; };      // state 0: result final; 1: run the chain

@@ -112,6 +112,46 @@ def main():
         lines.append("| %s | %d | %.1f | %.3f | %.3f |" % (k, c, c / trace_passes, tot / trace_passes / 1e6, mx / 1e6))
     open("profiles/%s_pmc.md" % tag, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    sq_summary(run, tag, nblocks, passes)
+
+
+SQ_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+               "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")
+
+
+def sq_summary(run, tag, nblocks, passes):
+    """profiles/<tag>_sq.md: the SQ counters of the two --pmc passes pmc_sq1 / pmc_sq2 per kernel, as ratios that can be read
+    against DESIGN's statements about what bounds a kernel (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+    quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES)."""
+    vals = {}
+    for sub in ("pmc_sq1", "pmc_sq2"):
+        path = os.path.join(run, sub, "bench_counter_collection.csv")
+        for c in SQ_COUNTERS:
+            for k, a in agg(path, c).items():
+                vals.setdefault(k, {})[c] = (a[1], a[0])
+    if not vals:
+        return
+    lines = ["# %s: SQ counters per kernel (rocprofv3 --pmc, two passes of four counters; sums over the %d passes of %d blocks)" % (tag, passes, nblocks), "",
+             "Reading: `valu` / `lds` = share of the wave cycles in which the wave had a VALU / LDS instruction in flight; `wait` = parked in "
+             "s_waitcnt (memory or LDS results outstanding); `stall` = ready but not issued (pipe or dependency); `lds array busy` = LDS-array "
+             "cycles (SQ_LDS_IDX_ACTIVE) per SQ busy cycle; `conflict` = share of those cycles that are bank-conflict replays.", "",
+             "| kernel | launches | wave cycles / block | valu | lds | wait | stall | lds array busy | conflict |", "|---|---|---|---|---|---|---|---|---|"]
+    rec = {}
+    for k in sorted(vals):
+        if not k.startswith("k_") or k == "k_probagen":
+            continue
+        v = {c: vals[k].get(c, (0.0, 0))[0] for c in SQ_COUNTERS}
+        wc = v["SQ_WAVE_CYCLES"] or 1.0
+        row = {"wave_cycles_per_block": v["SQ_WAVE_CYCLES"] / (nblocks * passes), "valu": v["SQ_ACTIVE_INST_VALU"] / wc, "lds": v["SQ_ACTIVE_INST_LDS"] / wc,
+               "wait": v["SQ_WAIT_ANY"] / wc, "stall": v["SQ_WAIT_INST_ANY"] / wc,
+               "lds_array_busy": v["SQ_LDS_IDX_ACTIVE"] / (v["SQ_BUSY_CYCLES"] or 1.0), "conflict": v["SQ_LDS_BANK_CONFLICT"] / (v["SQ_LDS_IDX_ACTIVE"] or 1.0)}
+        rec[k] = {kk: round(vv, 4) for kk, vv in row.items()}
+        rec[k]["raw"] = v
+        lines.append("| %s | %d | %.0f | %.3f | %.3f | %.3f | %.3f | %.3f | %.3f |" % (k, vals[k].get("SQ_WAVE_CYCLES", (0, 0))[1], row["wave_cycles_per_block"], row["valu"], row["lds"],
+                                                                                  row["wait"], row["stall"], row["lds_array_busy"], row["conflict"]))
+    open("profiles/%s_sq.md" % tag, "w").write("\n".join(lines) + "\n")
+    json.dump(rec, open("profiles/%s_sq.json" % tag, "w"), indent=1)
+    print("\n".join(lines))
 
 
 if __name__ == "__main__":

@@ -289,6 +289,33 @@ def test_huf_x2_tables_accepted(hip, ref):
             assert rg == r, (size, trial, rg, r)
             if not is_error(r):
                 assert (og[:r] == exp[:r]).all()
+        # damaged TABLES (cells whose symbols or bit counts no prefix code would produce; the length field stays 1 or 2 so that the
+        # reference itself stays inside its buffers): the stream-parallel decoder must not vouch for them -- the literal lock-step
+        # decoder reproduces whatever the reference makes of the table, on the valid stream and on a corrupted one
+        for trial in range(8):
+            i = trial % n
+            if not kinds[i]:
+                continue
+            dt = tables[i].copy()
+            tl = (int(dt[0]) >> 16) & 0xFF
+            cells = rng.integers(0, 1 << tl, 6)
+            for c in cells:
+                w = int(dt[1 + c])
+                if trial % 4 == 0:
+                    w ^= 0x5                                    # another first symbol
+                elif trial % 4 == 1:
+                    w ^= 0x0300                                 # another second symbol
+                elif trial % 4 == 2:
+                    w ^= 0x10000                                # bit count off by one
+                else:
+                    w = (w & 0x00FFFFFF) | ((3 - (w >> 24)) << 24) if (w >> 24) in (1, 2) else w   # one symbol <-> two symbols
+                dt[1 + c] = w
+            for strm in (streams[i], np.concatenate([streams[i][:6], streams[i][6:][::-1]])):
+                r, exp = ref.huf_decompress4x_using_dtable(strm, dt, size)
+                rg, og = hip.huf_decompress4x_using_dtable(strm, dt, size)
+                assert rg == r, (size, trial, rg, r)
+                if not is_error(r):
+                    assert (og[:r] == exp[:r]).all(), (size, trial)
 
 
 @pytest.mark.parametrize("size", [1, 7, 8, 12, 100, 1001, 4097, 32767, 32768, 65536, 131072])
