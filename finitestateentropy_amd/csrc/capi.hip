@@ -7,6 +7,7 @@
 #include <new>
 
 #define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" unsigned FSEHIP_isError(size_t code) { return code > FSEHIP_ERROR(maxCode); }
 
@@ -136,7 +137,6 @@ extern "C" int FSEHIP_probe_collect(double* totalMs, unsigned* launches)
     return 0;
 }
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline BlockView mkview(const void* base, size_t stride, const size_t* sizes, size_t uniform)
 {
     BlockView v; v.base = (const u8*)base; v.stride = stride; v.sizes = sizes; v.uniform = uniform; return v;
@@ -393,11 +393,53 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
 //  Layer 1: single-block calls on host pointers = batch of one (H2D, kernels, D2H)
 // =====================================================================================================
 namespace {
-struct DevBuf {
-    void* p = nullptr;
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
+struct Arena { void* base = nullptr; size_t cap = 0, used = 0, live = 0, peak = 0; int dev = -1;
+               ~Arena() { /* process / thread teardown: the runtime may already be gone -- the memory goes with the context */ } };
+thread_local Arena t_arena;
+}
+hipError_t HostCallBuf::alloc(size_t n)
+{
+    Arena& A = t_arena;
+    const size_t need = align_up(n ? n : 1, 256);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (A.live == 0) {                                            // between calls: follow the current device, grow to the last call's peak
+        size_t want = A.peak > need ? A.peak : need;
+        if (want > FSEHIP_SCRATCH_MAX) want = FSEHIP_SCRATCH_MAX;
+        if (A.dev != dev || A.cap < want) {
+            if (A.base && A.dev == dev) (void)hipFree(A.base);
+            A.base = nullptr; A.cap = 0; A.dev = dev;
+            if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+            if (hipMalloc(&A.base, want) == hipSuccess) A.cap = want; else { A.base = nullptr; (void)hipGetLastError(); }
+        }
+        A.used = 0; A.peak = 0;
+    }
+    ++A.live;
+    A.peak += need;
+    if (A.base && A.dev == dev && A.used + need <= A.cap) { p = (u8*)A.base + A.used; A.used += need; carved = need; owned = false; return hipSuccess; }
+    owned = true; carved = 0;
+    e = hipMalloc(&p, need);
+    if (e != hipSuccess) { p = nullptr; --A.live; }
+    return e;
+}
+HostCallBuf::~HostCallBuf()
+{
+    if (!p) return;
+    Arena& A = t_arena;
+    if (owned) (void)hipFree(p); else A.used -= carved;           // (stack order: destructors run in reverse order of the allocations)
+    --A.live;
+}
+typedef HostCallBuf DevBuf;
+// gives the calling thread's scratch arena back (between calls); the next call on host pointers allocates a new one
+extern "C" int FSEHIP_releaseScratch(void)
+{
+    Arena& A = t_arena;
+    if (A.live) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    if (A.base) { int dev = 0; e = hipGetDevice(&dev); if (e == hipSuccess && dev == A.dev) e = hipFree(A.base); }
+    A.base = nullptr; A.cap = 0; A.used = 0; A.peak = 0; A.dev = -1;
+    return (int)e;
 }
 
 // result transport for one block: returns GENERIC when the device path itself fails

@@ -17,11 +17,7 @@
 #include <vector>
 
 namespace {
-struct DevMem {
-    void* p = nullptr;
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-    ~DevMem() { if (p) (void)hipFree(p); }
-};
+typedef HostCallBuf DevMem;            // device scratch from the per-thread arena (internal.h): no hipMalloc / hipFree per frame
 #define FK(x) do { if ((x) != hipSuccess) return FSEHIP_ERROR(GENERIC); } while (0)
 struct HostMem {           // uninitialised host staging (a std::vector would zero-fill hundreds of megabytes)
     u8* p = nullptr;

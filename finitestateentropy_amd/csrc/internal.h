@@ -233,6 +233,21 @@ enum { PK_HIST = 0, PK_FSE_CPREP, PK_FSE_ENCODE, PK_FSE_DPREP, PK_FSE_DECODE, PK
 void probe_before(int kernelId, hipStream_t s);
 void probe_after(int kernelId, hipStream_t s);
 
+// Scratch for the calls on HOST pointers (single-block calls, .fse frames): a per-thread, per-device arena of device memory that only
+// grows -- a call carves its buffers from it stack-wise instead of paying hipMalloc / hipFree (tens of microseconds each, and a
+// device-wide synchronisation in hipFree) four or five times.  A buffer that does not fit is allocated the old way and the arena grows
+// to the call's peak before the next call (up to FSEHIP_SCRATCH_MAX); the batched calls on device pointers never allocate at all.
+struct HostCallBuf {
+    void* p = nullptr;
+    hipError_t alloc(size_t n);
+    ~HostCallBuf();
+    HostCallBuf() = default;
+    HostCallBuf(const HostCallBuf&) = delete; HostCallBuf& operator=(const HostCallBuf&) = delete;
+private:
+    size_t carved = 0; bool owned = false;
+};
+#define FSEHIP_SCRATCH_MAX ((size_t)1 << 30)
+
 // per-device caches (capi.hip): properties of the current device; "this kernel may use `bytes` of dynamic LDS" is set once
 // per (device, kernel)
 struct DevProps { int cus; int ldsPerCU; bool ok; };

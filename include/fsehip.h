@@ -248,6 +248,12 @@ FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
  * the first phase (set-up), [14] cycles after the last (literal tail).  Synchronises the device; for benchmarks only. */
 FSEHIP_API int FSEHIP_debug_decodeTiming(int enable, unsigned long long* out16);
 
+/* The calls on HOST pointers (layer 1, the frames) take their device scratch from an arena the calling thread keeps between calls
+ * (grow-only, at most 1 GiB; larger buffers are allocated and freed per call): no hipMalloc / hipFree on the repeated-call path.
+ * FSEHIP_releaseScratch() gives the calling thread's arena back; a thread that exits without calling it leaves its arena to the
+ * process teardown. */
+FSEHIP_API int FSEHIP_releaseScratch(void);
+
 /* build / device info: returns 0 and fills the fields when a gfx950 device is current */
 typedef struct { int deviceOrdinal; int computeUnits; int ldsBytesPerCU; int wavefrontSize; char archName[64]; } FSEHIP_DeviceInfo;
 FSEHIP_API int FSEHIP_deviceInfo(FSEHIP_DeviceInfo* info);
