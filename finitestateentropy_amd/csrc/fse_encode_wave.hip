@@ -26,7 +26,9 @@
 
 // Warm-up symbols (half per chain) in front of every range.  Two states fed the same symbols merge with probability
 // ~ present/tableSize per step (sum_s p_s / norm_s), so the warm-up is sized as a multiple of tableSize/present.
+#ifndef FSE_WV_WARM_FACTOR
 #define FSE_WV_WARM_FACTOR 2u
+#endif
 #define FSE_WV_WARM_MIN 64u
 #define FSE_WV_WARM_MAX 4096u
 
@@ -71,7 +73,9 @@ DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return 
 // indexed by the low bits of the word's global address, and every time a WV_LINE-byte aligned piece of the output is
 // complete it is written to global memory with 16-byte stores (whole sectors: the compressed stream leaves the chip
 // once).  The first bytes of a lane (up to the first line boundary) and its last ones go out bytewise / wordwise.
+#ifndef WV_LINE
 #define WV_LINE 32u
+#endif
 #define WV_RING (2u * WV_LINE)
 struct WvSink {
     u8* dstAl;            // destination rounded down to WV_RING bytes

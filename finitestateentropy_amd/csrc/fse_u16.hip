@@ -13,9 +13,10 @@
 //   * the encoder's chain is split across the 64 lanes of a wave by speculation and verification (k_u16_encode_wave: the scheme of
 //     fse_encode_wave.hip on one chain); blocks under 2048 symbols take the reference's loop on one lane (k_u16_encode), with its flush
 //     cadence and clamping;
-//   * a tANS decoder cannot be split (it does not resynchronise), and a single chain per block with 16-32 KB of tables would leave
-//     five to ten blocks per CU if the tables lived in LDS: the decoder runs the reference's loop one lane per block on tables in
-//     global memory (k_u16_decode) -- bound by random table reads.
+//   * a tANS decoder cannot be split (it does not resynchronise): the decoder is one chain per block with the 16-bit chain cells in LDS
+//     (18 blocks per CU) and the symbols gathered off the chain by service waves (k_u16_decode_lds, fse_u16_decode.hip); table log 13,
+//     which the reference's compressor never writes, stays with the reference's loop one lane per block on 32-bit cells in global
+//     memory (k_u16_decode).
 // Where the reference's behaviour is undefined the device path refuses instead: FSE_compressU16 with 8 bytes or less behind the
 // header (BIT_initCStream's error is ignored at fseU16.c:164 and the flushes then write in front of the buffer) stores no payload
 // and returns what the reference would (the header size alone); FSE_decompressU16 with nothing behind the header (the reference
@@ -398,24 +399,33 @@ __global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
     const size_t r = ((size_t)L.scal[1] << 32) | L.scal[0];
     if (is_err(r)) { if (lane == 0) { a.results[b] = r; a.meta[b] = m; } return; }
     const u32 maxSV = L.scal[2], tl = L.scal[3], ts = 1u << tl;
+    // Two table formats in the block's 32 KiB slot.  Table logs up to 12 (all the reference's compressor writes): the CHAIN cells
+    // newState | nbBits << 12 as 16-bit words (the image k_u16_decode_lds keeps in LDS) followed, 16 KiB further on, by the 16-bit symbol
+    // of every cell (gathered by its service waves) -- state 1.  Table log 13 needs 17 bits per chain cell: one 32-bit word per cell
+    // for the lane-per-block kernel -- state 3.
     u32* const cells = a.cells + (b << U16_MAXTL);
+    u16* const cells16 = (u16*)cells; u16* const syms16 = cells16 + ((size_t)1 << U16_MAXTL);
+    const bool wide = tl > 12;
     u16_spread_rank(L, maxSV, tl, lane, [&](u32 u, u32 s, u32 rk) {       // FSE_buildDTable (fse_decompress.c:116-123)
         const int v = L.nrm[s];
         const u32 next = (v == -1 ? 1u : (u32)v) + rk;
         const u32 nb = tl - hibit32(next);
-        cells[u] = (((next << nb) - ts) & 0xFFFFu) | (nb << 16) | (s << 20);
+        const u32 ns = ((next << nb) - ts) & 0xFFFFu;
+        if (wide) cells[u] = ns | (nb << 16) | (s << 20);
+        else { cells16[u] = (u16)(ns | (nb << 12)); syms16[u] = (u16)s; }      // (fse_u16_decode.hip: U16D_LOG)
     });
-    m.state = 1; m.hdrSize = (u32)r; m.tableLog = tl; m.maxSV = maxSV;
+    m.state = wide ? 3u : 1u; m.hdrSize = (u32)r; m.tableLog = tl; m.maxSV = maxSV;
     if (lane == 0) a.meta[b] = m;
 }
 
-// FSE_decompressU16_usingDTable (:273-301): one lane per block, the reference's loop with its bit reader
+// FSE_decompressU16_usingDTable (:273-301): one lane per block, the reference's loop with its bit reader -- the blocks with a table
+// log of 13 (32-bit cells in global memory; everything else is k_u16_decode_lds's, fse_u16_decode.hip)
 __global__ void k_u16_decode(U16DArgs a)
 {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.nBlocks) return;
     const U16Meta m = a.meta[b];
-    if (m.state == 0) return;
+    if (m.state != 3) return;
     const u8* const in = a.csrc + b * a.cStride + m.hdrSize;
     const size_t size = (a.cSizes ? a.cSizes[b] : a.uniformCSize) - m.hdrSize;
     const u32* const cells = a.cells + (b << U16_MAXTL);
@@ -458,6 +468,8 @@ hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_u16_dprep, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_u16_decode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    const hipError_t e = launch_u16_decode_lds(a, s);                     // table logs up to 12: chain cells in LDS
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_u16_decode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);   // table log 13
     return hipGetLastError();
 }
