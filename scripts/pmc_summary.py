@@ -115,6 +115,8 @@ def main():
     sq_summary(run, tag, nblocks, passes)
 
 
+CUS_PER_SQ = 8.0     # SQ_BUSY_CYCLES sums one busy-cycle count per shader engine (8 XCDs x 4), SQ_LDS_IDX_ACTIVE the LDS-array cycles of all 256 CUs:
+                     # checked against the kernel-trace durations (k_fse_decode: 6.4e8 busy cycles = 32 x kernel time x clock)
 SQ_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
                "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")
 
@@ -134,7 +136,7 @@ def sq_summary(run, tag, nblocks, passes):
     lines = ["# %s: SQ counters per kernel (rocprofv3 --pmc, two passes of four counters; sums over the %d passes of %d blocks)" % (tag, passes, nblocks), "",
              "Reading: `valu` / `lds` = share of the wave cycles in which the wave had a VALU / LDS instruction in flight; `wait` = parked in "
              "s_waitcnt (memory or LDS results outstanding); `stall` = ready but not issued (pipe or dependency); `lds array busy` = LDS-array "
-             "cycles (SQ_LDS_IDX_ACTIVE) per SQ busy cycle; `conflict` = share of those cycles that are bank-conflict replays.", "",
+             "cycles (SQ_LDS_IDX_ACTIVE, all CUs) / (8 CUs per shader engine x SQ_BUSY_CYCLES) = share of the kernel's time a CU's LDS array is working; `conflict` = share of those cycles that are bank-conflict replays.", "",
              "| kernel | launches | wave cycles / block | valu | lds | wait | stall | lds array busy | conflict |", "|---|---|---|---|---|---|---|---|---|"]
     rec = {}
     for k in sorted(vals):
@@ -144,7 +146,7 @@ def sq_summary(run, tag, nblocks, passes):
         wc = v["SQ_WAVE_CYCLES"] or 1.0
         row = {"wave_cycles_per_block": v["SQ_WAVE_CYCLES"] / (nblocks * passes), "valu": v["SQ_ACTIVE_INST_VALU"] / wc, "lds": v["SQ_ACTIVE_INST_LDS"] / wc,
                "wait": v["SQ_WAIT_ANY"] / wc, "stall": v["SQ_WAIT_INST_ANY"] / wc,
-               "lds_array_busy": v["SQ_LDS_IDX_ACTIVE"] / (v["SQ_BUSY_CYCLES"] or 1.0), "conflict": v["SQ_LDS_BANK_CONFLICT"] / (v["SQ_LDS_IDX_ACTIVE"] or 1.0)}
+               "lds_array_busy": v["SQ_LDS_IDX_ACTIVE"] / (CUS_PER_SQ * (v["SQ_BUSY_CYCLES"] or 1.0)), "conflict": v["SQ_LDS_BANK_CONFLICT"] / (v["SQ_LDS_IDX_ACTIVE"] or 1.0)}
         rec[k] = {kk: round(vv, 4) for kk, vv in row.items()}
         rec[k]["raw"] = v
         lines.append("| %s | %d | %.0f | %.3f | %.3f | %.3f | %.3f | %.3f | %.3f |" % (k, vals[k].get("SQ_WAVE_CYCLES", (0, 0))[1], row["wave_cycles_per_block"], row["valu"], row["lds"],
