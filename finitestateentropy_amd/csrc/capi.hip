@@ -27,7 +27,17 @@ extern "C" const char* FSEHIP_getErrorName(size_t code)   // lib/error_private.h
     }
 }
 
-extern "C" const char* FSEHIP_versionString(void) { return "fsehip 0.1 (gfx950)"; }
+extern "C" const char* FSEHIP_versionString(void) { return "fsehip 0.3 (gfx950)"; }
+
+extern "C" void FSEHIP_shardRange(size_t nBlocks, int rank, int world, size_t* first, size_t* count)   // = shard.shard_range
+{
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    const size_t base = nBlocks / (size_t)world, rem = nBlocks % (size_t)world, r = (size_t)rank;
+    const size_t lo = r * base + (r < rem ? r : rem);
+    if (first) *first = lo;
+    if (count) *count = r < (size_t)world ? base + (r < rem ? 1 : 0) : 0;
+}
 
 // Per-device caches (a process may drive several devices: the attribute and the CU count belong to the current one),
 // guarded for concurrent host threads.

@@ -248,6 +248,12 @@ FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
  * the first phase (set-up), [14] cycles after the last (literal tail).  Synchronises the device; for benchmarks only. */
 FSEHIP_API int FSEHIP_debug_decodeTiming(int enable, unsigned long long* out16);
 
+/* Sharding a batch over the GPUs of a node (one process per GPU; the reference's chunk loop, programs/bench.c:353-364,389-424, has no
+ * carried dependence, so contiguous ranges of blocks need no collective on the data path): rank `rank` of `world` codes blocks
+ * [*first, *first + *count), ranges differ by at most one block.  The RCCL calls a C host puts around it when the corpus lives on
+ * one rank -- one ncclGroup per direction -- are in INTEGRATION.md section 2c. */
+FSEHIP_API void FSEHIP_shardRange(size_t nBlocks, int rank, int world, size_t* first, size_t* count);
+
 /* The calls on HOST pointers (layer 1, the frames) take their device scratch from an arena the calling thread keeps between calls
  * (grow-only, at most 1 GiB; larger buffers are allocated and freed per call): no hipMalloc / hipFree on the repeated-call path.
  * FSEHIP_releaseScratch() gives the calling thread's arena back; a thread that exits without calling it leaves its arena to the

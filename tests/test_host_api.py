@@ -73,3 +73,29 @@ def test_mixed_corpus_layout():
             for row, (j, seed) in seen.items():
                 g = first + row
                 assert j == g % k and seed == g + 1
+
+
+def test_shard_range_c_abi_matches_the_python_one():
+    """FSEHIP_shardRange (what a C host shards with) = finitestateentropy_amd.shard.shard_range"""
+    from finitestateentropy_amd.shard import shard_range
+    lib = ctypes.CDLL(_lib_path())
+    lib.FSEHIP_shardRange.restype = None
+    for n in (0, 1, 7, 8, 100000, 1000000, 1000003):
+        for w in (1, 2, 3, 4, 8):
+            for r in range(w):
+                first, count = ctypes.c_size_t(), ctypes.c_size_t()
+                lib.FSEHIP_shardRange(ctypes.c_size_t(n), ctypes.c_int(r), ctypes.c_int(w), ctypes.byref(first), ctypes.byref(count))
+                lo, hi = shard_range(n, r, w)
+                assert (first.value, count.value) == (lo, hi - lo), (n, w, r)
+
+
+def test_c_host_example_with_rccl_compiles():
+    """examples/shard_rccl.c -- the scatter / code / gather of config 5 written against the C ABI and RCCL -- must compile against
+    include/fsehip.h and the ROCm headers (it can only RUN where several GPUs are)"""
+    import shutil, subprocess, tempfile
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h") or shutil.which("gcc") is None:
+        pytest.skip("no RCCL headers / gcc here")
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run(["gcc", "-D__HIP_PLATFORM_AMD__", "-Wall", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-c",
+                            os.path.join(ROOT, "examples", "shard_rccl.c"), "-o", os.path.join(d, "x.o")], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
