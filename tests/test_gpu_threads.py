@@ -43,3 +43,21 @@ def test_concurrent_callers(hip):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_host_call_scratch_arena_grows_and_is_released(hip, checker):
+    """the calls on host pointers carve their device buffers from a per-thread arena (no hipMalloc per call): results must not depend
+    on what the arena held before -- a large call, small ones, a release in between, a call larger than the arena's first size"""
+    import ctypes as C
+    small = checker.probagen_batch(14, 1, 3000, 5)[0]
+    big = checker.probagen_batch(14, 1, 1 << 21, 6)[0]                  # 2 MiB: beyond the arena's initial megabyte
+    want_s, want_b = checker.fse_compress2(small), checker.fse_compress2(big, 255, 12)
+    for rounds in range(2):
+        for blk, want, tl in ((small, want_s, 11), (big, want_b, 12), (small, want_s, 11)):
+            r, out = hip.fse_compress2(blk, 255, tl)
+            assert r == want[0] and (out[:r] == want[1][:r]).all()
+            r2, back = hip.fse_decompress(out[:r], blk.size)
+            assert r2 == blk.size and (back[:r2] == blk).all()
+            hr, ho = hip.huf_compress2(blk[:100000]), checker.huf_compress2(blk[:100000])
+            assert hr[0] == ho[0] and (hr[1][:hr[0]] == ho[1][:ho[0]]).all()
+        assert hip.lib.FSEHIP_releaseScratch() == 0
