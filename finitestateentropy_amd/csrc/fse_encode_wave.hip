@@ -6,21 +6,25 @@
 // where it came from.  That makes the block splittable without changing a single output bit:
 //
 //   WV_LANES (32) lanes per block, two blocks per 64-lane wave; only the packed CTable lives in LDS, so many blocks are
-//   resident per CU.  In emission order (last source byte first) lane t of a block owns a contiguous range of symbols.
-//   Pass 1: the lane warms both chains up over `warm` symbols in front of its range starting from an
-//   arbitrary state, remembers the states it arrives with (its speculated start), then runs its range counting
-//   bits and remembers the states it ends with.  Verification: lane t's speculated start must equal lane t-1's
-//   end; lane 0 starts from the exact FSE_initCState2 states, so if every link matches, every start is exact by
-//   induction.  A lane whose link does not match re-runs its range from its predecessor's end -- only as far as the
-//   first checkpoint at which it has merged with the trajectory its previous run recorded -- and the check is
-//   repeated until no link changes (worst case this degenerates into the serial algorithm).  Nothing is assumed:
-//   the output is bit-exact by construction.
-//   Pass 2: a wave prefix sum of the bit counts gives every lane its bit offset (and the exact compressed size /
-//   the BIT_closeCStream verdict before a single bit is written); each lane re-runs its range from its verified
-//   start and emits its bits through a small per-lane LDS ring, written out in aligned 32-byte pieces, the last
-//   whole bytes at the end.  The byte shared by two neighbouring ranges is stored by the upper lane with the lower
-//   lane's bits OR-ed in afterwards (one global atomic per lane).  CState2, CState1 and the end mark are appended
-//   by the lane that owns the final states (lib/fse_compress.c:608-610).
+//   resident per CU.  In emission order (last source byte first) the block is cut into 32 contiguous ranges of symbols.
+//   Pass 1 (counting, ONE CHAIN PER LANE: the two chains never interact): lane 2k + c walks chain c over the super-range
+//   k = ranges 2k and 2k+1.  It warms the chain up over `warm` symbols in front of the super-range starting from an
+//   arbitrary state, remembers the state it arrives with (its speculated start), then runs the super-range counting
+//   bits, noting state and count where the two ranges meet, and remembers the state it ends with.  Verification: a
+//   lane's speculated start must equal the end of the same chain's previous super-range; super-range 0 starts from the
+//   exact FSE_initCState2 state, so if every link matches, every start is exact by induction.  A lane whose link does not
+//   match re-runs from its predecessor's end -- only as far as the first checkpoint at which it has merged with the
+//   trajectory its previous run recorded -- and the check is repeated until no link changes (worst case this
+//   degenerates into the serial algorithm).  Nothing is assumed: the output is bit-exact by construction.
+//   (Half as many links per chain as ranges, each twice as long; a link fails when one chain has not merged, not either
+//   of two; a repair re-runs one chain: measured against two-chain lanes over single ranges, P80 4.5 repair rounds
+//   instead of 9.4 and 8.2 ms instead of 11.0 per 100k blocks, P14 1.0 instead of 1.4 rounds.)
+//   Pass 2: every range now knows both start states and its bit count; a wave prefix sum of the counts gives every lane
+//   its bit offset (and the exact compressed size / the BIT_closeCStream verdict before a single bit is written); lane t
+//   runs range t, both chains interleaved, from the verified states and emits its bits through a small per-lane LDS
+//   ring, written out in aligned 32-byte pieces, the last whole bytes at the end.  The byte shared by two neighbouring
+//   ranges is stored by the upper lane with the lower lane's bits OR-ed in afterwards (one global atomic per lane).
+//   CState2, CState1 and the end mark are appended by the lane that owns the last range (lib/fse_compress.c:608-610).
 //   Source bytes are streamed per lane in 64-byte aligned segments (four 16-byte loads), one segment ahead.
 #include "internal.h"
 
@@ -67,6 +71,7 @@ DEV void wv_step_bits(u32& st, u32 ttb, u32 sym, u32& nb, u32& bits)
 #define WV_STEP(ST, sym, nb) wv_step<TT4>(ST, ttb, sym, nb);
 #define WV_STEP_BITS(ST, sym, nb, bits) wv_step_bits<TT4>(ST, ttb, sym, nb, bits);
 
+DEV u32 wv_byte0(u32 w) { u32 r; __asm__("v_and_b32 %0, 0xff, %1" : "=v"(r) : "v"(w)); return r; }   // (opaque: or the shift of the address is pulled in front of the mask, one instruction more)
 DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
 // Bit sink of one lane.  Bits are appended LSB-first; completed 32-bit words go to a small per-lane LDS ring that is
@@ -80,11 +85,25 @@ DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return 
 struct WvSink {
     u8* dstAl;            // destination rounded down to WV_RING bytes
     u32* ring;            // this lane's LDS ring
+    u32 ringA;            // its absolute LDS byte address
     u32 woff;             // offset from dstAl of the next 32-bit word (multiple of 4)
     u32 done;             // offset from dstAl up to which this lane's bytes are in global memory
-    u64 acc; u32 nacc;
-    DEV void put(u32 v, u32 nb) { acc |= (u64)v << nacc; nacc += nb; }
-    DEV void spill() { if (nacc >= 32u) { ring[(woff & (WV_RING - 1)) >> 2] = (u32)acc; woff += 4; acc >>= 32; nacc -= 32u; } }
+    u32 acc, nacc;        // the bits not yet in a complete word (nacc < 32 between calls)
+    // append nb (<= 32) bits.  Branch-free: the word in progress is stored to the ring every time (it is overwritten until
+    // complete); a conditional flush costs more instructions than the store, and its branch is taken by some lane of the
+    // wave at nearly every call anyway (measured on P14: 618 GB/s against 604 with the store under `if (full)`, 584 with the
+    // branchy 64-bit accumulator)
+    DEV void push(u32 v, u32 nb)
+    {
+        const u64 sh = (u64)v << nacc;
+        acc |= (u32)sh;
+        nacc += nb;
+        const bool full = nacc >= 32u;
+        *(__attribute__((address_space(3))) u32*)(uintptr_t)(ringA | (woff & (WV_RING - 4u))) = acc;   // (the rings are WV_RING-aligned)
+        woff += full ? 4u : 0u;
+        acc = full ? (u32)(sh >> 32) : acc;
+        nacc &= 31u;
+    }
     DEV void copy_out(u32 upTo)                                         // bytes [done, upTo), any alignment
     {
         const u8* const rb = (const u8*)ring;
@@ -109,30 +128,21 @@ struct WvSink {
     }
 };
 
-// Run symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even).  Returns the
-// number of bits they emit; with EMIT the bits also go to the sink.  The source is streamed downwards: 64 bytes (four
-// 16-byte loads of one 64-byte segment, so the segment is fetched from memory once) one segment ahead of its use.
-// Checkpoints (counting passes only): after every ck->every 64-symbol groups of the range the pass records its state pair
-// and bit count (WV_CK_RECORD), or -- when a range is re-run from a corrected start state (WV_CK_MERGE) -- compares
-// them with what the previous run recorded there: once the states agree the rest of the range repeats the previous
-// run (same states, same symbols), so the new total is known and the pass stops.
-enum { WV_CK_NONE = 0, WV_CK_RECORD = 1, WV_CK_MERGE = 2 };
-#define WV_CK_MAX 8u
-struct WvCk { uint2* slot; u32 every; u32 oldBits; bool merged; };
-template <bool EMIT, bool TT4, int CK = WV_CK_NONE>
-DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink* k, WvCk* ck = nullptr)
+// EMIT symbols j in [ja, jb) (distance from the block end; even j -> chain A, odd j -> chain B; ja is even) from the verified
+// states (xa, xb) into the sink.  The source is streamed downwards: 64 bytes (four 16-byte loads of one 64-byte segment, so
+// the segment is fetched from memory once) one segment ahead of its use.
+template <bool TT4>
+DEV void wv_emit(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
 {
-    u32 bits = 0, j = ja;
-    u32 ckLeft = CK != WV_CK_NONE ? ck->every : 0u, ckIdx = 0;
+    u32 j = ja;
     u32 na, nbb, ba, bb;
 #define WV_PAIR(w, hiA, hiB)                                                                         \
-    {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = __builtin_amdgcn_ubfe(w, hiB, 8u);     \
-        if (EMIT) { WV_STEP_BITS(xa, sa, na, ba) WV_STEP_BITS(xb, sb, nbb, bb) k->put(ba | (bb << na), na + nbb); k->spill(); } \
-        else { WV_STEP(xa, sa, na) WV_STEP(xb, sb, nbb) bits += na + nbb; } }
+    {   const u32 sa = __builtin_amdgcn_ubfe(w, hiA, 8u), sb = hiB ? __builtin_amdgcn_ubfe(w, hiB, 8u) : wv_byte0(w); \
+        WV_STEP_BITS(xa, sa, na, ba) WV_STEP_BITS(xb, sb, nbb, bb) k.push(ba | (bb << na), na + nbb); }
 #define WV_QUAD(v)                                                                                   \
     WV_PAIR(v.w, 24u, 16u) WV_PAIR(v.w, 8u, 0u) WV_PAIR(v.z, 24u, 16u) WV_PAIR(v.z, 8u, 0u)           \
     WV_PAIR(v.y, 24u, 16u) WV_PAIR(v.y, 8u, 0u) WV_PAIR(v.x, 24u, 16u) WV_PAIR(v.x, 8u, 0u)          \
-    if (EMIT) k->line();
+    k.line();
     if (j + 64 <= jb) {
         const u8* p = src + (n - 64 - j);
         uint4 c0 = wv_load16(p), c1 = wv_load16(p + 16), c2 = wv_load16(p + 32), c3 = wv_load16(p + 48);
@@ -143,22 +153,6 @@ DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, 
             __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one segment ahead of its use
             WV_QUAD(c3) WV_QUAD(c2) WV_QUAD(c1) WV_QUAD(c0)
             c0 = n0; c1 = n1; c2 = n2; c3 = n3; j = nj;
-            if (CK != WV_CK_NONE && --ckLeft == 0) {
-                ckLeft = ck->every;
-                const u32 st = xa | (xb << 16);
-                if (CK == WV_CK_MERGE && ckIdx < WV_CK_MAX) {
-                    const uint2 o = ck->slot[ckIdx];
-                    if (o.x == st) {
-                        // keep the later records consistent with the new run: their bit counts shift by what the prefix changed by
-                        const u32 nck = ((jb - ja) / 64u) / ck->every, d = bits - o.y;
-                        for (u32 i = ckIdx; i < nck && i < WV_CK_MAX; ++i) ck->slot[i].y += d;
-                        ck->merged = true;
-                        return bits + (ck->oldBits - o.y);
-                    }
-                }
-                if (ckIdx < WV_CK_MAX) ck->slot[ckIdx] = make_uint2(st, bits);
-                ++ckIdx;
-            }
         }
     }
     while (j + 16 <= jb) {
@@ -172,14 +166,62 @@ DEV u32 wv_run(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, 
         const u32 sym = src[n - 1 - j];
         u32 nb, b1;
         if (j & 1u) { WV_STEP_BITS(xb, sym, nb, b1) } else { WV_STEP_BITS(xa, sym, nb, b1) }
-        if (EMIT) { k->put(b1, nb); k->spill(); } else bits += nb;
+        k.push(b1, nb);
     }
-    return bits;
 }
-template <bool TT4> DEV u32 wv_count(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb)
-{ return wv_run<false, TT4>(ttb, src, n, ja, jb, xa, xb, nullptr); }
-template <bool TT4> DEV void wv_emit(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32& xa, u32& xb, WvSink& k)
-{ wv_run<true, TT4>(ttb, src, n, ja, jb, xa, xb, &k); }
+
+// COUNT one chain over [ja, jb) (ja even; c = 0: the even j, 1: the odd j): its bits are added to `bits`, which -- like the
+// checkpoint bookkeeping in ck -- runs on over the caller's pieces.  Same source streaming as wv_emit; a lane uses every
+// other byte.  Checkpoints: after every ck->every 64-symbol groups the pass records its state and bit count
+// (WV_CK_RECORD), or -- when the chain is re-run from a corrected start state (WV_CK_MERGE) -- compares them with what
+// the previous run recorded there: once the states agree the rest repeats the previous run (same state, same symbols),
+// so every later count is the recorded one shifted by the difference, and the pass stops.
+enum { WV_CK_NONE = 0, WV_CK_RECORD = 1, WV_CK_MERGE = 2 };
+#define WV_CK_MAX 8u
+struct WvCk { uint2* slot; u32 every, left, idx, total; u32 d; bool merged; };
+template <bool TT4, int CK>
+DEV void wv_chain(u32 ttb, const u8* src, u32 n, u32 ja, u32 jb, u32 c, u32& x, u32& bits, WvCk* ck = nullptr)
+{
+    u32 j = ja;
+    const u32 shHi = 24u - 8u * c, shLo = 8u - 8u * c;                      // my byte of a word's upper / lower half (even j = the higher address)
+#define WV_CSTEP(w, sh) { const u32 sy = __builtin_amdgcn_ubfe(w, sh, 8u); u32 nb; WV_STEP(x, sy, nb) bits += nb; }
+#define WV_CQUAD(v) WV_CSTEP(v.w, shHi) WV_CSTEP(v.w, shLo) WV_CSTEP(v.z, shHi) WV_CSTEP(v.z, shLo) WV_CSTEP(v.y, shHi) WV_CSTEP(v.y, shLo) WV_CSTEP(v.x, shHi) WV_CSTEP(v.x, shLo)
+    if (j + 64 <= jb) {
+        const u8* p = src + (n - 64 - j);
+        uint4 c0 = wv_load16(p), c1 = wv_load16(p + 16), c2 = wv_load16(p + 32), c3 = wv_load16(p + 48);
+        while (j + 64 <= jb) {
+            const u32 nj = j + 64;
+            const u8* const q = src + (n - 64 - (nj + 64 <= jb ? nj : j));
+            const uint4 n0 = wv_load16(q), n1 = wv_load16(q + 16), n2 = wv_load16(q + 32), n3 = wv_load16(q + 48);
+            __asm__ volatile("" ::: "memory");                          // keep the prefetch up here: one segment ahead of its use
+            WV_CQUAD(c3) WV_CQUAD(c2) WV_CQUAD(c1) WV_CQUAD(c0)
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; j = nj;
+            if (CK != WV_CK_NONE && --ck->left == 0) {
+                ck->left = ck->every;
+                if (CK == WV_CK_MERGE && ck->idx < WV_CK_MAX) {
+                    const uint2 o = ck->slot[ck->idx];
+                    if (o.x == x) {
+                        // merged with the recorded trajectory: everything behind this point repeats it, its bit counts shifted by d
+                        const u32 d = bits - o.y;
+                        for (u32 i = ck->idx; i < ck->total && i < WV_CK_MAX; ++i) ck->slot[i].y += d;
+                        ck->d = d; ck->merged = true;
+                        return;
+                    }
+                }
+                if (ck->idx < WV_CK_MAX) ck->slot[ck->idx] = make_uint2(x, bits);
+                ++ck->idx;
+            }
+        }
+    }
+    while (j + 16 <= jb) {
+        const uint4 v = wv_load16(src + (n - 16 - j));
+        WV_CQUAD(v)
+        j += 16;
+    }
+#undef WV_CQUAD
+#undef WV_CSTEP
+    for (j += c; j < jb; j += 2) { u32 nb; WV_STEP(x, (u32)src[n - 1 - j], nb) bits += nb; }
+}
 
 template <bool TT4>
 DEV u32 wv_init_state(u32 ttb, u32 sym)                  // FSE_initCState2, lib/fse.h:503-512
@@ -309,7 +351,8 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     warm = (warm + 63u) & ~63u;
     warm = warm < FSE_WV_WARM_MIN ? FSE_WV_WARM_MIN : (warm > FSE_WV_WARM_MAX ? FSE_WV_WARM_MAX : warm);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // the slots are private to this wave: LDS is in order per wave
-    const u32 ttb = ldsOff + 4u * ttAl;                                    // absolute LDS address of the symbolTT copy
+    u32 ttb = ldsOff + 4u * ttAl;                                          // absolute LDS address of the symbolTT copy
+    __asm__("" : "+v"(ttb));                                               // (opaque: entry address = symbol * 4 + ttb in one v_lshl_add, not (symbol + ttb / 4) * 4 in two)
     u32* const ringBase = lds + tableWords;                                // WV_LANES output rings behind the table
     ETIMING(T1 = __builtin_readcyclecounter();)
 
@@ -327,41 +370,79 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     const bool mine = on && j0 < n;                                         // non-empty range
     const u32 lastLane = m ? ((m + delta - 1) / C < WV_LANES - 1u ? (m + delta - 1) / C : WV_LANES - 1u) : 0u;   // owner of the final states
 
-    // ---- pass 1: speculated start, bit count, end states.  The output rings are idle until pass 2: they hold the checkpoints
-    WvCk ck; ck.slot = (uint2*)(ringBase + hl * (WV_RING / 4)); ck.oldBits = 0; ck.merged = false;
-    ck.every = (C / 64u + WV_CK_MAX - 1u) / WV_CK_MAX; ck.every = ck.every ? ck.every : 1u;      // at most WV_CK_MAX checkpoints per range
-    // (measured: a checkpoint per 64-symbol group over the first eight groups only -- merges come early -- is 1.5 % slower on P14)
-    u32 xa = 0, xb = 0, start = 0, end = 0, bits = 0;
-    if (mine) {
-        if (j0 <= 2 + warm) {                                        // the warm-up would reach the block end: be exact
-            xa = wv_init_state<TT4>(ttb, src[n - 1]);
-            xb = wv_init_state<TT4>(ttb, src[n - 2]);
-            wv_count<TT4>(ttb, src, n, 2, j0, xa, xb);
+    // ---- pass 1: COUNTING, one chain per lane.  The two chains of a block never interact, so the block's lanes are paired up:
+    //      lane 2k + c walks chain c alone over the super-range k = ranges 2k and 2k+1 (bound(2k) .. bound(2k+2)): half as many
+    //      links per chain as ranges, each twice as long as a range -- a link fails when ONE chain has not merged (not either of
+    //      two), a repair re-runs one chain (not both), and a wrong end state needs two ranges' worth of symbols to survive into
+    //      the next link: what decides the repair rounds of slowly mixing tables.  The state and bit count at bound(2k+1) are
+    //      recorded on the way, so afterwards every range knows both start states and its bit count.
+    //      The output rings are idle until pass 2: they hold the checkpoints.
+    const u32 cc = hl & 1u, kk = hl >> 1;
+    const u32 sLo0 = kk ? 2 + 2u * kk * C - delta : 2u, sMid0 = 2 + (2u * kk + 1u) * C - delta, sHi0 = 2 + (2u * kk + 2u) * C - delta;
+    const u32 sLo = sLo0 < n ? sLo0 : n, sMid = sMid0 < n ? sMid0 : n;
+    const u32 sHi = (2u * kk + 2u >= WV_LANES || sHi0 > n) ? n : sHi0;
+    const bool mineC = on && sLo < n;
+    WvCk ck; ck.slot = (uint2*)(ringBase + hl * (WV_RING / 4)); ck.merged = false; ck.d = 0; ck.idx = 0;
+    ck.every = (2u * C / 64u + WV_CK_MAX - 1u) / WV_CK_MAX; ck.every = ck.every ? ck.every : 1u;   // at most WV_CK_MAX checkpoints per super-range
+    if (C & 63u) ck.every = 0x7FFFFFFFu;                                     // (small blocks: the ranges are not whole segments and too short to bother)
+    ck.left = ck.every; ck.total = (2u * C / 64u) / ck.every;
+    u32 cstart = 0, cmid = 0, cend = 0, bitsLo = 0, bitsTot = 0;
+    if (mineC) {
+        u32 x, scratch = 0;
+        if (sLo <= 2 + warm) {                                              // the warm-up would reach the block end: be exact
+            x = wv_init_state<TT4>(ttb, src[n - 1 - cc]);
+            wv_chain<TT4, WV_CK_NONE>(ttb, src, n, 2, sLo, cc, x, scratch);
         } else {
-            xa = xb = 1u << tl;                                             // any state will do (measured: the choice does not matter): it is verified below
-            wv_count<TT4>(ttb, src, n, j0 - warm, j0, xa, xb);
+            x = 1u << tl;                                                   // any state will do (measured: the choice does not matter): it is verified below
+            wv_chain<TT4, WV_CK_NONE>(ttb, src, n, sLo - warm, sLo, cc, x, scratch);
         }
-        start = xa | (xb << 16);
-        bits = wv_run<false, TT4, WV_CK_RECORD>(ttb, src, n, j0, j1, xa, xb, nullptr, &ck);
-        end = xa | (xb << 16);
+        cstart = x;
+        u32 lo = sLo, hi = sMid, nbits = 0;
+#pragma nounroll
+        for (int piece = 0; piece < 2; ++piece) {
+            wv_chain<TT4, WV_CK_RECORD>(ttb, src, n, lo, hi, cc, x, nbits, &ck);
+            if (piece == 0) { cmid = x; bitsLo = nbits; }
+            lo = sMid; hi = sHi;
+        }
+        cend = x; bitsTot = nbits;
     }
     ETIMING(T2 = __builtin_readcyclecounter();)
-    // ---- verification / repair: start[t] must equal end[t-1]; lane 0 (and every lane that ran from the block end) is exact
+    // ---- verification / repair per chain: start[k] must equal end[k-1]; super-range 0 (and every one that ran from the block end) is exact
     for (;;) {
-        const u32 prevEnd = (u32)__shfl_up((int)end, 1, WAVE);
-        const bool bad = mine && hl > 0 && start != prevEnd;
+        const u32 prevEnd = (u32)__shfl_up((int)cend, 2, WAVE);
+        const bool bad = mineC && kk > 0 && cstart != prevEnd;
         if (!__any(bad)) break;
         ETIMING(if (rounds == 0) { const unsigned long long bm = __ballot(bad); nBad0 = (u32)__builtin_popcountll(bm); firstBad = (u32)__builtin_ctzll(bm); })
         if (bad) {
-            start = prevEnd;
-            xa = start & 0xFFFFu; xb = start >> 16;
-            ck.oldBits = bits; ck.merged = false;
-            bits = wv_run<false, TT4, WV_CK_MERGE>(ttb, src, n, j0, j1, xa, xb, nullptr, &ck);
-            if (!ck.merged) end = xa | (xb << 16);                        // merged: the rest of the range, and its end states, repeat the previous run
+            cstart = prevEnd;
+            u32 x = cstart, lo = sLo, hi = sMid, nbits = 0;
+            ck.merged = false; ck.idx = 0; ck.left = ck.every;
+            bool midDone = false;
+#pragma nounroll
+            for (int piece = 0; piece < 2 && !ck.merged; ++piece) {
+                wv_chain<TT4, WV_CK_MERGE>(ttb, src, n, lo, hi, cc, x, nbits, &ck);
+                if (piece == 0 && !ck.merged) { cmid = x; bitsLo = nbits; midDone = true; }
+                lo = sMid; hi = sHi;
+            }
+            if (ck.merged) {                                                // the rest of the super-range, and its end state, repeat the previous run
+                if (!midDone) bitsLo += ck.d;
+                bitsTot += ck.d;
+            } else { cend = x; bitsTot = nbits; }
         }
         ETIMING(++rounds;)
     }
     ETIMING(T3 = __builtin_readcyclecounter();)
+    // ---- hand the results to the ranges: lane t (range t) takes both chains' states at bound(t) and its bit count
+    u32 start, bits;
+    {   const int la = (int)(partBase + (hl & ~1u)), lb = la + 1;
+        const u32 sA = (u32)__shfl((int)cstart, la, WAVE), sB = (u32)__shfl((int)cstart, lb, WAVE);
+        const u32 mA = (u32)__shfl((int)cmid, la, WAVE), mB = (u32)__shfl((int)cmid, lb, WAVE);
+        const u32 lA = (u32)__shfl((int)bitsLo, la, WAVE), lB = (u32)__shfl((int)bitsLo, lb, WAVE);
+        const u32 tA = (u32)__shfl((int)bitsTot, la, WAVE), tB = (u32)__shfl((int)bitsTot, lb, WAVE);
+        start = cc ? (mA | (mB << 16)) : (sA | (sB << 16));
+        bits = cc ? (tA - lA) + (tB - lB) : lA + lB;
+    }
+    u32 xa = 0, xb = 0;
 
     // ---- prefix sum of the bit counts over the block's lanes
     u32 incl = bits;
@@ -369,7 +450,6 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     for (int off = 1; off < (int)WV_LANES; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)hl >= off) incl += o; }
     const u32 excl = incl - bits;
     const u64 bodyBits = (u32)__shfl((int)incl, (int)(partBase + WV_LANES - 1u), WAVE);
-    const u32 fin = (u32)__shfl((int)end, (int)(partBase + lastLane), WAVE);
 
     // ---- verdict (BIT_closeCStream, bitstream.h:254-260): total bits incl. the two states and the end mark
     const u64 totalBits = bodyBits + 2u * tl + 1u;
@@ -397,23 +477,22 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
         WvSink k;
         const u32 lead = (u32)((uintptr_t)dst & (WV_RING - 1));
         const u32 off0 = lead + (excl >> 3);                                // my first byte, as an offset from dstAl
-        k.dstAl = dst - lead; k.ring = ringBase + hl * (WV_RING / 4);
+        k.dstAl = dst - lead; k.ring = ringBase + hl * (WV_RING / 4); k.ringA = wv_lds_addr(k.ring);
         k.woff = off0 & ~3u; k.done = off0; k.acc = 0; k.nacc = 8u * (off0 & 3u) + (excl & 7u);
         xa = start & 0xFFFFu; xb = start >> 16;
         wv_emit<TT4>(ttb, src, n, j0, j1, xa, xb, k);
         if (hl == lastLane) {
             // fse_compress.c:608-609 : CState2 then CState1.  n even -> CState2 is the even-distance chain (:577-580), n odd -> CState1 (:572-576)
-            const u32 fa = fin & 0xFFFFu, fb = fin >> 16;
-            const u32 c2 = (n & 1u) ? fb : fa, c1 = (n & 1u) ? fa : fb;
+            const u32 c2 = (n & 1u) ? xb : xa, c1 = (n & 1u) ? xa : xb;      // (the owner of the last range has just arrived at the final states)
             const u32 mask = (1u << tl) - 1u;
-            k.put(c2 & mask, tl); k.spill();
-            k.put(c1 & mask, tl); k.spill();
-            k.put(1u, 1u); k.spill();
+            k.push(c2 & mask, tl);
+            k.push(c1 & mask, tl);
+            k.push(1u, 1u);
             k.nacc = (k.nacc + 7u) & ~7u;                                   // the last partial byte is this lane's
         }
-        k.ring[(k.woff & (WV_RING - 1)) >> 2] = (u32)k.acc;                 // < 32 bits left
+        k.ring[(k.woff & (WV_RING - 1)) >> 2] = k.acc;                      // < 32 bits left
         k.copy_out(k.woff + (k.nacc >> 3));                                 // every complete byte
-        tail = (u32)(k.acc >> (k.nacc & ~7u));                              // < 8 bits, belong to the next lane's first byte
+        tail = k.acc >> (k.nacc & ~7u);                                   // < 8 bits, belong to the next lane's first byte
     }
     const u32 prevTail = (u32)__shfl_up((int)tail, 1, WAVE);
     if (on && mine && hl > 0 && (excl & 7u)) {
