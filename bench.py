@@ -29,6 +29,7 @@ Rank 0 prints ONE JSON line.  `value` = uncompressed MiB that went through encod
 (whole job, all ranks), inputs resident in HBM.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -490,7 +491,7 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=8))
         else:
             dist.init_process_group(backend)
     from finitestateentropy_amd import shard
@@ -629,7 +630,10 @@ def main():
             if corpus_note:
                 rec5["corpus_note"] = corpus_note
             if world > 1:
-                rec5["with_comm"] = with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, barrier, reduce_max, sharing)
+                try:
+                    rec5["with_comm"] = with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, barrier, reduce_max, sharing)
+                except Exception as e:   # the communication leg is a report beside the compute-only record, never a reason to lose the line
+                    rec5["with_comm"] = {"value": None, "error": repr(e)}
             del s5, cds5
         if want("fse_u16") and hasattr(hip, "fse_compress_u16_batch"):
             configs["fse_u16"] = u16_case(hip, dev, args.u16_blocks, cs, barrier, reduce_max, world, rank)
