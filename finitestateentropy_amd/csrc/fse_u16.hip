@@ -33,6 +33,11 @@
 #define U16_SYMS    (64 * U16_SPL)
 
 // ---- LDS of the builders (one wave per block) ------------------------------------------------------------------------------
+// TLMAX = the largest table log the instance builds: the cell -> symbol map is most of the footprint, and the footprint is what bounds
+// the builders (latency-bound, one wave per block: waves per CU).  The compress side never goes beyond 12 (k_u16_cprep), a stream may
+// carry 13: k_u16_dprep<12> leaves such blocks (meta.state 4) to a second launch of the 13-bit instance -- 12.5 KB -> 12 waves per CU
+// instead of 7 for everything the reference's compressor writes.
+template <u32 TLMAX>
 struct U16Lds {
     u32 cnt[U16_SYMS];          // histogram / scratch
     s16 nrm[U16_SYMS];          // normalised counters
@@ -41,7 +46,7 @@ struct U16Lds {
     u16 seen[U16_SYMS];         // cells of the symbol met so far (rank pass)
     u32 img[160];               // NCount header image
     u32 scal[8];
-    u16 symTab[1u << U16_MAXTL];   // symbol of every cell
+    u16 symTab[1u << TLMAX];       // symbol of every cell
 };
 
 DEV u32 u16_scan_excl(u32 v, u32 lane, u32* total)
@@ -55,8 +60,8 @@ DEV u32 u16_scan_excl(u32 v, u32 lane, u32* total)
 
 // Spread + rank for the counters in L.nrm (zero beyond maxSV).  Fills L.symTab and L.cum, then calls emit(u, symbol, rank) once per
 // cell, ranks ascending with u inside a symbol.  All 64 lanes, uniform arguments, the workgroup is this wave.
-template <class Emit>
-DEV void u16_spread_rank(U16Lds& L, u32 maxSV, u32 tl, u32 lane, Emit&& emit)
+template <u32 TLMAX, class Emit>
+DEV void u16_spread_rank(U16Lds<TLMAX>& L, u32 maxSV, u32 tl, u32 lane, Emit&& emit)
 {
     const u32 ts = 1u << tl, mask = ts - 1u, step = (ts >> 1) + (ts >> 3) + 3u;
     // ---- cumulative counts (lane l: symbols 5l .. 5l+4)
@@ -125,7 +130,7 @@ DEV void u16_spread_rank(U16Lds& L, u32 maxSV, u32 tl, u32 lane, Emit&& emit)
 // ---- compress side: FSE_compressU16 up to the table (fseU16.c:203-249) -------------------------------------------------------
 __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
 {
-    __shared__ U16Lds L;
+    __shared__ U16Lds<FSE_MAX_TL> L;                                        // (the compressor's table log is clamped to the byte coder's limit, see below)
     const u32 lane = threadIdx.x;
     const size_t b = blockIdx.x;
     const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
@@ -375,11 +380,13 @@ __global__ void k_u16_encode(U16CArgs a)
 }
 
 // ---- decompress side ------------------------------------------------------------------------------------------------------------
+template <u32 TLMAX>
 __global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
 {
-    __shared__ U16Lds L;
+    __shared__ U16Lds<TLMAX> L;
     const u32 lane = threadIdx.x;
     const size_t b = blockIdx.x;
+    if (TLMAX > 12 && a.meta[b].state != 4) return;                          // (second launch: only what the 12-bit instance left)
     const u8* const in = a.csrc + b * a.cStride;
     const size_t cSize = a.cSizes ? a.cSizes[b] : a.uniformCSize;
     U16Meta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
@@ -399,6 +406,7 @@ __global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
     const size_t r = ((size_t)L.scal[1] << 32) | L.scal[0];
     if (is_err(r)) { if (lane == 0) { a.results[b] = r; a.meta[b] = m; } return; }
     const u32 maxSV = L.scal[2], tl = L.scal[3], ts = 1u << tl;
+    if (tl > TLMAX) { m.state = 4; if (lane == 0) a.meta[b] = m; return; }    // uniform: the wide instance's block
     // Two table formats in the block's 32 KiB slot.  Table logs up to 12 (all the reference's compressor writes): the CHAIN cells
     // newState | nbBits << 12 as 16-bit words (the image k_u16_decode_lds keeps in LDS) followed, 16 KiB further on, by the 16-bit symbol
     // of every cell (gathered by its service waves) -- state 1.  Table log 13 needs 17 bits per chain cell: one 32-bit word per cell
@@ -467,7 +475,8 @@ hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s)
 hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_u16_dprep, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_u16_dprep<12>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_u16_dprep<U16_MAXTL>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);   // table log 13 (returns at once otherwise)
     const hipError_t e = launch_u16_decode_lds(a, s);                     // table logs up to 12: chain cells in LDS
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_u16_decode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);   // table log 13

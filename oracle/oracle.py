@@ -379,6 +379,21 @@ class Ref(_Base):
                        C.c_uint(max_sv), C.c_uint(table_log))
         return int(r), out[:cap]
 
+    def fse_build_ctable_u16(self, norm, max_sv, table_log):
+        """FSE_buildCTableU16 (lib/fseU16.c:103, fse_compress.c:66-169 compiled for 16-bit symbols): table logs up to 13"""
+        norm = np.ascontiguousarray(norm, dtype=np.int16)
+        ct = np.zeros(1 + (1 << (max(table_log, 1) - 1)) + (max_sv + 1) * 2 + 8, dtype=np.uint32)
+        r = self._call("FSE_buildCTableU16", self.sz, ct.ctypes.data_as(self.vp), norm.ctypes.data_as(self.vp), C.c_uint(max_sv), C.c_uint(table_log))
+        return int(r), ct
+
+    def fse_compress_u16_using_ctable(self, src, ct, cap):
+        """FSE_compressU16_usingCTable (lib/fseU16.c:150-200)"""
+        src = np.ascontiguousarray(src, dtype=np.uint16)
+        out = np.zeros(max(cap, 1) + 16, dtype=np.uint8)
+        r = self._call("FSE_compressU16_usingCTable", self.sz, out.ctypes.data_as(self.vp), self.sz(cap), src.ctypes.data_as(self.vp), self.sz(src.size),
+                       ct.ctypes.data_as(self.vp))
+        return int(r), out[:cap]
+
     def fse_decompress_u16(self, csrc, cap):
         csrc, ps = _u8(csrc)
         out = np.zeros(max(cap, 1) + 8, dtype=np.uint16)

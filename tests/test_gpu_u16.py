@@ -186,6 +186,106 @@ def test_decompress_u16_damaged_streams(hip, ref):
         assert r == ref.fse_decompress_u16(np.zeros(size, np.uint8), 10)[0] and is_error(r)
 
 
+def _write_ncount(norm, max_sv, tl):
+    """The NCount header (format: SURVEY A.2, written by lib/fse_compress.c:227-320) for any table log -- the reference's writer is
+    the byte coder's object and refuses 13.  Checked against the reference's bytes at table log 12 by the test below."""
+    out = bytearray()
+    bit_stream, bit_count = tl - 5, 4
+    remaining, threshold, nb = (1 << tl) + 1, 1 << tl, tl + 1
+    sym, prev0, alphabet = 0, False, max_sv + 1
+
+    def flush16():
+        nonlocal bit_stream, bit_count
+        out.append(bit_stream & 0xFF); out.append((bit_stream >> 8) & 0xFF)
+        bit_stream >>= 16; bit_count -= 16
+    while sym < alphabet and remaining > 1:
+        if prev0:
+            start = sym
+            while sym < alphabet and norm[sym] == 0:
+                sym += 1
+            assert sym < alphabet
+            while sym >= start + 24:
+                start += 24
+                bit_stream += 0xFFFF << bit_count
+                bit_count += 16; flush16()
+            while sym >= start + 3:
+                start += 3
+                bit_stream += 3 << bit_count; bit_count += 2
+            bit_stream += (sym - start) << bit_count; bit_count += 2
+            if bit_count > 16:
+                flush16()
+        count = int(norm[sym]); sym += 1
+        mx = (2 * threshold - 1) - remaining
+        remaining -= abs(count)
+        count += 1
+        if count >= threshold:
+            count += mx
+        bit_stream += count << bit_count
+        bit_count += nb - (1 if count < mx else 0)
+        prev0 = count == 1
+        assert remaining >= 1
+        while remaining < threshold:
+            nb -= 1; threshold >>= 1
+        if bit_count > 16:
+            flush16()
+    assert remaining == 1
+    out.append(bit_stream & 0xFF); out.append((bit_stream >> 8) & 0xFF)
+    return np.frombuffer(bytes(out[:len(out) - 2 + (bit_count + 7) // 8]), dtype=np.uint8).copy()
+
+
+def test_decompress_u16_table_log_13(hip, ref):
+    """Streams with a table log of 13: the reference's compressor never writes one (its normaliser and header writer are the byte
+    coder's, limit 12) but FSE_decompressU16 takes them (FSE_buildDTableU16 is instantiated with the 16-bit limits).  Built here from
+    the reference's own parts: counts normalised to 12 bits and doubled, header by the writer above, table and payload by
+    FSE_buildCTableU16 / FSE_compressU16_usingCTable.  Device side: k_u16_dprep's second launch and the lane-per-block decoder."""
+    rng = np.random.default_rng(8)
+    done = 0
+    for tl, nsym in ((12, 200), (9, 60), (12, 256), (6, 20)):                # the header writer above == the reference's where that one works
+        w = rng.random(nsym) ** 3
+        c = np.maximum(np.floor(w / w.sum() * (1 << tl)), 1).astype(np.int64)
+        c[np.argmax(c)] += (1 << tl) - int(c.sum())
+        c[int(rng.integers(1, nsym - 1))] = 0; c[np.argmax(c)] += (1 << tl) - int(c.sum())     # a zero inside the alphabet (run coding)
+        assert c.min() >= 0 and c[-1] > 0
+        r, h = ref.fse_write_ncount(600, c.astype(np.int16), nsym - 1, tl)
+        assert not is_error(r) and (h[:r] == _write_ncount(c, nsym - 1, tl)).all(), (tl, nsym)
+    for n, kind in ((5000, "p8"), (16384, "p8"), (3000, "flat"), (20000, "p80"), (4097, "p8")):
+        src = u16_block(rng, n, kind)
+        msv = int(src.max())
+        cnt = np.bincount(src, minlength=msv + 1).astype(np.uint32)
+        # the byte coder's normaliser takes at most 256 symbols: do it here (largest-remainder on 12 bits, every present symbol >= 1)
+        p = cnt.astype(np.float64) * 4096 / n
+        norm12 = np.maximum(np.floor(p), (cnt > 0)).astype(np.int64)
+        norm12[np.argmax(norm12)] += 4096 - int(norm12.sum())
+        assert norm12.min() >= 0 and int(norm12.sum()) == 4096 and (norm12[cnt > 0] > 0).all()
+        # check the header writer on this very distribution at table log 12 against the reference's (alphabets it accepts)
+        if msv <= 255:
+            r12, h12 = ref.fse_write_ncount(600, norm12.astype(np.int16), msv, 12)
+            assert not is_error(r12) and (h12[:r12] == _write_ncount(norm12, msv, 12)).all()
+        norm13 = (2 * norm12).astype(np.int16)
+        hdr = _write_ncount(norm13, msv, 13)
+        h, m2, tl2, back = ref.fse_read_ncount(hdr, MAXSV)
+        assert h == hdr.size and tl2 == 13 and m2 == msv and (back[:msv + 1] == norm13).all()
+        e, ct = ref.fse_build_ctable_u16(norm13, msv, 13)
+        assert not is_error(e)
+        cs, payload = ref.fse_compress_u16_using_ctable(src, ct, 2 * n + 1024)
+        assert not is_error(cs) and cs > 0
+        comp = np.concatenate([hdr, payload[:cs]])
+        for cap in (n, n + 9, n - 1):
+            rr, rout = ref.fse_decompress_u16(comp, cap)
+            r, out = hip.fse_decompress_u16(comp, cap)
+            assert r == rr, (n, kind, cap, r, rr)
+            if not is_error(rr):
+                assert (out[:rr] == rout[:rr]).all(), (n, kind, cap)
+                if cap >= n:
+                    assert rr == n and (rout[:n] == src).all()
+                done += 1
+        bad = comp.copy(); bad[int(rng.integers(hdr.size, comp.size))] ^= 0x10
+        rr, rout = ref.fse_decompress_u16(bad, n)
+        r, out = hip.fse_decompress_u16(bad, n)
+        assert r == rr, (n, kind, "damaged", r, rr)
+    assert done >= 8
+
+
 def test_u16_batch_ragged(hip, ref):
     rng = np.random.default_rng(7)
     nb, width = 97, 9000
