@@ -177,13 +177,28 @@ extern "C" int FSEHIP_probagen_batch_ex(void* d_dst, size_t dstStride, size_t bl
                                         const uint8_t h_table[4096], uint32_t firstSeed, uint32_t seedStep, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    u8* d_table = nullptr;
-    CK(hipMalloc(&d_table, 4096));
-    hipError_t e = hipMemcpyAsync(d_table, h_table, 4096, hipMemcpyHostToDevice, s);
+    // The 4 KiB table goes through a small per-thread ring of slots (device memory + pinned staging, allocated once): no
+    // hipMalloc / hipFree and no host synchronisation per call.  h_table is consumed before the call returns (host copy into
+    // the pinned slot); a slot is reused 16 calls later, after the event recorded behind the kernel that read it.
+    enum { SLOTS = 16 };
+    static thread_local struct { u8* dev = nullptr; u8* pin = nullptr; int device = -1; unsigned next = 0; hipEvent_t ev[SLOTS]; bool used[SLOTS]; } ring;
+    int dev = 0;
+    CK(hipGetDevice(&dev));
+    if (!ring.dev || ring.device != dev) {                    // (a ring left on another device stays with that context)
+        ring.dev = nullptr; ring.pin = nullptr;
+        CK(hipMalloc((void**)&ring.dev, SLOTS * 4096));
+        CK(hipHostMalloc((void**)&ring.pin, SLOTS * 4096, hipHostMallocDefault));
+        for (int i = 0; i < SLOTS; ++i) { CK(hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming)); ring.used[i] = false; }
+        ring.device = dev; ring.next = 0;
+    }
+    const unsigned k = ring.next++ % SLOTS;
+    if (ring.used[k]) CK(hipEventSynchronize(ring.ev[k]));
+    memcpy(ring.pin + 4096u * k, h_table, 4096);
+    u8* const d_table = ring.dev + 4096u * k;
+    hipError_t e = hipMemcpyAsync(d_table, ring.pin + 4096u * k, 4096, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = launch_probagen((u8*)d_dst, dstStride, blockSize, nBlocks, d_table, firstSeed, seedStep, s);
-    hipError_t e2 = hipStreamSynchronize(s);   // the table must outlive the kernel
-    (void)hipFree(d_table);
-    return (int)(e != hipSuccess ? e : e2);
+    if (e == hipSuccess) { e = hipEventRecord(ring.ev[k], s); ring.used[k] = e == hipSuccess; }
+    return (int)e;
 }
 
 // Argument errors of the one-shot calls are per-block results, like everything else the reference call would return for

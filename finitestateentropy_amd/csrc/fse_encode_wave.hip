@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64) void k_fse_enc_lists(FseEncArgs a)
 hipError_t launch_fse_enc_lists(const FseEncArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const hipError_t e = hipMemsetAsync(a.count, 0, FSE_EBINS * sizeof(u32), s);
+    const hipError_t e = launch_zero_u32(a.count, FSE_EBINS, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_fse_enc_lists, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();

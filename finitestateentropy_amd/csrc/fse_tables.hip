@@ -226,7 +226,7 @@ hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     const u32 capTs = 1u << a.maxLog;
-    hipError_t e = hipMemsetAsync(a.counts, 0, FSE_DCLS_COUNT * sizeof(u32), s);
+    hipError_t e = launch_zero_u32(a.counts, FSE_DCLS_COUNT, s);
     if (e != hipSuccess) return e;
     probe_before(PK_FSE_DPREP, s);
     hipLaunchKernelGGL(k_fse_dparse, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);

@@ -115,6 +115,18 @@ __global__ __launch_bounds__(64) void k_hist(HistArgs a)
     if (lane == 0) { if (a.maxSVs) a.maxSVs[b] = (unsigned)top; a.results[b] = (size_t)best; }
 }
 
+__global__ __launch_bounds__(64) void k_zero_u32(u32* p, u32 n)
+{
+    for (u32 i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) p[i] = 0;
+}
+hipError_t launch_zero_u32(u32* p, u32 n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const u32 groups = (n + 63u) / 64u;
+    hipLaunchKernelGGL(k_zero_u32, dim3(groups < 1024u ? groups : 1024u), dim3(64), 0, s, p, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_hist(const HistArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;

@@ -866,7 +866,7 @@ hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* /*unused
 hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    {   const hipError_t e = hipMemsetAsync(a.counts, 0, HUF_DCLS_COUNT * sizeof(u32), s); if (e != hipSuccess) return e; }
+    {   const hipError_t e = launch_zero_u32(a.counts, HUF_DCLS_COUNT, s); if (e != hipSuccess) return e; }
     probe_before(PK_HUF_DPREP, s);
     hipLaunchKernelGGL(k_huf_dprep<HP_G_DECOMPRESS>, dim3((unsigned)((a.nBlocks + HP_G_DECOMPRESS - 1) / HP_G_DECOMPRESS)), dim3(64), HP_G_DECOMPRESS * HP_SLOT, s, a);
     probe_after(PK_HUF_DPREP, s);

@@ -13,6 +13,10 @@ struct HistArgs {
     size_t nBlocks;
 };
 hipError_t launch_hist(const HistArgs& a, hipStream_t s);
+// n 32-bit words at p set to zero by a kernel of ours (p 4-byte aligned).  Used instead of hipMemsetAsync for the few counter words
+// the pipelines clear per call: captured into a HIP graph, the runtime's small-memset node faulted on later replays (ROCm 7.2, after
+// other work had been synchronised on the stream in between) -- a plain kernel node does not.
+hipError_t launch_zero_u32(u32* p, u32 n, hipStream_t s);
 
 // ---- FSE ------------------------------------------------------------------------------------------
 // per-block record shared by the prepare and the hot-loop kernels

@@ -111,6 +111,11 @@ FSEHIP_API size_t FSEHIP_HUF_decompress(void* dst, size_t originalSize, const vo
  *  the corresponding single-block reference call would return for block b.  `stream` is a
  *  hipStream_t (NULL = default stream).  Return value: 0 (hipSuccess) or a hipError_t.
  *  Launches are asynchronous on `stream`; the library never allocates on these paths.
+ *  Streams and graphs: a call is kernel launches on `stream` and nothing else -- no host synchronisation, no
+ *  read-back (what one stage decides for the next travels in device-side lists inside the workspace), no
+ *  memset or copy nodes -- so after one ordinary call (which sets the kernels' function attributes) the calls
+ *  can be captured into a HIP graph (hipStreamBeginCapture on `stream`) and replayed on new contents of the
+ *  same buffers (tests/test_gpu_graph.py).
  * ================================================================================================= */
 /* HIST_count over a batch.  d_counts: nBlocks x 256 unsigned (entries 0..min(maxSV_in,255) written).
  * d_maxSymbolValues: nBlocks in/out values (NULL = 255 in, not reported). */
@@ -183,7 +188,8 @@ FSEHIP_API int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
 
 /* Workload generator of the reference's benchmark (programs/probaGenerator.c:70-74,95-126), on the
  * device: block b = generate(blockSize bytes, table, seed = firstSeed + b).  h_table4096 is the
- * HOST 4096-entry symbol table built by FSEHIP_probagen_table(). */
+ * HOST 4096-entry symbol table built by FSEHIP_probagen_table(); it is consumed before the call returns (the
+ * call is asynchronous on `stream` like the others). */
 FSEHIP_API void FSEHIP_probagen_table(uint8_t table4096[4096], double p);
 FSEHIP_API int FSEHIP_probagen_batch(void* d_dst, size_t dstStride, size_t blockSize, size_t nBlocks,
                                      const uint8_t h_table4096[4096], uint32_t firstSeed, void* stream);

@@ -1,0 +1,72 @@
+"""The batched entry points are pure stream work (kernel launches and asynchronous memsets on the caller's stream, device-side
+lists instead of host read-backs), so a caller with a launch-bound inner loop -- small batches, many calls -- can capture them in a
+HIP graph and replay it (include/fsehip.h "Streams and graphs").  Captured here through torch.cuda.graph (hipStreamBeginCapture on
+torch's capture stream, which api.py hands to the library): the replays must produce what direct calls produce, for new source
+bytes in the same buffers, on both codecs and both directions."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _valid(dst, res):
+    k = int(res.max())
+    m = torch.arange(k, device=dst.device)[None, :] < res[:, None]
+    return dst[:, :k] * m
+
+
+@pytest.mark.parametrize("codec", ["fse", "huf"])
+def test_batched_calls_replay_from_a_hip_graph(hip, checker, codec):
+    n, size = 96, 32768
+    comp = hip.fse_compress_batch if codec == "fse" else hip.huf_compress_batch
+    deco = (lambda c, r: hip.fse_decompress_batch(c, r, size)) if codec == "fse" else (lambda c, r: hip.huf_decompress_batch(c, r, size))
+    src = hip.probagen_batch(14, n, size, first_seed=11).clone()
+    # static buffers of the graph
+    cws = hip.fse_workspace(n, 11, False) if codec == "fse" else hip.huf_workspace(n, False)
+    dws = hip.fse_workspace(n, 12, True) if codec == "fse" else hip.huf_workspace(n, True)
+    cdst, cres = comp(src, workspace=cws)                                   # warm-up outside the capture (one-time function attributes)
+    out, dres = deco(cdst, cres) if codec == "huf" else hip.fse_decompress_batch(cdst, cres, size, workspace=dws)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        if codec == "fse":
+            hip.fse_compress_batch(src, dst=cdst, results=cres, workspace=cws)
+            hip.fse_decompress_batch(cdst, cres, size, dst=out, results=dres, workspace=dws)
+        else:
+            hip.huf_compress_batch(src, dst=cdst, results=cres, workspace=cws)
+            hip.huf_decompress_batch(cdst, cres, size, dst=out, results=dres, workspace=dws)
+    for trial, (proba, seed) in enumerate(((14, 500), (80, 900), (2, 1300))):
+        src.copy_(hip.probagen_batch(proba, n, size, first_seed=seed))
+        cdst.zero_(); out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ed, er = comp(src)                                                   # the same work by direct calls into fresh buffers
+        assert torch.equal(cres, er), (codec, trial)
+        assert torch.equal(_valid(cdst, cres), _valid(ed, er)), (codec, trial)
+        assert bool((dres == size).all()) and torch.equal(out[:, :size], src), (codec, trial)
+        # and against the reference itself on a few blocks
+        h = src[:4].cpu().numpy()
+        for i in range(4):
+            r, ref_bytes = (checker.fse_compress2(h[i]) if codec == "fse" else checker.huf_compress2(h[i]))
+            assert int(cres[i]) == r and (cdst[i, :r].cpu().numpy() == ref_bytes[:r]).all(), (codec, trial, i)
+    # what the capture buys a launch-bound caller: time per round trip of this small batch, direct calls against one graph launch
+    def timed(fn, reps=30):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def direct():
+        if codec == "fse":
+            hip.fse_compress_batch(src, dst=cdst, results=cres, workspace=cws)
+            hip.fse_decompress_batch(cdst, cres, size, dst=out, results=dres, workspace=dws)
+        else:
+            hip.huf_compress_batch(src, dst=cdst, results=cres, workspace=cws)
+            hip.huf_decompress_batch(cdst, cres, size, dst=out, results=dres, workspace=dws)
+    td, tg = timed(direct), timed(g.replay)
+    print("\n%s round trip of %d x 32 KB blocks: direct calls %.1f us, graph replay %.1f us" % (codec, n, td * 1e6, tg * 1e6))
+    assert tg < 2.0 * td + 1e-3                                              # (not a performance gate: only that the replay is sane)
