@@ -88,14 +88,23 @@ def test_shard_ranges():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_scatter_compress_gather_world2():
+def _run_world(world, n_blocks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 37, 4096, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_blocks, 4096, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_scatter_compress_gather_world2():
+    _run_world(2, 37)
+
+
+def test_scatter_compress_gather_world3_uneven_shards():
+    """three ranks: the root's grouped scatter / gather has two peers, the shards are 14 + 13 + 13 blocks"""
+    _run_world(3, 40)
