@@ -1,5 +1,5 @@
 """development aid: extended randomized differential run against the CPU oracle (more seeds / sizes / table logs than the
-test suite affords): python scripts/soak.py [seconds]"""
+test suite affords): python scripts/soak.py [seconds [first seed]]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -12,7 +12,8 @@ hip = FseHip()
 oracle = Oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time()
-seed = 0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+seed0 = seed
 nblocks = 0
 while time.time() - t0 < budget:
     seed += 1
@@ -92,4 +93,4 @@ while time.time() - t0 < budget:
         good = want == size
         assert (out.cpu().numpy()[:, :size][good] == blocks[okh][good]).all(), ("huf dbytes", seed, size, htl)
     nblocks += len(blocks)
-print("soak ok: %d rounds, %d blocks, %.0f s" % (seed, nblocks, time.time() - t0))
+print("soak ok: seeds %d..%d, %d blocks, %.0f s" % (seed0 + 1, seed, nblocks, time.time() - t0))
