@@ -76,8 +76,8 @@ DEV uint4 wv_load16(const u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return 
 
 // Bit sink of one lane.  Bits are appended LSB-first; completed 32-bit words go to a small per-lane LDS ring that is
 // indexed by the low bits of the word's global address, and every time a WV_LINE-byte aligned piece of the output is
-// complete it is written to global memory with 16-byte stores (whole sectors: the compressed stream leaves the chip
-// once).  The first bytes of a lane (up to the first line boundary) and its last ones go out bytewise / wordwise.
+// complete it is written to global memory with 16-byte stores (whole 32-byte sectors; measured, 64-byte lines still leave
+// L2 in two halves often enough that 31 KB are written for 17 KB of payload).  The first bytes of a lane (up to the first line boundary) and its last ones go out bytewise / wordwise.
 #ifndef WV_LINE
 #define WV_LINE 32u
 #endif
