@@ -1,4 +1,4 @@
-"""The batched entry points are pure stream work (kernel launches and asynchronous memsets on the caller's stream, device-side
+"""The batched entry points are pure stream work (kernel launches on the caller's stream and nothing else, device-side
 lists instead of host read-backs), so a caller with a launch-bound inner loop -- small batches, many calls -- can capture them in a
 HIP graph and replay it (include/fsehip.h "Streams and graphs").  Captured here through torch.cuda.graph (hipStreamBeginCapture on
 torch's capture stream, which api.py hands to the library): the replays must produce what direct calls produce, for new source
@@ -70,3 +70,36 @@ def test_batched_calls_replay_from_a_hip_graph(hip, checker, codec):
     td, tg = timed(direct), timed(g.replay)
     print("\n%s round trip of %d x 32 KB blocks: direct calls %.1f us, graph replay %.1f us" % (codec, n, td * 1e6, tg * 1e6))
     assert tg < 2.0 * td + 1e-3                                              # (not a performance gate: only that the replay is sane)
+
+
+def test_u16_batched_calls_replay_from_a_hip_graph(hip):
+    """the 16-bit-symbol coder's batch calls (two table-builder launches, the LDS decoder, the lane-per-block kernels) captured too"""
+    import ctypes as C
+    n, nsym = 48, 16384
+    g0 = torch.Generator(device="cuda"); g0.manual_seed(5)
+
+    def make(seed):
+        g0.manual_seed(seed)
+        u = torch.rand((n, nsym), device="cuda", generator=g0)
+        return (torch.log1p(-u) / torch.log(torch.tensor(0.92, device="cuda"))).clamp_(0, 286).to(torch.int16)   # geometric over 287 symbols
+    src = make(1)
+    SZ = C.c_size_t
+    cws = torch.empty(int(hip.lib.FSEHIP_FSE_compressU16_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device="cuda")
+    dws = torch.empty(int(hip.lib.FSEHIP_FSE_decompressU16_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device="cuda")
+    cdst, cres = hip.fse_compress_u16_batch(src, workspace=cws)
+    out, dres = hip.fse_decompress_u16_batch(cdst, cres, nsym, workspace=dws)
+    torch.cuda.synchronize()
+    assert bool((dres == nsym).all()) and torch.equal(out[:, :nsym], src)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        hip.fse_compress_u16_batch(src, dst=cdst, results=cres, workspace=cws)
+        hip.fse_decompress_u16_batch(cdst, cres, nsym, dst=out, results=dres, workspace=dws)
+    for seed in (2, 3, 4, 5):
+        src.copy_(make(seed))
+        cdst.zero_(); out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ed, er = hip.fse_compress_u16_batch(src)
+        assert torch.equal(cres, er) and torch.equal(_valid(cdst, cres), _valid(ed, er)), seed
+        assert bool((dres == nsym).all()) and torch.equal(out[:, :nsym], src), seed
+        _ = src[:2].cpu()                                                     # (a host synchronisation between the replays)
