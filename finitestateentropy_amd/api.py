@@ -62,7 +62,55 @@ def _blocks(t, what):
     return t
 
 
+class _Guarded:
+    """Destination of a batched call in guard mode (FseHip.guard > 0): every block's slot is followed by `guard` bytes of 0xA5 -- the
+    row stride is capacity + guard, the capacity handed to the library stays `cap` -- and `check()` asserts after the call that no
+    kernel touched them: the device-side form of the reference fuzzers' guard byte (programs/fuzzer.c:217-230,
+    programs/fuzzerHuff0.c:198-212; SURVEY 8(b): nothing is written beyond dst + dstCapacity)."""
+    FILL = 0xA5
+
+    def __init__(self, n, cap, guard, device, dtype=torch.uint8, zero=False):
+        self.cap = cap
+        self.full = torch.empty((n, max(cap, 1) + guard), dtype=dtype, device=device)
+        self.fill = self.FILL if dtype == torch.uint8 else 0xA5A5 - 0x10000
+        self.full.fill_(self.fill)
+        self.view = self.full[:, :max(cap, 1)]
+        if zero and cap > 0:
+            self.view.zero_()
+
+    def check(self, what, sizes=None):
+        """sizes: per-block capacities (tensor) when they differ from block to block (Huff0 decoders: the exact regenerated size)"""
+        if sizes is None or isinstance(sizes, numbers.Integral):
+            cap = self.cap if sizes is None else int(sizes)
+            touched = self.full[:, cap:] != self.fill
+            caps = None
+        else:
+            caps = sizes.to(torch.int64).to(self.full.device).clamp(max=self.full.shape[1])
+            cols = torch.arange(self.full.shape[1], device=self.full.device)
+            touched = (self.full != self.fill) & (cols[None, :] >= caps[:, None])
+            cap = 0
+        bad = touched.any(dim=1)
+        if bool(bad.any().item()):
+            rows = torch.nonzero(bad).flatten()[:8].tolist()
+            b = rows[0]
+            where = (torch.nonzero(touched[b]).flatten()[:8] + cap).tolist()
+            raise AssertionError("%s wrote past its destination capacity (%s): blocks %s (block %d at byte offsets %s)"
+                                 % (what, self.cap if caps is None else int(caps[b]), rows, b, where))
+
+
 class FseHip:
+    # > 0: the batch helpers below that allocate their own destination put `guard` sentinel bytes (symbols for the 16-bit coder)
+    # behind every block's capacity and assert after the call that they are untouched (synchronises; tests only)
+    guard = 0
+
+    def _dst(self, n, cap, device, zero=False, dtype=torch.uint8):
+        """(destination tensor handed to the library, guard object or None)"""
+        if self.guard > 0:
+            g = _Guarded(n, cap, self.guard, device, dtype, zero)
+            return g.view, g
+        alloc = torch.zeros if zero else torch.empty
+        return alloc((n, max(cap, 1)), dtype=dtype, device=device), None
+
     def __init__(self):
         self.lib = _lib.load()
         L = self.lib
@@ -135,18 +183,20 @@ class FseHip:
     def fse_compress_using_ctable_batch(self, src, ctables, max_table_log=12, sizes=None, dst_capacity=None, shared_table=False):
         n = _blocks(src, "src").shape[0]
         cap = fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
-        dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        dst, g = self._dst(n, cap, src.device, zero=True)
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
         ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_FSE_compress_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
                                                               ps, uni, _ptr(ctables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()),
                "FSE_compress_usingCTable_batch")
+        if g:
+            g.check("FSE_compress_usingCTable_batch")
         return dst, res
 
     def fse_decompress_using_dtable_batch(self, csrc, csizes, dtables, dst_capacity, max_table_log=12, shared_table=False):
         n = _blocks(csrc, "csrc").shape[0]
-        dst = torch.zeros((n, max(dst_capacity, 1)), dtype=torch.uint8, device=csrc.device)
+        dst, g = self._dst(n, dst_capacity, csrc.device, zero=True)
         res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
         ps, uni, keep = _sizes_arg(csizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)
@@ -154,6 +204,8 @@ class FseHip:
                                                                 SZ(csrc.stride(0)), ps, uni, _ptr(dtables), SZ(stride),
                                                                 C.c_uint(max_table_log), SZ(n), _stream()),
                "FSE_decompress_usingDTable_batch")
+        if g:
+            g.check("FSE_decompress_usingDTable_batch")
         return dst, res
 
     # ------------------------------------------------------------------ one-shot FSE over a batch
@@ -165,8 +217,9 @@ class FseHip:
     def fse_compress_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
         n = _blocks(src, "src").shape[0]
         cap = (fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity)
+        g = None
         if dst is None:
-            dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+            dst, g = self._dst(n, cap, src.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=src.device)
         if workspace is None:
@@ -175,12 +228,15 @@ class FseHip:
         _check(self.lib.FSEHIP_FSE_compress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(src.stride(0)), ps, uni,
                                                   C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace),
                                                   SZ(workspace.numel()), _stream()), "FSE_compress_batch")
+        if g:
+            g.check("FSE_compress_batch")
         return dst, results
 
     def fse_decompress_batch(self, csrc, csizes, dst_capacity, max_log=12, dst=None, results=None, workspace=None):
         n = _blocks(csrc, "csrc").shape[0]
+        g = None
         if dst is None:
-            dst = torch.empty((n, max(dst_capacity, 1)), dtype=torch.uint8, device=csrc.device)
+            dst, g = self._dst(n, dst_capacity, csrc.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=csrc.device)
         if workspace is None:
@@ -189,6 +245,8 @@ class FseHip:
         _check(self.lib.FSEHIP_FSE_decompress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(results), _ptr(csrc), SZ(csrc.stride(0)),
                                                     ps, uni, C.c_uint(max_log), SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()),
                "FSE_decompress_batch")
+        if g:
+            g.check("FSE_decompress_batch")
         return dst, results
 
     # ------------------------------------------------------------------ layer 1 (host pointers, reference signatures)
@@ -233,8 +291,9 @@ def _huf_methods():
     def huf_compress_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
         n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        g = None
         if dst is None:
-            dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+            dst, g = self._dst(n, cap, src.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=src.device)
         if workspace is None:
@@ -243,13 +302,16 @@ def _huf_methods():
         _check(self.lib.FSEHIP_HUF_compress_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(src.stride(0)), ps, uni,
                                                   C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace),
                                                   SZ(workspace.numel()), _stream()), "HUF_compress_batch")
+        if g:
+            g.check("HUF_compress_batch")
         return dst, results
 
     def huf_decompress_batch(self, csrc, csizes, dst_sizes, dst=None, results=None, workspace=None):
         n = _blocks(csrc, "csrc").shape[0]
         width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
+        g = None
         if dst is None:
-            dst = torch.empty((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
+            dst, g = self._dst(n, width, csrc.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=csrc.device)
         if workspace is None:
@@ -258,32 +320,38 @@ def _huf_methods():
         pd, unid, keepd = _sizes_arg(dst_sizes, csrc)
         _check(self.lib.FSEHIP_HUF_decompress_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(results), _ptr(csrc), SZ(csrc.stride(0)), pc, unic,
                                                     SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()), "HUF_decompress_batch")
+        if g:
+            g.check("HUF_decompress_batch", dst_sizes)
         return dst, results
 
     def huf_compress4x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
         """ctables: (n, 256) int32/uint32 HUF_CElt entries (val | nbBits << 16)"""
         n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
-        dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        dst, g = self._dst(n, cap, src.device, zero=True)
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
         ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_HUF_compress4X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
                                                                 ps, uni, _ptr(ctables), SZ(stride), SZ(n), _stream()),
                "HUF_compress4X_usingCTable_batch")
+        if g:
+            g.check("HUF_compress4X_usingCTable_batch")
         return dst, res
 
     def huf_compress1x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
         """HUF_compress1X_usingCTable over a batch (lib/huf.h:290): one stream per block"""
         n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
-        dst = torch.zeros((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+        dst, g = self._dst(n, cap, src.device, zero=True)
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
         ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_HUF_compress1X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
                                                                 ps, uni, _ptr(ctables), SZ(stride), SZ(n), _stream()),
                "HUF_compress1X_usingCTable_batch")
+        if g:
+            g.check("HUF_compress1X_usingCTable_batch")
         return dst, res
 
     def huf_decompress4x_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
@@ -293,13 +361,15 @@ def _huf_methods():
     def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, _fn="FSEHIP_HUF_decompress4X1_usingDTable_batch"):
         n = _blocks(csrc, "csrc").shape[0]
         width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
-        dst = torch.zeros((n, max(width, 1)), dtype=torch.uint8, device=csrc.device)
+        dst, g = self._dst(n, width, csrc.device, zero=not self.guard)
         res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
         pc, unic, keepc = _sizes_arg(csizes, csrc)
         pd, unid, keepd = _sizes_arg(dst_sizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)
         _check(getattr(self.lib, _fn)(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(res), _ptr(csrc), SZ(csrc.stride(0)),
                                       pc, unic, _ptr(dtables), SZ(stride), C.c_uint(max_table_log), SZ(n), _stream()), _fn)
+        if g:
+            g.check(_fn, dst_sizes)
         return dst, res
 
     # layer 1
@@ -385,8 +455,9 @@ def _u16_methods():
     def fse_compress_u16_batch(self, src, table_log=0, max_symbol_value=0, sizes=None, dst=None, dst_capacity=None, results=None, workspace=None):
         n = _blocks16(src, "src").shape[0]
         cap = fse_u16_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
+        g = None
         if dst is None:
-            dst = torch.empty((n, max(cap, 1)), dtype=torch.uint8, device=src.device)
+            dst, g = self._dst(n, cap, src.device)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=src.device)
         if workspace is None:
@@ -395,12 +466,15 @@ def _u16_methods():
         _check(self.lib.FSEHIP_FSE_compressU16_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(results), _ptr(src), SZ(2 * src.stride(0)), ps, uni,
                                                      C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()),
                "FSE_compressU16_batch")
+        if g:
+            g.check("FSE_compressU16_batch")
         return dst, results
 
     def fse_decompress_u16_batch(self, csrc, csizes, dst_capacity, dst=None, results=None, workspace=None):
         n = _blocks(csrc, "csrc").shape[0]
+        g = None
         if dst is None:
-            dst = torch.empty((n, max(dst_capacity, 1)), dtype=torch.int16, device=csrc.device)
+            dst, g = self._dst(n, dst_capacity, csrc.device, dtype=torch.int16)
         if results is None:
             results = torch.empty(n, dtype=torch.int64, device=csrc.device)
         if workspace is None:
@@ -408,6 +482,8 @@ def _u16_methods():
         ps, uni, keep = _sizes_arg(csizes, csrc)
         _check(self.lib.FSEHIP_FSE_decompressU16_batch(_ptr(dst), SZ(2 * dst.stride(0)), SZ(dst_capacity), _ptr(results), _ptr(csrc), SZ(csrc.stride(0)), ps, uni,
                                                        SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()), "FSE_decompressU16_batch")
+        if g:
+            g.check("FSE_decompressU16_batch")
         return dst, results
 
     # host pointers, reference signatures

@@ -154,7 +154,14 @@ FSEHIP_API int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
 
 /* Huff0: HUF_compress4X_usingCTable / HUF_decompress4X1_usingDTable over a batch, and the one-shot
  * HUF_compress2 / HUF_decompress (4X1 decoder) over a batch.  For the one-shot decoder d_dstSizes (or
- * uniformDstSize) is the exact regenerated size of each block, as HUF_decompress requires. */
+ * uniformDstSize) is the exact regenerated size of each block, as HUF_decompress requires.
+ * Memory contract of the batched calls (tests/test_gpu_edges.py, guard mode of tests/conftest.py): nothing is read behind
+ * src + srcSize / cSrc + cSrcSize, nothing is written behind dst + dstCapacity (decoders: dst + dstSize); FSE tables are read
+ * at their exact sizes (FSE_CTABLE_SIZE_U32(tableLog, maxSymbolValue) / FSE_DTABLE_SIZE_U32(tableLog) of the table's own header),
+ * Huff0 DTables at 1 + (1 << tableLog) cells of their type.  A HUF_CElt table carries no header, so every table of a batch must
+ * be readable at HUF_CTABLE_SIZE_U32(255) = 256 entries (what the reference's own callers declare, lib/huf_compress.c:628-632);
+ * entries of symbols that do not occur are not interpreted.  The single-block calls on host pointers read only the entries of
+ * symbols present in src, like the reference. */
 FSEHIP_API int FSEHIP_HUF_compress4X_usingCTable_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
                                                        const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
                                                        const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,

@@ -46,4 +46,9 @@ def hip():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     from finitestateentropy_amd.api import FseHip
+    # Guard mode for the whole GPU suite (SURVEY 8(b) "never write beyond dst + dstCapacity"; the reference's fuzzers check a guard
+    # byte, programs/fuzzer.c:217-230, fuzzerHuff0.c:198-212): every destination the binding allocates gets a row stride of
+    # capacity + guard with 0xA5 behind each block's capacity, asserted untouched after every batched call.  FSEHIP_TEST_GUARD=0
+    # switches it off, an odd value additionally misaligns every slot.
+    FseHip.guard = int(os.environ.get("FSEHIP_TEST_GUARD", "64"))
     return FseHip()

@@ -397,3 +397,41 @@ def test_oneshot_batch_argument_errors(hip, oracle):
     _, res = hip.huf_compress_batch(big, table_log=13)
     r, _ = oracle.huf_compress2(np.zeros(131073, np.uint8), 255, 13)
     assert res.cpu().numpy()[0] == s64(r)
+
+
+def test_huf_oneshot_valid_max_symbol_value_below_255(hip, oracle):
+    """HUF_compress2 with a VALID maxSymbolValue < 255 (lib/huf_compress.c:661-671 -> HIST_count_wksp, lib/hist.c:128,169-170):
+    exact fit, one too small (maxSymbolValue_tooSmall per block), generous limits; bytes, return values, decode."""
+    n = 48
+    for P in (14, 80, 2):
+        src = hip.probagen_batch(P, n, 32768, first_seed=91)
+        host = src.cpu().numpy()
+        seen = int(host.max())
+        for msv in sorted({seen, seen - 1, seen + 1, max(seen // 2, 1), 1, 100, 200, 254} - {0}):
+            if msv > 255:
+                continue
+            for tl in (11, 12, 0):
+                dst, res = hip.huf_compress_batch(src, table_log=tl, max_symbol_value=msv)
+                dh, rh = dst.cpu().numpy(), res.cpu().numpy()
+                for b in range(0, n, 5):
+                    r, out = oracle.huf_compress2(host[b], msv, tl)
+                    assert rh[b] == s64(r), (P, msv, tl, b, rh[b], r)
+                    if msv < int(host[b].max()):
+                        assert rh[b] == -7
+                    elif r > 1:
+                        assert (dh[b][:r] == out[:r]).all(), (P, msv, tl, b)
+                if msv >= seen and (rh > 1).all():
+                    out, dres = hip.huf_decompress_batch(dst, res, 32768)
+                    assert (dres.cpu().numpy() == 32768).all() and torch.equal(out, src), (P, msv, tl)
+    blocks = mixed_blocks(oracle, 30, 4096, seed=19)
+    src = torch.from_numpy(blocks).cuda()
+    sizes = torch.tensor([4096 - 41 * (b % 5) for b in range(30)], dtype=torch.int64, device="cuda")
+    hs = sizes.cpu().numpy()
+    for msv in (6, 52, 53, 199, 200, 254):
+        dst, res = hip.huf_compress_batch(src, table_log=11, max_symbol_value=msv, sizes=sizes)
+        dh, rh = dst.cpu().numpy(), res.cpu().numpy()
+        for b in range(30):
+            r, out = oracle.huf_compress2(blocks[b][:hs[b]], msv, 11)
+            assert rh[b] == s64(r), (msv, b, rh[b], r)
+            if not is_error(r) and r > 1:
+                assert (dh[b][:r] == out[:r]).all(), (msv, b)
