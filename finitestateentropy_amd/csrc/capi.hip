@@ -177,20 +177,30 @@ extern "C" int FSEHIP_probagen_batch_ex(void* d_dst, size_t dstStride, size_t bl
                                         const uint8_t h_table[4096], uint32_t firstSeed, uint32_t seedStep, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    // The 4 KiB table goes through a small per-thread ring of slots (device memory + pinned staging, allocated once): no
+    // The 4 KiB table goes through a small per-thread, per-device ring of slots (device memory + pinned staging, allocated once): no
     // hipMalloc / hipFree and no host synchronisation per call.  h_table is consumed before the call returns (host copy into
     // the pinned slot); a slot is reused 16 calls later, after the event recorded behind the kernel that read it.
     enum { SLOTS = 16 };
-    static thread_local struct { u8* dev = nullptr; u8* pin = nullptr; int device = -1; unsigned next = 0; hipEvent_t ev[SLOTS]; bool used[SLOTS]; } ring;
+    struct Ring { u8* dev = nullptr; u8* pin = nullptr; int device = -1; unsigned next = 0; hipEvent_t ev[SLOTS] = {}; bool used[SLOTS] = {}; int nEv = 0;
+                  void drop() { for (int i = 0; i < nEv; ++i) (void)hipEventDestroy(ev[i]); nEv = 0;
+                                if (pin) (void)hipHostFree(pin); if (dev) (void)hipFree(dev); pin = nullptr; dev = nullptr; device = -1; (void)hipGetLastError(); } };
+    struct Rings { std::vector<Ring> v; ~Rings() { for (auto& r : v) r.drop(); } };
+    static thread_local Rings rings;                              // one ring per device the thread has generated on
     int dev = 0;
     CK(hipGetDevice(&dev));
-    if (!ring.dev || ring.device != dev) {                    // (a ring left on another device stays with that context)
-        ring.dev = nullptr; ring.pin = nullptr;
-        CK(hipMalloc((void**)&ring.dev, SLOTS * 4096));
-        CK(hipHostMalloc((void**)&ring.pin, SLOTS * 4096, hipHostMallocDefault));
-        for (int i = 0; i < SLOTS; ++i) { CK(hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming)); ring.used[i] = false; }
-        ring.device = dev; ring.next = 0;
+    Ring* rp = nullptr;
+    for (auto& r : rings.v) if (r.device == dev) rp = &r;
+    if (!rp) {
+        Ring r;
+        hipError_t e = hipMalloc((void**)&r.dev, SLOTS * 4096);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&r.pin, SLOTS * 4096, hipHostMallocDefault);
+        for (int i = 0; i < SLOTS && e == hipSuccess; ++i) { e = hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming); if (e == hipSuccess) r.nEv = i + 1; }
+        if (e != hipSuccess) { r.drop(); return (int)e; }         // nothing half-built is kept
+        r.device = dev;
+        rings.v.push_back(r);
+        rp = &rings.v.back();
     }
+    Ring& ring = *rp;
     const unsigned k = ring.next++ % SLOTS;
     if (ring.used[k]) CK(hipEventSynchronize(ring.ev[k]));
     memcpy(ring.pin + 4096u * k, h_table, 4096);
@@ -309,6 +319,7 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
                                          void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     if (tableLog > FSEHIP_FSE_MAX_TABLELOG)                                       // FSE_compress2 -> tableLog_tooLarge for every block (fse_compress.c:691)
         return batch_arg_error(d_results, nullptr, 0, dstCapacity, nBlocks, FSEHIP_ERROR(tableLog_tooLarge), 0, s);
@@ -328,7 +339,6 @@ extern "C" int FSEHIP_FSE_compress_batch(void* d_dst, size_t dstStride, size_t d
     if (chunk >= nBlocks) chunk = nBlocks;
     else chunk = round_chunk(chunk, fse_encode_blocks_per_round(w.maxTl));
     // carve the workspace
-    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
     unsigned* counts = (unsigned*)carve(chunk * 1024);
@@ -383,6 +393,7 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
                                            void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     maxLog = clamp_maxlog(maxLog);
     const size_t per = fse_dws_per_block(maxLog);
@@ -390,7 +401,6 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     size_t chunk = (workspaceBytes - WS_SLACK) / per;
     if (chunk >= nBlocks) chunk = nBlocks;
     else chunk = round_chunk(chunk, fse_decode_blocks_per_round(maxLog));
-    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // the decoder reads its bin lengths with one 16-byte load
     u8* p = (u8*)d_workspace;
     FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
     s16* norms = (s16*)p; p += align_up(chunk * 512, 256);
@@ -418,8 +428,12 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
 //  Layer 1: single-block calls on host pointers = batch of one (H2D, kernels, D2H)
 // =====================================================================================================
 namespace {
+// hipFree takes a pointer of any device, so an arena is given back wherever it was allocated: when the thread moves to another device,
+// when it grows, on FSEHIP_releaseScratch and when the thread ends (thread_local destructors run at thread exit and, for the main
+// thread, before the destructors of static objects -- the runtime is still there; an error from a runtime already shut down is ignored).
 struct Arena { void* base = nullptr; size_t cap = 0, used = 0, live = 0, peak = 0; int dev = -1;
-               ~Arena() { /* process / thread teardown: the runtime may already be gone -- the memory goes with the context */ } };
+               void drop() { if (base) { (void)hipFree(base); (void)hipGetLastError(); } base = nullptr; cap = 0; used = 0; dev = -1; }
+               ~Arena() { if (live == 0) drop(); } };
 thread_local Arena t_arena;
 }
 hipError_t HostCallBuf::alloc(size_t n)
@@ -433,8 +447,8 @@ hipError_t HostCallBuf::alloc(size_t n)
         size_t want = A.peak > need ? A.peak : need;
         if (want > FSEHIP_SCRATCH_MAX) want = FSEHIP_SCRATCH_MAX;
         if (A.dev != dev || A.cap < want) {
-            if (A.base && A.dev == dev) (void)hipFree(A.base);
-            A.base = nullptr; A.cap = 0; A.dev = dev;
+            A.drop();                                             // (also an arena left on the device the thread used before)
+            A.dev = dev;
             if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
             if (hipMalloc(&A.base, want) == hipSuccess) A.cap = want; else { A.base = nullptr; (void)hipGetLastError(); }
         }
@@ -462,7 +476,7 @@ extern "C" int FSEHIP_releaseScratch(void)
     Arena& A = t_arena;
     if (A.live) return (int)hipErrorInvalidValue;
     hipError_t e = hipSuccess;
-    if (A.base) { int dev = 0; e = hipGetDevice(&dev); if (e == hipSuccess && dev == A.dev) e = hipFree(A.base); }
+    if (A.base) e = hipFree(A.base);                              // whatever device the thread is on now
     A.base = nullptr; A.cap = 0; A.used = 0; A.peak = 0; A.dev = -1;
     return (int)e;
 }
@@ -632,6 +646,7 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
                                          void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255)               // huf_compress.c:656-660, in the reference's order, per block
         return batch_arg_error(d_results, d_sizes, uniformSize, dstCapacity, nBlocks,
@@ -639,7 +654,6 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
     if (workspaceBytes < HUF_CWS_PER_BLOCK + HUF_CWS_NODE_PAD + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK - HUF_CWS_NODE_PAD) / HUF_CWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
-    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
     unsigned* counts = (unsigned*)carve(chunk * 1024);
@@ -682,11 +696,11 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
                                            size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     if (workspaceBytes < HUF_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / HUF_DWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
-    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     const size_t dtU32 = FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1);      // 2-byte cells: 2^tableLog cells = 2^(tableLog-1) words
     HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
@@ -843,11 +857,11 @@ extern "C" int FSEHIP_FSE_compressU16_batch(void* d_dst, size_t dstStride, size_
                                             void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     if (workspaceBytes < U16_CWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / U16_CWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
-    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     u16* stateTables = (u16*)p; p += align_up(chunk * ((size_t)2 << FSEHIP_FSEU16_MAX_TABLELOG), 256);
     u32* symTT = (u32*)p; p += align_up(chunk * 8 * (FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1), 256);
@@ -870,11 +884,11 @@ extern "C" int FSEHIP_FSE_decompressU16_batch(unsigned short* d_dst, size_t dstS
                                               const size_t* d_cSizes, size_t uniformCSize, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     if (workspaceBytes < U16_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
     size_t chunk = (workspaceBytes - WS_SLACK) / U16_DWS_PER_BLOCK;
     if (chunk >= nBlocks) chunk = nBlocks;
-    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
     u8* p = (u8*)d_workspace;
     u32* cells = (u32*)p; p += align_up(chunk * ((size_t)4 << FSEHIP_FSEU16_MAX_TABLELOG), 256);
     U16Meta* meta = (U16Meta*)p;

@@ -21,6 +21,7 @@
 //     bytes above the stream start, where every reload is the "fast" one (:378-388) and (ptr, bitsConsumed) are a
 //     function of the absolute bit position alone.
 #include "internal.h"
+#include <atomic>
 
 #include "bitreader.h"
 
@@ -87,7 +88,7 @@
 //   clock the kernel really ran at), [13] cycles from kernel entry to the first phase (table staging, reader set-up, first ring fill),
 //   [14] cycles from the last phase to the end (literal tail), [15] / [10] cycles / number of rounds that ran finishing phases only
 __device__ unsigned long long g_decTiming[16];
-static bool g_decTimingOn = false;
+static std::atomic<bool> g_decTimingOn{false};   // benchmark-only switch (FSEHIP_debug_decodeTiming): process-wide, meant for one thread that owns the device while it is on
 #define TIMING(...) do { if constexpr (TIMED) { __VA_ARGS__ } } while (0)
 struct BulkState { u32 s, q, bq; };     // this lane's state (cell address) and the pair's bit cursor
 
@@ -754,7 +755,7 @@ static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
     fse_decode_geometry(a.ldsLog, ldsBytes, &a.slotU32, &a.G);
     if (a.G < 1) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
-    if (rev && g_decTimingOn) hipLaunchKernelGGL((k_fse_decode<true, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    if (rev && g_decTimingOn.load(std::memory_order_relaxed)) hipLaunchKernelGGL((k_fse_decode<true, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     else if (rev) hipLaunchKernelGGL((k_fse_decode<true, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     else          hipLaunchKernelGGL((k_fse_decode<false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     return hipGetLastError();
@@ -770,10 +771,10 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decodeTiming(
     if (enable) {
         unsigned long long zero[16] = { 0 };
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_decTiming), zero, sizeof(zero));
-        g_decTimingOn = e == hipSuccess;
+        g_decTimingOn.store(e == hipSuccess);
         return (int)e;
     }
-    g_decTimingOn = false;
+    g_decTimingOn.store(false);
     if (!out16) return 0;
     e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_decTiming), sizeof(g_decTiming));
     if (e != hipSuccess) return (int)e;

@@ -180,12 +180,20 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     if (tableType == 0) {
         const u32 words = 1u << (dtLog - 1);
         u16* const s = (u16*)lds;
+        // The loops below advance by the cells' nbBits alone: a cell of a caller-built (zero-filled, half-built, damaged) table with
+        // nbBits 0 would pin the cursor for ever, one beyond the table log breaks the 48-bits-per-iteration bound of hpar_run.  The
+        // reference's loop is bounded by its output pointer whatever the table says (lib/huf_decompress.c:214-237), and so is the
+        // serial kernel: such a table is declined to it.
+        bool badCell = false;
         for (u32 i = lane; i < words; i += 64) {
             const u32 w = gt[1 + i];
+            const u32 nb0 = (w >> 8) & 0xFFu, nb1 = (w >> 24) & 0xFFu;
+            badCell |= (nb0 - 1u >= dtLog) | (nb1 - 1u >= dtLog);
             const u32 r0 = __brev(2u * i) >> (32u - dtLog);
-            s[r0] = (u16)(((w >> 8) & 0xFFu) | ((w & 0xFFu) << 8));
-            s[r0 | (1u << (dtLog - 1))] = (u16)(((w >> 24) & 0xFFu) | (((w >> 16) & 0xFFu) << 8));
+            s[r0] = (u16)(nb0 | ((w & 0xFFu) << 8));
+            s[r0 | (1u << (dtLog - 1))] = (u16)(nb1 | (((w >> 16) & 0xFFu) << 8));
         }
+        if (__any(badCell)) { decline(); return; }                       // uniform
     } else if constexpr (X2CAP) {
         // ---- a double-symbol table from the reference's HUF_readDTableX2 (lib/huf_decompress.c:460-640): cell v = {u16 sequence; u8 nbBits;
         //      u8 length} -- the one or two symbols the next tableLog bits v start with and what they consume together.  A prefix code

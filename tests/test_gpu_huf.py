@@ -435,3 +435,61 @@ def test_huf_oneshot_valid_max_symbol_value_below_255(hip, oracle):
             assert rh[b] == s64(r), (msv, b, rh[b], r)
             if not is_error(r) and r > 1:
                 assert (dh[b][:r] == out[:r]).all(), (msv, b)
+
+
+@pytest.mark.timeout(300)
+def test_huf_x1_damaged_tables(hip, ref):
+    """Caller-built SINGLE-symbol tables that no HUF_readDTableX1 would produce -- cells with nbBits 0 (a zero-filled or half-built
+    table), bit counts beyond the table log, other symbols -- through the batch call and the single-block call: the stream-parallel
+    decoder advances by the cells' nbBits alone and must not vouch for (or spin on) such a table; whatever the reference makes of it
+    (lib/huf_decompress.c:214-237,262-354: its loops are bounded by the output pointer) is reproduced by the serial kernel."""
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    rng = np.random.default_rng(21)
+    W = 1 + (1 << 11)
+    for size in (32768, 6000):
+        blocks, tables, streams = [], [], []
+        for i, P in enumerate((14, 2, 80, 50, 14, 2)):
+            blk = orc.probagen_batch(P, 1, size, 300 + i)[0]
+            cs, c = ref.huf_compress2(blk)
+            assert cs > 1
+            h, dt = ref.huf_read_dtable_x1(c[:cs], 11)
+            assert not is_error(h)
+            dt = np.pad(dt, (0, max(W - len(dt), 0)))[:W].copy()
+            tl = (int(dt[0]) >> 16) & 0xFF
+            cells = dt[1:].view(np.uint16)                        # {byte, nbBits} per cell, low byte first
+            kind = i % 6
+            pick = rng.integers(0, 1 << tl, 5)
+            if kind == 0:
+                cells[pick] &= 0x00FF                             # nbBits 0 in a few cells
+            elif kind == 1:
+                cells[: 1 << tl] = 0                              # zero-filled table behind a plausible descriptor
+            elif kind == 2:
+                cells[pick] = (cells[pick] & 0x00FF) | ((tl + 1 + (pick & 3)).astype(np.uint16) << 8)   # more bits than the table log
+            elif kind == 3:
+                cells[pick] ^= 0x0011                             # other symbols (a valid decode of other bytes)
+            elif kind == 4:
+                cells[0] &= 0x00FF                                # the all-zero index only
+            else:
+                cells[(1 << tl) - 1] = 0xFF00 | (cells[(1 << tl) - 1] & 0xFF)   # nbBits 255 on the all-ones index
+            blocks.append(blk); tables.append(dt); streams.append(c[h:cs].copy())
+        n = len(blocks)
+        cbuf = np.zeros((n, max(len(s) for s in streams) + 8), np.uint8); csz = np.zeros(n, np.int64)
+        for i, s in enumerate(streams):
+            cbuf[i, :len(s)] = s; csz[i] = len(s)
+        d_c = torch.from_numpy(cbuf).cuda(); d_sz = torch.from_numpy(csz).cuda()
+        d_dt = torch.from_numpy(np.stack(tables).view(np.int32)).cuda()
+        for fn in (hip.huf_decompress4x1_using_dtable_batch, hip.huf_decompress4x_using_dtable_batch):
+            out, res = fn(d_c, d_sz, d_dt, size, max_table_log=11)
+            out, res = out.cpu().numpy(), res.cpu().numpy()
+            for i in range(n):
+                r, exp = ref.huf_decompress4x1_using_dtable(streams[i], tables[i], size)
+                assert res[i] == s64(r), (size, i, res[i], r)
+                if not is_error(r):
+                    assert (out[i][:r] == exp[:r]).all(), (size, i)
+        for i in range(n):
+            r, exp = ref.huf_decompress4x1_using_dtable(streams[i], tables[i], size)
+            rg, og = hip.huf_decompress4x1_using_dtable(streams[i], tables[i], size)
+            assert rg == r, (size, i, rg, r)
+            if not is_error(r):
+                assert (og[:r] == exp[:r]).all(), (size, i)
