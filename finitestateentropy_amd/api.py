@@ -123,7 +123,9 @@ class FseHip:
                      "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize",
                      "FSEHIP_frame_compressBound", "FSEHIP_frame_compress", "FSEHIP_frame_decompress",
                      "FSEHIP_FSE_countU16", "FSEHIP_FSE_compressU16", "FSEHIP_FSE_decompressU16",
-                     "FSEHIP_FSE_compressU16_batch_workspaceSize", "FSEHIP_FSE_decompressU16_batch_workspaceSize"):
+                     "FSEHIP_FSE_compressU16_batch_workspaceSize", "FSEHIP_FSE_decompressU16_batch_workspaceSize",
+                     "FSEHIP_FSE_buildCTable_batch_workspaceSize", "FSEHIP_FSE_buildDTable_batch_workspaceSize",
+                     "FSEHIP_HUF_buildCTable_batch_workspaceSize", "FSEHIP_HUF_readDTableX1_batch_workspaceSize"):
             if hasattr(L, name):
                 getattr(L, name).restype = SZ
         L.FSEHIP_getErrorName.restype = C.c_char_p
@@ -249,6 +251,35 @@ class FseHip:
             g.check("FSE_decompress_batch")
         return dst, results
 
+    # ------------------------------------------------------------------ tables built on the device (g1-g3)
+    def fse_build_ctable_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, header_capacity=512):
+        """FSE_buildCTable_batch: (ctables (n, FSE_CTABLE_SIZE_U32(max(table_log, 9), 255)) int32, headers (n, header_capacity) uint8, results)"""
+        n = _blocks(src, "src").shape[0]
+        tl = min(max(table_log or 11, 9), 12)
+        ctw = 1 + (1 << (tl - 1)) + 512
+        ct = torch.zeros((n, ctw), dtype=torch.int32, device=src.device)
+        hdr, g = self._dst(n, header_capacity, src.device, zero=True)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        ws = torch.empty(int(self.lib.FSEHIP_FSE_buildCTable_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
+        _check(self.lib.FSEHIP_FSE_buildCTable_batch(_ptr(ct), SZ(ct.stride(0)), _ptr(hdr), SZ(hdr.stride(0)), SZ(header_capacity), _ptr(res), _ptr(src),
+                                                     SZ(src.stride(0)), ps, uni, C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(ws),
+                                                     SZ(ws.numel()), _stream()), "FSE_buildCTable_batch")
+        if g:
+            g.check("FSE_buildCTable_batch")
+        return ct, hdr, res
+
+    def fse_build_dtable_batch(self, headers, header_sizes, max_log=12):
+        """FSE_buildDTable_batch: (dtables (n, FSE_DTABLE_SIZE_U32(max_log)) int32 in the reference layout, results = header bytes or error)"""
+        n = _blocks(headers, "headers").shape[0]
+        dt = torch.zeros((n, 1 + (1 << max_log)), dtype=torch.int32, device=headers.device)
+        res = torch.zeros(n, dtype=torch.int64, device=headers.device)
+        ws = torch.empty(int(self.lib.FSEHIP_FSE_buildDTable_batch_workspaceSize(SZ(n), C.c_uint(max_log))), dtype=torch.uint8, device=headers.device)
+        ps, uni, keep = _sizes_arg(header_sizes, headers)
+        _check(self.lib.FSEHIP_FSE_buildDTable_batch(_ptr(dt), SZ(dt.stride(0)), _ptr(res), _ptr(headers), SZ(headers.stride(0)), ps, uni,
+                                                     C.c_uint(max_log), SZ(n), _ptr(ws), SZ(ws.numel()), _stream()), "FSE_buildDTable_batch")
+        return dt, res
+
     # ------------------------------------------------------------------ layer 1 (host pointers, reference signatures)
     def _single(self, fname, cap, src, *extra):
         src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -372,6 +403,32 @@ def _huf_methods():
             g.check(_fn, dst_sizes)
         return dst, res
 
+    def huf_build_ctable_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, header_capacity=256):
+        """HUF_buildCTable_batch: (ctables (n, 256) int32 HUF_CElt, headers (n, header_capacity) uint8, results)"""
+        n = _blocks(src, "src").shape[0]
+        ct = torch.zeros((n, 256), dtype=torch.int32, device=src.device)
+        hdr, g = self._dst(n, header_capacity, src.device, zero=True)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        ws = torch.empty(int(self.lib.FSEHIP_HUF_buildCTable_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
+        _check(self.lib.FSEHIP_HUF_buildCTable_batch(_ptr(ct), SZ(ct.stride(0)), _ptr(hdr), SZ(hdr.stride(0)), SZ(header_capacity), _ptr(res), _ptr(src),
+                                                     SZ(src.stride(0)), ps, uni, C.c_uint(max_symbol_value), C.c_uint(table_log), SZ(n), _ptr(ws),
+                                                     SZ(ws.numel()), _stream()), "HUF_buildCTable_batch")
+        if g:
+            g.check("HUF_buildCTable_batch")
+        return ct, hdr, res
+
+    def huf_read_dtable_x1_batch(self, csrc, csizes, max_table_log=11):
+        """HUF_readDTableX1_batch: (dtables (n, 1 + (1 << max_table_log)) int32, results = header bytes or error)"""
+        n = _blocks(csrc, "csrc").shape[0]
+        dt = torch.zeros((n, 1 + (1 << max_table_log)), dtype=torch.int32, device=csrc.device)
+        res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
+        ws = torch.empty(int(self.lib.FSEHIP_HUF_readDTableX1_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=csrc.device)
+        ps, uni, keep = _sizes_arg(csizes, csrc)
+        _check(self.lib.FSEHIP_HUF_readDTableX1_batch(_ptr(dt), SZ(dt.stride(0)), C.c_uint(max_table_log), _ptr(res), _ptr(csrc), SZ(csrc.stride(0)), ps, uni,
+                                                      SZ(n), _ptr(ws), SZ(ws.numel()), _stream()), "HUF_readDTableX1_batch")
+        return dt, res
+
     # layer 1
     def huf_compress2(self, src, max_sv=255, huff_log=11, cap=None):
         return self._single("FSEHIP_HUF_compress2", huf_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(huff_log))
@@ -395,7 +452,7 @@ def _huf_methods():
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_HUF_decompress4X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
 
-    for f in (huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
+    for f in (huf_build_ctable_batch, huf_read_dtable_x1_batch, huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
               huf_decompress4x1_using_dtable_batch, huf_decompress4x_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
               huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable):
         setattr(FseHip, f.__name__, f)

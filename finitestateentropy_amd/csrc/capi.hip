@@ -276,7 +276,7 @@ extern "C" int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstSt
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstCapacity = dstCapacity; a.results = d_results;
     a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
     a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.atab = nullptr; a.symtab = nullptr; a.meta = nullptr;
-    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks; a.tlMin = 0; a.declineNb0 = 0; a.onlyDeclined = 0;
     return (int)launch_fse_decode(a, (hipStream_t)stream);
 }
 
@@ -418,8 +418,183 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
         FseDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
         e.csrc = cs; e.dtables = nullptr; e.dtStrideU32 = 0; e.atab = atab; e.symtab = symtab; e.meta = meta;
-        e.maxTableLog = maxLog; e.G = 0; e.slotU32 = 0; e.nBlocks = nb;
+        e.maxTableLog = maxLog; e.G = 0; e.slotU32 = 0; e.nBlocks = nb; e.tlMin = 0; e.declineNb0 = 0; e.onlyDeclined = 0;
         CK(launch_fse_decode_classes(e, lists, counts, s));
+    }
+    return 0;
+}
+
+// =====================================================================================================
+//  Tables for the *_usingCTable / *_usingDTable batch calls, built on the device (SURVEY 8(a') g1-g3, g5-g6 as calls of their own)
+// =====================================================================================================
+__global__ void k_hdr_results(const u8* meta, size_t metaStride, size_t* results, size_t nBlocks)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const u32* const m = (const u32*)(meta + b * metaStride);            // {state, hdrSize, ...} in FseMeta and HufMeta alike
+    if (m[0] != 0) results[b] = m[1];
+}
+hipError_t launch_hdr_results(const void* meta, size_t metaStride, size_t* results, size_t nBlocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hdr_results, dim3((unsigned)((nBlocks + 255) / 256)), dim3(256), 0, s, (const u8*)meta, metaStride, results, nBlocks);
+    return hipGetLastError();
+}
+
+static const size_t FSE_BCT_PER_BLOCK = 1024 + 4 + 8 + sizeof(FseMeta);
+extern "C" size_t FSEHIP_FSE_buildCTable_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    return (c ? c : 1) * FSE_BCT_PER_BLOCK + WS_SLACK;
+}
+extern "C" int FSEHIP_FSE_buildCTable_batch(FSEHIP_FSE_CTable* d_ctables, size_t ctableStrideU32, void* d_headers, size_t headerStride, size_t headerCapacity,
+                                            size_t* d_results, const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                            unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
+    if (nBlocks == 0) return 0;
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return batch_arg_error(d_results, nullptr, 0, headerCapacity, nBlocks, FSEHIP_ERROR(tableLog_tooLarge), 0, s);
+    const FseCWs w = fse_cws(tableLog);
+    if (ctableStrideU32 < w.ctU32) return (int)hipErrorInvalidValue;              // room for FSE_CTABLE_SIZE_U32(largest table log the request can lead to, 255)
+    if (workspaceBytes < FSE_BCT_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / FSE_BCT_PER_BLOCK;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
+    unsigned* counts = (unsigned*)carve(chunk * 1024);
+    unsigned* maxSVs = (unsigned*)carve(chunk * 4);
+    size_t* hres = (size_t*)carve(chunk * 8);
+    FseMeta* meta = (FseMeta*)carve(chunk * sizeof(FseMeta));
+    if ((size_t)(p - (u8*)d_workspace) > workspaceBytes) return (int)hipErrorInvalidValue;
+    unsigned msv = maxSymbolValue ? maxSymbolValue : 255;
+    if (msv > 255) msv = 255;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        const BlockView src = mkview((const u8*)d_src + b0 * srcStride, srcStride, d_sizes ? d_sizes + b0 : nullptr, uniformSize);
+        HistArgs h;
+        h.counts = counts; h.maxSVs = maxSVs; h.uniformMaxSV = msv; h.useUniformIn = 1; h.results = hres; h.src = src; h.nBlocks = nb;
+        CK(launch_hist(h, s));
+        FseCPrepArgs c;
+        c.counts = counts; c.maxSVs = maxSVs; c.histResults = hres; c.src = src;
+        c.dst = (u8*)d_headers + b0 * headerStride; c.dstStride = headerStride; c.dstCapacity = headerCapacity;
+        c.maxSVReq = msv; c.tableLogReq = tableLog;
+        c.ctables = d_ctables + b0 * ctableStrideU32; c.ctStrideU32 = ctableStrideU32; c.maxTl = w.maxTl;
+        c.meta = meta; c.results = d_results + b0; c.nBlocks = nb;
+        CK(launch_fse_cprep(c, s));
+        CK(launch_hdr_results(meta, sizeof(FseMeta), d_results + b0, nb, s));
+    }
+    return 0;
+}
+
+extern "C" size_t FSEHIP_FSE_buildDTable_batch_workspaceSize(size_t nBlocks, unsigned maxLog) { return FSEHIP_FSE_decompress_batch_workspaceSize(nBlocks, maxLog); }
+extern "C" int FSEHIP_FSE_buildDTable_batch(FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, size_t* d_results,
+                                            const void* d_headers, size_t headerStride, const size_t* d_headerSizes, size_t uniformHeaderSize,
+                                            unsigned maxLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
+    if (nBlocks == 0) return 0;
+    maxLog = clamp_maxlog(maxLog);
+    if (dtableStrideU32 < FSEHIP_FSE_DTABLE_SIZE_U32(maxLog)) return (int)hipErrorInvalidValue;
+    const size_t per = fse_dws_per_block(maxLog);
+    if (workspaceBytes < per + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / per;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
+    s16* norms = (s16*)p; p += align_up(chunk * 512, 256);
+    u16* atab = (u16*)p; p += align_up((chunk * 2) << maxLog, 256);
+    u8* symtab = p; p += align_up(chunk << maxLog, 256);
+    u32* lists = (u32*)p; p += align_up(chunk * FSE_DCLS_COUNT * sizeof(u32), 256);
+    u32* counts = (u32*)p;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        FseDPrepArgs d;
+        d.csrc = mkview((const u8*)d_headers + b0 * headerStride, headerStride, d_headerSizes ? d_headerSizes + b0 : nullptr, uniformHeaderSize);
+        d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.lists = lists; d.counts = counts;
+        d.results = d_results + b0; d.nBlocks = nb;
+        CK(launch_fse_dprep(d, s));
+        CK(launch_fse_export_dtables(d, d_dtables + b0 * dtableStrideU32, dtableStrideU32, s));
+        CK(launch_hdr_results(meta, sizeof(FseMeta), d_results + b0, nb, s));
+    }
+    return 0;
+}
+
+static const size_t HUF_BCT_PER_BLOCK = 1024 + 4 + 8 + sizeof(HufMeta);
+extern "C" size_t FSEHIP_HUF_buildCTable_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    return (c ? c : 1) * HUF_BCT_PER_BLOCK + WS_SLACK;
+}
+extern "C" int FSEHIP_HUF_buildCTable_batch(FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32, void* d_headers, size_t headerStride, size_t headerCapacity,
+                                            size_t* d_results, const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                            unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
+    if (nBlocks == 0) return 0;
+    if (tableLog > FSEHIP_HUF_TABLELOG_MAX || maxSymbolValue > 255)
+        return batch_arg_error(d_results, d_sizes, uniformSize, headerCapacity, nBlocks,
+                               tableLog > FSEHIP_HUF_TABLELOG_MAX ? FSEHIP_ERROR(tableLog_tooLarge) : FSEHIP_ERROR(maxSymbolValue_tooLarge), 1, s);
+    if (ctableStrideU32 < 256) return (int)hipErrorInvalidValue;
+    if (workspaceBytes < HUF_BCT_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / HUF_BCT_PER_BLOCK;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    auto carve = [&](size_t bytes) { u8* r = p; p += align_up(bytes, 256); return r; };
+    unsigned* counts = (unsigned*)carve(chunk * 1024);
+    unsigned* maxSVs = (unsigned*)carve(chunk * 4);
+    size_t* hres = (size_t*)carve(chunk * 8);
+    HufMeta* meta = (HufMeta*)carve(chunk * sizeof(HufMeta));
+    if ((size_t)(p - (u8*)d_workspace) > workspaceBytes) return (int)hipErrorInvalidValue;
+    const unsigned msv = maxSymbolValue ? maxSymbolValue : 255;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        const BlockView src = mkview((const u8*)d_src + b0 * srcStride, srcStride, d_sizes ? d_sizes + b0 : nullptr, uniformSize);
+        HistArgs h;
+        h.counts = counts; h.maxSVs = maxSVs; h.uniformMaxSV = msv; h.useUniformIn = 1; h.results = hres; h.src = src; h.nBlocks = nb;
+        CK(launch_hist(h, s));
+        HufCPrepArgs c;
+        c.counts = counts; c.maxSVs = maxSVs; c.histResults = hres; c.src = src;
+        c.dst = (u8*)d_headers + b0 * headerStride; c.dstStride = headerStride; c.dstCapacity = headerCapacity;
+        c.maxSVReq = msv; c.huffLogReq = tableLog; c.ctables = d_ctables + b0 * ctableStrideU32; c.ctStrideU32 = ctableStrideU32;
+        c.meta = meta; c.results = d_results + b0; c.nBlocks = nb;
+        CK(launch_huf_cprep(c, s, nullptr));
+        CK(launch_hdr_results(meta, sizeof(HufMeta), d_results + b0, nb, s));
+    }
+    return 0;
+}
+
+static const size_t HUF_RDT_PER_BLOCK = sizeof(HufMeta) + HUF_DCLS_COUNT * sizeof(u32);
+extern "C" size_t FSEHIP_HUF_readDTableX1_batch_workspaceSize(size_t nBlocks)
+{
+    size_t c = nBlocks < WS_MAX_CHUNK ? nBlocks : WS_MAX_CHUNK;
+    return (c ? c : 1) * HUF_RDT_PER_BLOCK + WS_SLACK;
+}
+extern "C" int FSEHIP_HUF_readDTableX1_batch(FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog, size_t* d_results,
+                                             const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize,
+                                             size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
+    if (nBlocks == 0) return 0;
+    if (maxTableLog == 0 || maxTableLog > FSEHIP_HUF_TABLELOG_MAX) maxTableLog = FSEHIP_HUF_TABLELOG_MAX;
+    if (dtableStrideU32 < 1 + ((size_t)1 << maxTableLog)) return (int)hipErrorInvalidValue;       // HUF_DTABLE_SIZE(maxTableLog)
+    if (workspaceBytes < HUF_RDT_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / HUF_RDT_PER_BLOCK;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    HufMeta* meta = (HufMeta*)p; p += align_up(chunk * sizeof(HufMeta), 256);
+    u32* lists = (u32*)p; p += align_up(chunk * HUF_DCLS_COUNT * sizeof(u32), 256);
+    u32* counts = (u32*)p;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        HufDPrepArgs d;
+        d.csrc = mkview((const u8*)d_src + b0 * srcStride, srcStride, d_srcSizes ? d_srcSizes + b0 : nullptr, uniformSrcSize);
+        d.dstSizes = mkview(nullptr, 0, nullptr, 0); d.dst = nullptr; d.dstStride = 0;
+        d.dtables = d_dtables + b0 * dtableStrideU32; d.dtStrideU32 = dtableStrideU32; d.meta = meta; d.lists = lists; d.counts = counts;
+        d.results = d_results + b0; d.nBlocks = nb; d.tableOnly = 1; d.dtMaxLog = maxTableLog;
+        CK(launch_huf_dprep(d, s));
     }
     return 0;
 }
@@ -714,6 +889,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
         HufDPrepArgs d;
         d.csrc = cs; d.dstSizes = ds; d.dst = (u8*)d_dst + b0 * dstStride; d.dstStride = dstStride;
         d.dtables = dtables; d.dtStrideU32 = dtU32; d.meta = meta; d.lists = lists; d.counts = counts; d.results = d_results + b0; d.nBlocks = nb;
+        d.tableOnly = 0; d.dtMaxLog = FSEHIP_HUF_TABLELOG_MAX - 1;
         CK(launch_huf_dprep(d, s));
         HufDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstSizes = ds; e.results = d_results + b0;

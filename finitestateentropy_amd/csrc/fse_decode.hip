@@ -263,7 +263,10 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
     // per-block constants live in the registers of lane l of this wave
     const unsigned long long inBits = ((unsigned long long)ctl->inHi << 32) | ctl->inLo;
     const unsigned long long outBits = ((unsigned long long)ctl->outHi << 32) | ctl->outLo;
-    const unsigned long long tabBits = ((unsigned long long)ctl->symHi << 32) | ctl->symLo;
+    const unsigned long long tabBits = ((unsigned long long)(ctl->symHi & 0xFFFFu) << 32) | ctl->symLo;
+    // bit-reversed cells over a caller-built reference-layout table: the record holds the index rev(state) of the LDS cell, the symbol
+    // sits in the reference cell of `state` itself -- symRev = the table log (0: the symbol table is indexed like the LDS cells)
+    const u32 symRev = ctl->symHi >> 24;
     const int S32 = ctl->S32;
     int validLo = ctl->initValidLo;
     u32 flushed = 0, fpos = 0;                               // records flushed so far, and that count modulo the ring size
@@ -331,6 +334,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             if (!((fm >> l) & 1ull)) continue;               // uniform
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
             const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, l, WAVE);
+            const u32 tlr = (u32)__shfl((int)symRev, l, WAVE);       // (all lanes active here: a shuffle inside the branch below would read lane l disabled when cnt <= l)
             if ((u32)lane < cnt) {
                 // iteration i lives in slot pair (i >> 1): 16 bytes = lane A's {iteration 2p, 2p+1} words, then lane B's
                 u32 ri = fp_g + (u32)lane;
@@ -338,8 +342,13 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
                 const u32* const rw = (const u32*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff) + 4u * (ri >> 1) + (ri & 1u);
                 uint2 rec; rec.x = rw[0]; rec.y = rw[2];      // x: state 1 before symbols 0 / 2, y: state 2 before symbols 1 / 3
                 // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+ldsLog)
-                const u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.ldsLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.ldsLog);
-                const u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.ldsLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.ldsLog);
+                u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.ldsLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.ldsLog);
+                u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.ldsLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.ldsLog);
+                if (tlr) {                                   // uniform per block: state = the index's tlr bits reversed (address bits [1, 1+tlr) / [17, 17+tlr))
+                    const u32 rx = __brev(rec.x), ry = __brev(rec.y);
+                    x0 = __builtin_amdgcn_ubfe(rx, 31u - tlr, tlr); x1 = __builtin_amdgcn_ubfe(rx, 15u - tlr, tlr);
+                    x2 = __builtin_amdgcn_ubfe(ry, 31u - tlr, tlr); x3 = __builtin_amdgcn_ubfe(ry, 15u - tlr, tlr);
+                }
                 yq[l][0] = tg[x0 << symShift]; yq[l][2] = tg[x1 << symShift]; yq[l][1] = tg[x2 << symShift]; yq[l][3] = tg[x3 << symShift];
             }
         }
@@ -443,10 +452,10 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // ---- stage: reference cells {u16 newState; u8 symbol; u8 nbBits} -> compact u16 (uniform control flow, both waves).
     //      A table whose fields do not fit 12+4 bits (cannot come from FSE_buildDTable) is flagged and decoded
     //      by the literal path only.
-    u32* const flagsSh = (u32*)(ldsb + (size_t)a.G * slotBytes);  // behind the slots: [0] bad-table mask, [1] any nbBits == 0
-    if (tid < 2) flagsSh[tid] = 0;
+    u32* const flagsSh = (u32*)(ldsb + (size_t)a.G * slotBytes);  // behind the slots: [0] any nbBits == 0, [1] unused, [2..3] bad-table mask, [4..5] decline mask
+    if (tid < 6) flagsSh[tid] = 0;
     __syncthreads();
-    {   u32 badBits = 0; bool anyNb0 = false;
+    {   u64 badBits = 0, declBits = 0; bool anyNb0 = false;
         if (a.atab) {
             // k_fse_dbuild output: already in the LDS format; the first tabStride bytes of every block's global table slot are
             // its LDS image.  Every load is issued before the first store (a lone copy loop would pay the memory latency once
@@ -487,33 +496,68 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             if (!FAST) for (size_t g = 0; g < nTab; ++g) {                 // a cell with nbBits == 0 needs a counter > tableSize/2
                 const u32 st = a.meta[slotBlock(g)].state; anyNb0 |= st != 0 && !(st & 2u); }
         }
-        else for (int g = 0; g < a.G; ++g) {
-            if (first + g >= nTot) break;
-            const size_t b = slotBlock(g);
-            if (a.meta && a.meta[b].state == 0) continue;
-            if (FAST) __builtin_trap();                          // the bit-reversed loop takes k_fse_dbuild tables only (launch_fse_decode)
-            const u32* t = a.dtables + b * a.dtStrideU32;
-            const u32 tl = t[0] & 0xFFFFu;
-            if (tl > a.ldsLog) continue;
-            const u32 ts = 1u << tl;
-            u16* A = (u16*)(lds8 + (size_t)g * tabStride);
-            bool bad = false;
-            for (u32 i = tid; i < ts; i += FSE_DEC_THREADS) {
-                const u32 c = t[1 + i];
-                const u32 ns = c & 0xFFFFu, nb = c >> 24;
-                bad |= (ns >= 0x1000u) | (nb > 15u) | ((ns & ((1u << (nb & 15u)) - 1u)) != 0);
-                anyNb0 |= (nb == 0);
-                A[i] = (u16)((ns & 0xFFFu) | (nb << 12));
+        else {
+            // Caller-built reference-layout tables {u16 newState; u8 symbol; u8 nbBits} (lib/fse.h:570-575), taken straight from global
+            // memory: FAST stages them as the bit-reversed cells of fse_bulk_phase_rev -- cell rev(x) = nbBits | rev(newState) << 5 --
+            // the plain loop as newState | nbBits << 12.  Every table is checked while it passes through: what FSE_buildDTable
+            // guarantees (newState below the table size and a multiple of 1 << nbBits, nbBits <= tableLog: lib/fse_decompress.c:
+            // 113-124) is what the address arithmetic of the bulk loops rests on; a table that fails it is decoded by the literal
+            // path alone (bad mask), which does with it whatever the reference does.  A table of log 12 with a cell of nbBits 0
+            // (rev(newState) then needs 12 bits) is the plain loop's: marked in the decline mask when this launch may hand it on.
+            // Cells are loaded four tables ahead of their conversion (4-byte coalesced loads; the table starts one word into its
+            // slot), so that a workgroup pays a few memory latencies per 33 tables, not one per table.
+            const size_t nTab = nTot - first < (size_t)a.G ? nTot - first : (size_t)a.G;
+            constexpr u32 TB = 4;                                        // tables in flight
+            constexpr u32 CPT = ((1u << FSEHIP_FSE_MAX_TABLELOG) + FSE_DEC_THREADS - 1) / FSE_DEC_THREADS;   // cells per thread and table
+            for (u32 gb = 0; gb < (u32)nTab; gb += TB) {
+                u32 cellv[TB][CPT]; u32 tlg[TB];
+#pragma unroll
+                for (u32 k = 0; k < TB; ++k) {
+                    const u32 g = gb + k;
+                    tlg[k] = 0xFFFFu;                                     // = not this launch's
+                    if (g >= (u32)nTab) continue;
+                    const size_t bi = slotBlock(g);
+                    if (a.meta && a.meta[bi].state == 0) continue;
+                    if (a.onlyDeclined && a.results[bi] != FSE_DECLINED) continue;
+                    const u32* const t = a.dtables + bi * a.dtStrideU32;
+                    const u32 tl = t[0] & 0xFFFFu;
+                    if (tl > a.ldsLog || tl < a.tlMin) continue;
+                    tlg[k] = tl;
+#pragma unroll
+                    for (u32 j = 0; j < CPT; ++j) { const u32 i = (u32)tid + j * FSE_DEC_THREADS; cellv[k][j] = i < (1u << tl) ? t[1 + i] : 0u; }
+                }
+#pragma unroll
+                for (u32 k = 0; k < TB; ++k) {
+                    const u32 tl = tlg[k];
+                    if (tl == 0xFFFFu) continue;                          // uniform
+                    u16* const A = (u16*)(lds8 + (size_t)(gb + k) * tabStride);
+                    bool bad = false, nbz = false;
+#pragma unroll
+                    for (u32 j = 0; j < CPT; ++j) {
+                        const u32 i = (u32)tid + j * FSE_DEC_THREADS;
+                        if (i >= (1u << tl)) continue;
+                        const u32 c = cellv[k][j];
+                        const u32 ns = c & 0xFFFFu, nb = c >> 24;
+                        bad |= (ns >> tl) != 0 || nb > tl || nb > 15u || (ns & ((1u << (nb & 15u)) - 1u)) != 0;
+                        nbz |= nb == 0;
+                        if (FAST) A[__brev(i) >> (32u - tl)] = (u16)((nb & 31u) | ((__brev(ns & ((1u << tl) - 1u)) >> (32u - tl)) << 5));
+                        else A[i] = (u16)((ns & 0xFFFu) | (nb << 12));
+                    }
+                    if (bad) badBits |= 1ull << (gb + k);
+                    if (FAST && nbz && tl == 12u) declBits |= 1ull << (gb + k);
+                    anyNb0 |= nbz;
+                }
             }
-            if (bad) badBits |= 1u << g;
         }
-        if (badBits) atomicOr(&flagsSh[0], badBits);
-        if (anyNb0) atomicOr(&flagsSh[1], 1u);
+        if (badBits) { atomicOr(&flagsSh[2], (u32)badBits); atomicOr(&flagsSh[3], (u32)(badBits >> 32)); }
+        if (declBits) { atomicOr(&flagsSh[4], (u32)declBits); atomicOr(&flagsSh[5], (u32)(declBits >> 32)); }
+        if (anyNb0) atomicOr(&flagsSh[0], 1u);
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the LDS-DMA pieces have landed (lgkmcnt / expcnt fields left at their maxima)
     __syncthreads();
-    const u32 badMask = flagsSh[0];
-    const bool nb0 = flagsSh[1] != 0;
+    const u64 badMask = (u64)flagsSh[2] | ((u64)flagsSh[3] << 32);
+    const u64 declMask = (u64)flagsSh[4] | ((u64)flagsSh[5] << 32);
+    const bool nb0 = flagsSh[0] != 0;
 
     // ---- per-block set-up by the decoder wave: lanes 2g and 2g+1 walk block first+g together and both run this set-up
     //      (identical values in both; only the even lane publishes, finishes the block and writes its result)
@@ -531,9 +575,16 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     const bool compact = a.atab != nullptr;
     const u32* const gtab = compact ? nullptr : a.dtables + (owner ? b : 0) * a.dtStrideU32;   // reference-layout table in global memory
     if (owner) {
-        if (compact) { tl = a.meta[b].tableLog; fast = (a.meta[b].state & 2u) != 0; }
-        else { const u32 h0 = gtab[0]; tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0; }
-        if (tl > a.ldsLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; }
+        if (compact) { tl = a.meta[b].tableLog; fast = (a.meta[b].state & 2u) != 0; if (tl > a.ldsLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; } }
+        else {
+            // caller tables: one launch per class over all blocks (FseDecArgs); the first launch (tlMin 0) reports tables beyond the
+            // caller's maxTableLog, a launch that may hand blocks on marks the ones it leaves to the plain-cell launch
+            const u32 h0 = gtab[0]; tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0;
+            if (a.onlyDeclined) { if (a.results[b] != FSE_DECLINED) owner = false; }
+            else if (tl > a.maxTableLog) { if (a.tlMin == 0 && half == 0) a.results[b] = FERR(tableLog_tooLarge); owner = false; }
+            else if (tl > a.ldsLog || tl < a.tlMin) owner = false;
+            else if (a.declineNb0 && ((declMask >> gsl) & 1ull)) { if (half == 0) a.results[b] = FSE_DECLINED; owner = false; }
+        }
     }
     const u32* const cells = compact ? nullptr : gtab + 1;      // literal path: reference cells, or the LDS cells + symbol table
     const u8* const syms = compact ? a.symtab + ((owner ? b : 0) << a.maxTableLog) : (const u8*)cells + 2;
@@ -581,7 +632,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // bitsConsumed counted from it): rebuilt below from the cursor at the head of the last iteration and the cursor now.
     // (The plain-cell loop keeps its coarser rule: window at least 24 bytes above the stream start.)
     // unread bits of the payload after the two state reads (a stream of a few bytes has been read beyond its end by now: negative)
-    const bool bulkOk = owner && S < (1ull << 28) && !((badMask >> gsl) & 1u);
+    const bool bulkOk = owner && S < (1ull << 28) && !((badMask >> gsl) & 1ull) && !(FAST && !compact && ((declMask >> gsl) & 1ull));
     const int Bstart = bulkOk ? (int)(8u * ((u32)r.at + 8u)) - (int)r.used : 0;
     const long groups0 = (omax - 3 - op + 3) / 4;
     bool can = bulkOk && (FAST ? Bstart >= 65 + 48 * (FSE_CHECK_EVERY - 1) : r.at >= 24 + 6 * FSE_CHECK_EVERY + 8) && groups0 >= FSE_CHECK_EVERY;
@@ -614,7 +665,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S + inA : 0);
         const unsigned long long ib = (unsigned long long)(uintptr_t)(in - inA), ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)syms;
-        ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
+        ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb;
+        ctl->symHi = ((u32)(tb >> 32) & 0xFFFFu) | ((FAST && !compact ? tl : 0u) << 24);     // (addresses have 48 bits)
     }
     __syncthreads();
     if (!decWave) { fse_decode_service<TIMED>(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - FSE_DEC_WAVES) * FSE_SRV_G, FAST); return; }
@@ -716,9 +768,9 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
     size_t result;
-    if (FAST)         result = fse_tail(FseCellsRev{A, syms, tl, 5u}, s1, s2, r, out, op, omax, fast);
-    else if (compact) result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
-    else         result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
+    if (!compact)     result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);     // caller tables: the reference's own cells
+    else if (FAST)    result = fse_tail(FseCellsRev{A, syms, tl, 5u}, s1, s2, r, out, op, omax, fast);
+    else              result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
     TIMING(if (lane == 0) { const unsigned long long tE = __builtin_readcyclecounter(); atomicAdd(&g_decTiming[11], tE - tBorn); atomicAdd(&g_decTiming[12], wall_clock64() - wBorn);
                             atomicAdd(&g_decTiming[14], tE - tBulk1); });
@@ -727,7 +779,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
     *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
-    int g = (int)((ldsBytes - 16) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (16 bytes: the flag words)
+    int g = (int)((ldsBytes - 32) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (32 bytes: the flag words)
     if (g > FSE_MAXG) g = FSE_MAXG;
     *G = g;
 }
@@ -787,13 +839,25 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_decodeTiming(
     return 0;
 }
 
-// caller-built reference-layout DTables (FSE_decompress_usingDTable over a batch): staged as plain cells
+// Caller-built reference-layout DTables (FSE_decompress_usingDTable over a batch).  The call has no workspace, so there are no class
+// lists: every launch walks all blocks and takes the ones of its class, judged from the table's own header (a uniform batch -- the
+// usual case -- fills every workgroup; in a mixed one the other classes' slots stay empty for the launch):
+//   1. tableLog <= 11 (or the caller's smaller maxTableLog): bit-reversed cells converted while staging, 4 KiB LDS slots -- the fast loop;
+//   2. tableLog 12 (only if maxTableLog allows it): the same with 8 KiB slots; a table with a cell of nbBits 0 is marked FSE_DECLINED
+//   3. ... and taken by the plain-cell loop.
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    a.ldsLog = a.maxTableLog; a.list = nullptr; a.count = nullptr;
+    a.list = nullptr; a.count = nullptr;
     probe_before(PK_FSE_DECODE, s);
-    const hipError_t e = fse_decode_launch(a, false, s);
+    a.ldsLog = a.maxTableLog < FSE_DEC_FAST_MAXLOG ? a.maxTableLog : FSE_DEC_FAST_MAXLOG;
+    a.tlMin = 0; a.declineNb0 = 0; a.onlyDeclined = 0;
+    hipError_t e = fse_decode_launch(a, true, s);
+    if (e == hipSuccess && a.maxTableLog > FSE_DEC_FAST_MAXLOG) {
+        a.ldsLog = a.maxTableLog; a.tlMin = FSE_DEC_FAST_MAXLOG + 1; a.declineNb0 = 1;
+        e = fse_decode_launch(a, true, s);
+        if (e == hipSuccess) { a.tlMin = 0; a.declineNb0 = 0; a.onlyDeclined = 1; e = fse_decode_launch(a, false, s); }
+    }
     probe_after(PK_FSE_DECODE, s);
     return e;
 }

@@ -209,6 +209,34 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs, in
     if (lane == 0) a.meta[b].state = m.state | (fast ? 2u : 0u);
 }
 
+// FSE_buildDTable over a batch: what k_fse_dparse / k_fse_dbuild left in the decoder's own formats, written out in the reference's
+// layout (lib/fse.h:565-575: {U16 tableLog; U16 fastMode} then {U16 newState; BYTE symbol; BYTE nbBits} per state), coalesced
+__global__ __launch_bounds__(256) void k_fse_export_dtable(FseDPrepArgs a, u32 capTs, u32* dtables, size_t dtStrideU32)
+{
+    const size_t b = blockIdx.x;
+    const FseMeta m = a.meta[b];
+    if (m.state == 0) return;                                              // (its error is in results[b])
+    const u32 tl = m.tableLog, ts = 1u << tl;
+    const bool rev = ((m.state >> 2) & 3u) != FSE_DCLS_PLAIN;
+    const u16* const A = a.atab + b * capTs;
+    const u8* const S = a.symtab + b * capTs;
+    u32* const dt = dtables + b * dtStrideU32;
+    if (threadIdx.x == 0) dt[0] = tl | ((m.state & 2u) ? 1u << 16 : 0u);
+    for (u32 x = threadIdx.x; x < ts; x += blockDim.x) {
+        const u32 i = rev ? __brev(x) >> (32u - tl) : x;
+        const u32 c = A[i];
+        const u32 nb = rev ? (c & 31u) : (c >> 12);
+        const u32 ns = rev ? __brev(c >> 5) >> (32u - tl) : (c & 0xFFFu);
+        dt[1 + x] = ns | ((u32)S[i] << 16) | (nb << 24);
+    }
+}
+hipError_t launch_fse_export_dtables(const FseDPrepArgs& a, u32* dtables, size_t dtStrideU32, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fse_export_dtable, dim3((unsigned)a.nBlocks), dim3(256), 0, s, a, 1u << a.maxLog, dtables, dtStrideU32);
+    return hipGetLastError();
+}
+
 #ifdef FSE_WB_TIMING
 extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_wbTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wbTiming), sizeof(g_wbTiming)); }
 #endif

@@ -292,6 +292,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_huf_decode(HufDecArgs a)
         out = a.dst + b * a.dstStride;
         if (((desc >> 8) & 0xFFu) != 0) blockErr = FERR(GENERIC);                       // X2 table: huf_decompress.c:411-412 (4X1 entry point)
         else if (dtLog > a.maxTableLog) blockErr = FERR(tableLog_tooLarge);
+        else if (dtLog < 1) blockErr = FERR(corruption_detected);                       // no table has tableLog 0 (a zero-filled DTable): the reference's look-up
+                                                                                        // would shift by 64 and index with the whole container -- undefined there, refused here
         else if (cSize < 10) blockErr = FERR(corruption_detected);                      // :269
         if (!blockErr) {
             const size_t l1 = ld16(in), l2 = ld16(in + 2), l3 = ld16(in + 4);

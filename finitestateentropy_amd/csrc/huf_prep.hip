@@ -648,11 +648,12 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             const u8* const in = view_ptr(a.csrc, b);
             const size_t cSize = view_size(a.csrc, b), dstSize = view_size(a.dstSizes, b);
             u8* const w = slot + HD_WGT;
-            if (dstSize == 0) result = FERR(dstSize_tooSmall);            // huf_decompress.c:1063-1066
-            else if (cSize > dstSize) result = FERR(corruption_detected);
-            else if (cSize == dstSize) { state = 2; result = dstSize; }   // not compressed: copied below, coalesced
-            else if (cSize == 1) { state = 3; result = dstSize; }         // one byte repeated
-            else {                                                         // weights header (entropy_common.c:154-182); cSize >= 2 here
+            if (a.tableOnly && cSize == 0) result = FERR(srcSize_wrong);  // HUF_readStats, entropy_common.c:165
+            else if (!a.tableOnly && dstSize == 0) result = FERR(dstSize_tooSmall);            // huf_decompress.c:1063-1066
+            else if (!a.tableOnly && cSize > dstSize) result = FERR(corruption_detected);
+            else if (!a.tableOnly && cSize == dstSize) { state = 2; result = dstSize; }   // not compressed: copied below, coalesced
+            else if (!a.tableOnly && cSize == 1) { state = 3; result = dstSize; }         // one byte repeated
+            else {                                                         // weights header (entropy_common.c:154-182); cSize >= 2 here (table only: >= 1)
                 const u32 first = in[0];
                 if (first >= 128) {                                        // 4 bits per weight
                     const u32 nW = first - 127, bytes = (nW + 1) / 2;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
             const u8* const in = view_ptr(a.csrc, b);
             const size_t cSize = view_size(a.csrc, b), hdr = sc[DS_HDR];
             u32 kind = HUF_DKIND_SERIAL;
-            if (cSize >= hdr + 10 && view_size(a.dstSizes, b) >= 64) {     // the jump table (huf_decompress.c:277-287)
+            if (!a.tableOnly && cSize >= hdr + 10 && view_size(a.dstSizes, b) >= 64) {     // the jump table (huf_decompress.c:277-287)
                 const u8* const jt = in + hdr;
                 const size_t l0 = jt[0] | ((u32)jt[1] << 8), l1 = jt[2] | ((u32)jt[3] << 8), l2 = jt[4] | ((u32)jt[5] << 8), used = 6 + l0 + l1 + l2;
                 if (used < cSize - hdr) {
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
                 const Pk tot = pk_rank(cls, rank, lane);
                 const u32 cnt1 = pk_get(tot, 1);
                 if (cnt1 < 2 || (cnt1 & 1u)) err = FERR(corruption_detected);   // entropy_common.c:208
-                else if (tl > (HUF_MAX_TL - 1) + 1) err = FERR(tableLog_tooLarge);   // DTable of HUF_CREATE_STATIC_DTABLEX1(.., HUF_TABLELOG_MAX)
+                else if (tl > a.dtMaxLog + 1) err = FERR(tableLog_tooLarge);   // huf_decompress.c:137 (one-shot path: the DTable of HUF_CREATE_STATIC_DTABLEX1(.., HUF_TABLELOG_MAX))
                 else {
                     // X1 cells {byte, nbBits} (huf_decompress.c:158-183): symbol n owns (1 << w) >> 1 consecutive cells, the symbols of
                     // a weight follow each other in symbol order, the weights in ascending order.  Restated by cell: the symbols are
@@ -824,12 +825,13 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
                         else lo = hi = sorted[cb + ((u - cs) >> (v - 1))];
                         out[q] = (lo | nbits) | ((hi | nbits) << 16);
                     }
-                    if (lane == 0) dt[0] = ((HUF_MAX_TL - 1) & 0xFFu) | (tl << 16);
+                    if (lane == 0) dt[0] = ((a.dtMaxLog & 0xFFu) * 0x01000001u) | (tl << 16);   // {maxTableLog, tableType 0, tableLog, reserved as HUF_CREATE_STATIC_DTABLEX1 leaves it}
                 }
             }
             const u32 hdr = sc[DS_HDR];
-            if (!err && (size_t)hdr >= view_size(a.csrc, b)) err = FERR(srcSize_wrong);   // nothing behind the header (huf_decompress.c:432)
+            if (!err && !a.tableOnly && (size_t)hdr >= view_size(a.csrc, b)) err = FERR(srcSize_wrong);   // nothing behind the header (huf_decompress.c:432)
             if (err) result = err;
+            else if (a.tableOnly) result = hdr;                           // (state stays 0: nothing to decode, the result is final)
             else { m.state = 1; m.hdrSize = hdr; m.tableLog = tl; }
         }
         if (lane == 0) { a.meta[b] = m; if (m.state == 0) a.results[b] = result; sc[DS_CLS] = m.state ? 2u * sc[DS_CLS] + (m.tableLog > 11u ? 1u : 0u) : 0xFFFFFFFFu; }

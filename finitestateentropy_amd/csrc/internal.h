@@ -122,7 +122,13 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     int G;
     unsigned slotU32;
     size_t nBlocks;
+    // caller-built tables (usingDTable batch: no workspace, hence no class lists): every launch walks all blocks and takes those of its
+    // class, judged from the table's own header -- tableLog in [tlMin, ldsLog]; `declineNb0`: a table with a cell of nbBits 0 is left to
+    // the plain-cell launch (marked FSE_DECLINED in results[]); `onlyDeclined`: take exactly the marked blocks
+    unsigned tlMin; int declineNb0; int onlyDeclined;
 };
+// marker in results[] between the launches of the caller-table batch (no size_t a decoder returns, cf. HUF_DECLINED)
+#define FSE_DECLINED ((size_t)0 - (size_t)0x7001)
 #define FSE_DEC_FAST_MAXLOG 11u   // largest tableLog of the 4 KiB class
 hipError_t launch_fse_decode(FseDecArgs a, hipStream_t s);
 // one-shot path: one launch per decoder class over the lists written by k_fse_dparse
@@ -179,8 +185,15 @@ struct HufDPrepArgs {            // glue g6: HUF_readStats + HUF_readDTableX1 (+
     u32* counts;
     size_t* results;
     size_t nBlocks;
+    int tableOnly;               // HUF_readDTableX1 over a batch (lib/huf_decompress.c:118-185): no raw / RLE decisions, nothing of the payload
+                                 // looked at; results[b] = header size (HUF_readStats' return value) or its error
+    unsigned dtMaxLog;           // DTableDesc.maxTableLog of the tables (the one-shot path: HUF_TABLELOG_MAX - 1, lib/huf_decompress.c:1030)
 };
 hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s);
+// results[b] = meta[b].hdrSize for every block a prepare kernel left pending (state != 0): the table-building batch calls
+hipError_t launch_hdr_results(const void* meta, size_t metaStride, size_t* results, size_t nBlocks, hipStream_t s);
+// FSE_buildDTable over a batch: the decoder-format tables of k_fse_dbuild written out in the reference's layout (lib/fse.h:565-575)
+hipError_t launch_fse_export_dtables(const FseDPrepArgs& a, u32* dtables, size_t dtStrideU32, hipStream_t s);
 
 struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes per block (one per stream)
     u8* dst; size_t dstStride;

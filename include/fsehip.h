@@ -193,6 +193,41 @@ FSEHIP_API int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
                                            size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
                                            size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
 
+/* ---- Tables for the *_usingCTable / *_usingDTable batch calls, built on the device from the blocks themselves: the steps the
+ * reference runs between HIST_count and the hot loops (SURVEY 8(a') g1-g3, g5-g6), as calls of their own so that a caller of the
+ * using-table forms never has to build tables on the host and upload them.
+ *   FSE_buildCTable_batch  = HIST_count + the early-outs of FSE_compress_wksp + FSE_optimalTableLog + FSE_normalizeCount +
+ *                            FSE_writeNCount + FSE_buildCTable_wksp per block (lib/fse_compress.c:646-665).  d_ctables + b*ctableStrideU32
+ *                            receives the CTable in the reference's layout (ctableStrideU32 >= FSE_CTABLE_SIZE_U32(max(tableLog, 9), 255):
+ *                            FSE_optimalTableLog may raise a small request), d_headers + b*headerStride the NCount header (at most
+ *                            headerCapacity bytes), d_results[b] the header size (> 1: table and header valid) or what FSE_compress2 returns
+ *                            when it stops before coding: 0 (not compressible), 1 (one repeated byte) or an error code.
+ *   FSE_buildDTable_batch  = FSE_readNCount + the maxLog check + FSE_buildDTable per block (lib/fse_decompress.c:264-271): d_headers
+ *                            points at the NCount headers (or at whole compressed blocks); d_dtables + b*dtableStrideU32 receives the DTable
+ *                            in the reference's layout (dtableStrideU32 >= FSE_DTABLE_SIZE_U32(maxLog)); d_results[b] = bytes the header
+ *                            takes (where the payload starts) or an error code.
+ *   HUF_buildCTable_batch  = HIST_count + early-outs + HUF_buildCTable_wksp + HUF_writeCTable per block (lib/huf_compress.c:654-703): 256
+ *                            HUF_CElt per table (ctableStrideU32 >= 256), the weights header in d_headers, d_results[b] = header size or
+ *                            0 / 1 (the repeated byte goes to d_headers[b][0]) / error as HUF_compress2.
+ *   HUF_readDTableX1_batch = HUF_readDTableX1 per block (lib/huf_decompress.c:118-185): single-symbol DTable with DTableDesc.maxTableLog =
+ *                            maxTableLog (dtableStrideU32 >= HUF_DTABLE_SIZE(maxTableLog) = 1 + (1 << maxTableLog)); d_results[b] = header size or error. */
+FSEHIP_API size_t FSEHIP_FSE_buildCTable_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API int FSEHIP_FSE_buildCTable_batch(FSEHIP_FSE_CTable* d_ctables, size_t ctableStrideU32, void* d_headers, size_t headerStride, size_t headerCapacity,
+                                            size_t* d_results, const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                            unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API size_t FSEHIP_FSE_buildDTable_batch_workspaceSize(size_t nBlocks, unsigned maxLog);
+FSEHIP_API int FSEHIP_FSE_buildDTable_batch(FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, size_t* d_results,
+                                            const void* d_headers, size_t headerStride, const size_t* d_headerSizes, size_t uniformHeaderSize,
+                                            unsigned maxLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API size_t FSEHIP_HUF_buildCTable_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API int FSEHIP_HUF_buildCTable_batch(FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32, void* d_headers, size_t headerStride, size_t headerCapacity,
+                                            size_t* d_results, const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                            unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API size_t FSEHIP_HUF_readDTableX1_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API int FSEHIP_HUF_readDTableX1_batch(FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog, size_t* d_results,
+                                             const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize,
+                                             size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+
 /* Workload generator of the reference's benchmark (programs/probaGenerator.c:70-74,95-126), on the
  * device: block b = generate(blockSize bytes, table, seed = firstSeed + b).  h_table4096 is the
  * HOST 4096-entry symbol table built by FSEHIP_probagen_table(); it is consumed before the call returns (the
