@@ -76,8 +76,11 @@ def test_fse_build_ctable_and_dtable_batch(hip, oracle, size):
         # maxLog below the table's log: tableLog_tooLarge like FSE_decompress_wksp (lib/fse_decompress.c:266)
         dt, dres = hip.fse_build_dtable_batch(hdr[idx].contiguous(), res[idx], max_log=9)
         for i, b in enumerate(built):
-            _, _, tl, _ = oracle.fse_read_ncount(hdr_h[b][:int(res_h[b])])
-            assert (dres[i].item() == -5) == (tl > 9), (size, tl_req, b)
+            rr, _, tl, _ = oracle.fse_read_ncount(hdr_h[b][:int(res_h[b])])
+            if is_error(rr):             # (a header that ends on a long zero run needs bytes behind it: FSE_readNCount freezes its window near the end)
+                assert dres[i].item() == s64(rr), (size, tl_req, b)
+            else:
+                assert (dres[i].item() == -5) == (tl > 9), (size, tl_req, b)
         # the whole using-table pipeline on the device
         comp, cres = hip.fse_compress_using_ctable_batch(src[idx].contiguous(), ct[idx].contiguous(), max_table_log=12)
         dt, dres = hip.fse_build_dtable_batch(hdr[idx].contiguous(), res[idx], max_log=12)
