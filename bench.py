@@ -70,7 +70,9 @@ def parse():
     ap.add_argument("--cfg5-total", type=int, default=1000000, help="blocks of the fixed config-5 corpus (strong scaling; BASELINE configs[4])")
     ap.add_argument("--comm-passes", type=int, default=3, help="timed passes of the with-comm variant (after one untimed pass)")
     ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
-    ap.add_argument("--parity-blocks", type=int, default=8192, help="strided blocks whose encoder bytes are compared with the CPU reference (untimed)")
+    ap.add_argument("--parity-blocks", type=int, default=0, help="blocks whose encoder bytes are compared with the CPU reference, untimed (0 = every block of the "
+                                                                 "headline and of configs 2-4; the mixed 1M-block configurations use --cfg5-parity-blocks)")
+    ap.add_argument("--cfg5-parity-blocks", type=int, default=65536, help="strided blocks per codec of the config-5 records compared with the CPU reference")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pinned-host H2D + kernels + D2H figure")
     ap.add_argument("--plain", action="store_true", help="profiler runs (scripts/profile.sh): warm-up + timed steps only -- no event-probe pass, no instrumented "
                                                           "decode pass, no host-inclusive / CPU legs -- so that every kernel is launched exactly warmup + steps times")
@@ -131,7 +133,15 @@ def cpu_baseline(args, sample, codec_name):
     st = mib1 / (one["enc_s"] + one["dec_s"])
     value = mib / (best["enc_s"] + best["dec_s"])
     stream = lib.stream_bandwidth(1 << 30, cores, 5)
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
     return {
+        "cpu_model": model, "host_logical_cpus": os.cpu_count(),
         "value": round(value, 1), "unit": "MiB/s (encode+decode round trip, uncompressed bytes)",
         "cores": best["threads"], "kind": lib.kind,
         "sample": "%d probagen P%02d blocks of 32 KB (the first blocks of the GPU workload), %s_compress2 + %s_decompress per block, OpenMP %s over "
@@ -180,28 +190,64 @@ class Codec:
             self.hip.huf_decompress_batch(self.dst, self.res, BLOCK, dst=self.out, results=self.dres, workspace=self.ws_d)
 
 
-def check_parity(cd, rank, n_check=8192):
-    """untimed gates: round trip on every block; encoder bytes and return values against the compiled reference (or the
-    oracle when oracle/_ref is absent) on a strided sample across the whole batch"""
+def reference_bytes_check(lib, codec_name, table_log, src, dst, res, n_check=0, chunk=16384, hdr=None, hdr_sizes=None):
+    """encoder bytes and return values of blocks against the compiled reference (the restatement when oracle/_ref is absent), untimed:
+    all blocks (n_check = 0) or n_check blocks strided across the batch, in chunks -- the reference codes a chunk on the host cores,
+    the comparison itself runs on the device.  With `hdr` / `hdr_sizes` (the using-table calls) the reference's block is header then
+    payload: the device's header bytes and payload bytes are compared with the two parts.  Returns the number of blocks checked."""
+    nb = src.shape[0]
+    dev = src.device
+    idx = torch.arange(nb, device=dev) if not n_check or n_check >= nb else torch.arange(0, nb, max(1, nb // n_check), device=dev)[:n_check]
+    codec = 0 if codec_name == "fse" else 1
+    cols = torch.arange(dst.shape[1], device=dev)
+    for lo in range(0, idx.numel(), chunk):
+        sel = idx[lo:lo + chunk]
+        host = src[sel].cpu().numpy()
+        _, ores, odst = lib.compress_batch(codec, host, table_log=table_log, nthreads=host_threads(), cap=dst.shape[1])
+        ref_res = torch.from_numpy(ores.astype(np.int64)).to(dev)
+        ref_dst = torch.from_numpy(odst).to(dev)
+        coded = (ref_res > 1) & (ref_res < (1 << 40))
+        if hdr is None:
+            got = res[sel]
+            assert torch.equal(got, ref_res), "%s encode return values differ from the CPU %s (block %d)" % (
+                codec_name, lib.kind, int(sel[(got != ref_res).nonzero()[0, 0]]))
+            live = cols[None, :] < (ref_res * coded)[:, None]
+            bad = ((dst[sel] != ref_dst) & live).any(dim=1)
+        else:
+            h = hdr_sizes[sel]
+            assert bool((coded == (h > 1)).all()), "%s table builder and the CPU %s disagree on which blocks are coded" % (codec_name, lib.kind)
+            assert bool(((res[sel] + h == ref_res) | ~coded).all()), "%s header + payload sizes differ from the CPU %s" % (codec_name, lib.kind)
+            hc = cols[None, :hdr.shape[1]]
+            bad = ((hdr[sel] != ref_dst[:, :hdr.shape[1]]) & (hc < (h * coded)[:, None])).any(dim=1)
+            # payload byte j of the device = byte h + j of the reference's block
+            shifted = torch.gather(ref_dst, 1, (cols[None, :] + (h * coded)[:, None]).clamp(max=ref_dst.shape[1] - 1))
+            bad |= ((dst[sel] != shifted) & (cols[None, :] < (res[sel] * coded)[:, None])).any(dim=1)
+        assert not bool(bad.any()), "%s encode bytes differ from the CPU %s (block %d)" % (codec_name, lib.kind, int(sel[bad.nonzero()[0, 0]]))
+    return int(idx.numel())
+
+
+def checker_lib():
+    try:
+        from oracle.oracle import Oracle, Ref
+        return Ref() if Ref.available() else Oracle()
+    except OSError:
+        return None
+
+
+def check_parity(cd, rank, n_check=0):
+    """untimed gates: round trip on every block; encoder bytes and return values of EVERY block (n_check = 0; else a strided sample)
+    against the compiled reference (or the oracle when oracle/_ref is absent)"""
     nb = cd.src.shape[0]
     assert bool((cd.dres == BLOCK).all()), "%s decode return values wrong" % cd.name
     assert torch.equal(cd.out, cd.src), "%s decode(encode(x)) != x" % cd.name
     parity = "roundtrip-all-blocks"
     if rank != 0:
-        return parity
-    try:
-        from oracle.oracle import Oracle, Ref
-        lib = Ref() if Ref.available() else Oracle()
-    except OSError:
-        return parity + "(checker unavailable)"
-    idx = torch.arange(0, nb, max(1, nb // n_check), device=cd.src.device)[:n_check]
-    host = cd.src[idx].cpu().numpy()
-    _, ores, odst = lib.compress_batch(0 if cd.name == "fse" else 1, host, table_log=cd.tl, nthreads=host_threads())
-    rh, dh = cd.res[idx].cpu().numpy(), cd.dst[idx].cpu().numpy()
-    assert (rh == ores.astype(np.int64)).all(), "%s encode sizes differ from the CPU %s" % (cd.name, lib.kind)
-    for b in range(len(rh)):
-        assert (dh[b][:rh[b]] == odst[b][:rh[b]]).all(), "%s encode bytes differ from the CPU %s (block %d)" % (cd.name, lib.kind, int(idx[b]))
-    return parity + "+%s-bytes-%d-blocks-strided" % (lib.kind, len(rh))
+        return parity, 0
+    lib = checker_lib()
+    if lib is None:
+        return parity + "(checker unavailable)", 0
+    n = reference_bytes_check(lib, cd.name, cd.tl, cd.src, cd.dst, cd.res, n_check)
+    return parity + "+%s-bytes-%s" % (lib.kind, "all-%d-blocks" % n if n == nb else "%d-blocks-strided" % n), n
 
 
 def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
@@ -257,10 +303,101 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
                         "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
 
 
+def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warmup, barrier, reduce_max, world, rank):
+    """The functions north_star names, in the form it names them (lib/fse.h:174,247, lib/huf.h:190,275; what programs/fullbench.c:805-814,
+    851-862,897-905,987-998 time separately): tables built ONCE on the device (FSEHIP_*_build*Table_batch: the library's own prepare
+    kernels behind calls of their own), then `steps` timed passes of *_compress_usingCTable_batch + *_decompress_usingDTable_batch over
+    the same blocks.  Parity: every block's header + payload against the reference's one-shot output, every block round-tripped."""
+    from finitestateentropy_amd.api import fse_compress_bound, huf_compress_bound
+    nb = src.shape[0]
+    dev = src.device
+    fse = codec_name == "fse"
+    cap = fse_compress_bound(BLOCK) if fse else huf_compress_bound(BLOCK)
+    dst = pools["dst_" + codec_name][:nb * cap].view(nb, cap)
+    res = pools["res_" + codec_name][:nb]
+    out = pools["out_" + codec_name][:nb * BLOCK].view(nb, BLOCK)
+    dres = pools["dres_" + codec_name][:nb]
+    if fse:
+        ct, hdr, hres = hip.fse_build_ctable_batch(src, table_log=table_log)
+        dt, dtres = hip.fse_build_dtable_batch(hdr, hres, max_log=table_log)
+        dec_maxlog = int(os.environ.get("FSEHIP_BENCH_UT_MAXLOG", "12"))      # what the caller promises about its tables (12 = nothing: FSE_MAX_TABLELOG)
+    else:
+        ct, hdr, hres = hip.huf_build_ctable_batch(src, table_log=table_log)
+        dt, dtres = hip.huf_read_dtable_x1_batch(hdr, hres, max_table_log=table_log)
+    torch.cuda.synchronize()
+    assert bool((hres > 1).all()) and bool((dtres == hres).all()), "%s table builders refused a block of the workload" % codec_name
+
+    def encode():
+        if fse:
+            hip.fse_compress_using_ctable_batch(src, ct, max_table_log=table_log, dst=dst, results=res)
+        else:
+            hip.huf_compress4x_using_ctable_batch(src, ct, dst=dst, results=res)
+
+    def decode():
+        if fse:
+            hip.fse_decompress_using_dtable_batch(dst, res, dt, BLOCK, max_table_log=dec_maxlog, dst=out, results=dres)
+        else:
+            hip.huf_decompress4x1_using_dtable_batch(dst, res, dt, BLOCK, max_table_log=table_log, dst=out, results=dres)
+
+    for _ in range(warmup):
+        encode(); decode()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        encode(); ev[2 * i + 1].record()
+        decode(); ev[2 * i + 2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_double * 16)(); launches = (C.c_uint * 16)()
+    if not PLAIN:
+        hip.lib.FSEHIP_probe_begin()
+        for _ in range(steps):
+            encode(); decode()
+        barrier()
+        hip.lib.FSEHIP_probe_collect(ms, launches)
+    enc = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)) * 1e-3
+    dec = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(steps)) * 1e-3
+    best = min(ev[2 * i].elapsed_time(ev[2 * i + 2]) for i in range(steps)) * 1e-3
+    elapsed, enc, dec, best = reduce_max([elapsed, enc, dec, best])
+    assert bool((dres == BLOCK).all()) and torch.equal(out, src), "%s usingDTable(usingCTable(x)) != x" % codec_name
+    parity, checked = "roundtrip-all-blocks", 0
+    if rank == 0:
+        lib = checker_lib()
+        if lib is not None:
+            checked = reference_bytes_check(lib, codec_name, table_log, src, dst, res, 0, hdr=hdr, hdr_sizes=hres)
+            parity += "+%s-header-and-payload-bytes-all-%d-blocks" % (lib.kind, checked)
+    total = world * nb * BLOCK * steps
+    payload = float(res.sum().item()) / nb
+    per = {KERNEL_NAMES[i]: (ms[i], launches[i]) for i in range(len(KERNEL_NAMES)) if launches[i]}
+    rec = {"value": round(total / 2.0 ** 20 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "best_step_ms": round(best * 1e3, 3), "steps": steps,
+           "blocks_per_gpu": nb, "encode_GBps": round(total / enc / 1e9, 2), "decode_GBps": round(total / dec / 1e9, 2),
+           "payload_bytes_per_block": round(payload, 1), "header_bytes_per_block": round(float(hres.sum().item()) / nb, 1),
+           "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in per.items()}, "parity": parity, "parity_blocks_checked": checked,
+           "functions": ("FSEHIP_FSE_compress_usingCTable_batch + FSEHIP_FSE_decompress_usingDTable_batch" if fse else
+                         "FSEHIP_HUF_compress4X_usingCTable_batch + FSEHIP_HUF_decompress4X1_usingDTable_batch"),
+           "workload": "probagen Proba%02d, %d x 32KB blocks per GPU, tables (reference layouts, table log %d) built once by FSEHIP_%s_batch, then the "
+                       "using-table calls alone" % (proba, nb, table_log, "FSE_buildCTable / FSE_buildDTable" if fse else "HUF_buildCTable / HUF_readDTableX1")}
+    alg = BLOCK + payload                                          # SURVEY 8(d): read input once + write output once (tables excluded)
+    roofs = {}
+    for direction, kernels in (("encode", ("k_fse_encode_wave", "k_fse_encode") if fse else ("k_huf_encode",)), ("decode", ("k_fse_decode",) if fse else ("k_huf_decode",))):
+        hot = [k for k in kernels if k in per]
+        if hot:
+            k = max(hot, key=lambda x: per[x][0])
+            kms = per[k][0] / steps
+            roofs[direction] = {"bound": "hbm", "kernel": k, "achieved": round(alg * nb / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg * nb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms_per_pass": round(kms, 3),
+                                "algorithmic_bytes_per_block": round(alg, 1), "traffic": None}
+    rec["roofline"] = roofs
+    del ct, hdr, dt
+    return rec
+
+
 PLAIN = False          # --plain: see parse()
 
 
-def run_case(hip, codecs, steps, warmup, barrier, rank, check=True, n_check=8192):
+def run_case(hip, codecs, steps, warmup, barrier, rank, check=True, n_check=0):
     """time `steps` steps (each: encode + decode of every codec in `codecs`), bracketed by barrier + synchronize, with the
     kernel probe OFF; then the same steps once more with every launch of the library bracketed by HIP events on its stream
     (FSEHIP_probe_*) for the per-kernel table and the roofline.  Returns the raw timings of this rank and the per-kernel probe."""
@@ -298,11 +435,13 @@ def run_case(hip, codecs, steps, warmup, barrier, rank, check=True, n_check=8192
             enc_s[cd.name] += ev[k - 1].elapsed_time(ev[k]) / 1e3; k += 1
             dec_s[cd.name] += ev[k - 1].elapsed_time(ev[k]) / 1e3; k += 1
     per = {KERNEL_NAMES[i]: (ms[i], launches[i]) for i in range(len(KERNEL_NAMES)) if launches[i]}
-    out = {"elapsed": elapsed, "probe_elapsed": probe_elapsed, "enc_s": enc_s, "dec_s": dec_s, "per": per, "parity": {}, "csize": {}}
+    out = {"elapsed": elapsed, "probe_elapsed": probe_elapsed, "enc_s": enc_s, "dec_s": dec_s, "per": per, "parity": {}, "csize": {}, "parity_blocks_checked": 0,
+           "step_s": [(ev[2 * len(codecs) * i].elapsed_time(ev[2 * len(codecs) * (i + 1)])) / 1e3 for i in range(steps)]}
     for cd in codecs:
         out["csize"][cd.name] = float(cd.res.sum().item()) / cd.src.shape[0]
         if check:
-            out["parity"][cd.name] = check_parity(cd, rank, n_check)
+            out["parity"][cd.name], n = check_parity(cd, rank, n_check)
+            out["parity_blocks_checked"] += n
     return out
 
 
@@ -432,6 +571,7 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     achieved = alg * blocks_per_launch / (dom_ms / dom_launches * 1e-3) / 1e9
     traffic = None
     by_size = None
+    traffic_source = None
     if traffic_tag is not None:
         tpath = os.path.join(ROOT, "profiles", "traffic_%s%s.json" % (dom, traffic_tag))
         if os.path.exists(tpath):
@@ -439,6 +579,9 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
                 rec = json.load(open(tpath))
                 traffic = round(rec.get("hbm_bytes_per_block") * blocks_per_launch)
                 by_size = rec.get("request_size_bytes_per_block")
+                traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile.sh (%s blocks per launch there), HBM bytes per block "
+                                  "scaled to this run's blocks per launch -- a cross-reference recorded by the builder, not counters of this run"
+                                  % (os.path.basename(tpath), rec.get("blocks_per_launch", rec.get("blocks", "?"))))
             except Exception:
                 traffic = None
     out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -447,6 +590,8 @@ def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
     if dom.endswith("decode"):    # the decoders run one launch per class of blocks; HIP events bracket the group
         out["note"] = ("avg_launch_ms brackets the kernel's launches of one step (one per decoder class: launches over classes without blocks "
                        "return in microseconds and show up as extra calls in rocprofv3's table; profiles/*_pmc.md lists the per-pass totals)")
+    if traffic_source:
+        out["traffic_source"] = traffic_source
     if by_size:   # cross-check of `traffic`: the L2's memory-side requests counted by request size (exact bytes, profiles/*_pmc.md)
         out["traffic_by_request_size"] = {"read_bytes_per_block": by_size["read"], "write_bytes_per_block": by_size["write"]}
     return out
@@ -469,6 +614,12 @@ def summarize(r, codecs, nb, steps, world, reduce_max, total_blocks=None, traffi
     rec["roofline"] = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, steps, traffic_tag=traffic_tag)
     if r["parity"]:
         rec["parity"] = "; ".join("%s: %s" % (n, r["parity"][n]) for n in names)
+        rec["parity_blocks_checked"] = r["parity_blocks_checked"]
+    # the reference keeps the fastest of its runs (programs/bench.c:370-371); `value` is the mean over the timed steps as the harness
+    # contract asks, the best step rides beside it
+    best = reduce_max([min(r["step_s"])])[0]
+    rec["best_step_ms"] = round(best * 1e3, 3)
+    rec["best_step_value"] = round((total_blocks if total_blocks is not None else world * nb) * BLOCK / 2.0 ** 20 / best, 1)
     return rec, vals
 
 
@@ -590,10 +741,10 @@ def main():
     configs = {}
     if not args.no_configs:
 
-        def case(key, proba, names, n, first_block, table_log=args.table_log, max_log=args.max_log, desc="", total=None):
+        def case(key, proba, names, n, first_block, table_log=args.table_log, max_log=args.max_log, desc="", total=None, n_check=None):
             s = gen(proba, n, first_block)
             cds = [Codec(hip, nm, s, pools, table_log, max_log) for nm in names]
-            rr = run_case(hip, cds, cs, cw, barrier, rank, n_check=args.parity_blocks)
+            rr = run_case(hip, cds, cs, cw, barrier, rank, n_check=args.parity_blocks if n_check is None else n_check)
             rec, _ = summarize(rr, cds, n, cs, world, reduce_max, total_blocks=total)
             rec["workload"] = desc
             configs[key] = rec
@@ -610,9 +761,18 @@ def main():
             case("fse_tl12", 14, ("fse",), nb, rank * nb, table_log=12, desc="Proba14, FSE with tableLog 12 (what `fse -b` requests, programs/bench.c:113)")
         if want("huf_tl12"):
             case("huf_tl12", 2, ("huf",), nb, rank * nb, table_log=12, desc="Proba02 (256 symbols), Huff0 with tableLog 12 (HUF_TABLELOG_MAX)")
+        if want("using_tables"):
+            ut = {}
+            for key, codec_name, proba in (("fse_p14", "fse", 14), ("fse_p80", "fse", 80), ("huf_p14", "huf", 14)):
+                s_ut = gen(proba, nb, rank * nb)
+                ut[key] = using_tables_case(hip, codec_name, proba, s_ut, pools, args.table_log, cs, cw, barrier, reduce_max, world, rank)
+            ut["note"] = ("the north-star-named calls on caller-built tables in the reference's layouts; FSE decode converts the tables to its bit-reversed "
+                          "cells while staging them and runs the same fast loop as the one-shot path (compare kernel_ms_per_step.k_fse_decode with the "
+                          "headline's and cfg3's)")
+            configs["using_tables"] = ut
         if want("cfg5_mixed_shard"):
             n5 = args.cfg5_blocks
-            s5, cds5 = case("cfg5_mixed_shard", "mixed", ("fse", "huf"), n5, rank * n5,
+            s5, cds5 = case("cfg5_mixed_shard", "mixed", ("fse", "huf"), n5, rank * n5, n_check=args.cfg5_parity_blocks,
                             desc="BASELINE configs[4]'s mix at a fixed %d x 32KB blocks per GPU (%d in all): probagen mixed {P02,P14,P80} (block g: P[g mod 3], "
                                  "seed g+1), FSE and Huff0 round trip of every block, contiguous block ranges, no collective" % (n5, n5 * world))
             configs["cfg5_mixed_shard"]["scaling"] = "weak"
@@ -620,7 +780,7 @@ def main():
             del s5, cds5
         if want("cfg5_mixed_1M"):
             total = args.cfg5_total
-            s5, cds5 = case("cfg5_mixed_1M", "mixed", ("fse", "huf"), n5s, lo5, total=total,
+            s5, cds5 = case("cfg5_mixed_1M", "mixed", ("fse", "huf"), n5s, lo5, total=total, n_check=args.cfg5_parity_blocks,
                             desc="BASELINE configs[4] as named: probagen mixed {P02,P14,P80} (block g: P[g mod 3], seed g+1), %d x 32KB blocks in all, "
                                  "FSE and Huff0 round trip of every block, rank r codes shard_range(%d, r, %d) (this run: %d blocks per GPU); compute-only "
                                  "(each rank generates its shard, no collective)" % (total, total, world, n5s))

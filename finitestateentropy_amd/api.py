@@ -182,11 +182,13 @@ class FseHip:
         return counts, msv, res
 
     # ------------------------------------------------------------------ a2 / a3
-    def fse_compress_using_ctable_batch(self, src, ctables, max_table_log=12, sizes=None, dst_capacity=None, shared_table=False):
+    def fse_compress_using_ctable_batch(self, src, ctables, max_table_log=12, sizes=None, dst_capacity=None, shared_table=False, dst=None, results=None):
         n = _blocks(src, "src").shape[0]
         cap = fse_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
-        dst, g = self._dst(n, cap, src.device, zero=True)
-        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        g = None
+        if dst is None:
+            dst, g = self._dst(n, cap, src.device, zero=True)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device) if results is None else results
         ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_FSE_compress_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
@@ -196,10 +198,12 @@ class FseHip:
             g.check("FSE_compress_usingCTable_batch")
         return dst, res
 
-    def fse_decompress_using_dtable_batch(self, csrc, csizes, dtables, dst_capacity, max_table_log=12, shared_table=False):
+    def fse_decompress_using_dtable_batch(self, csrc, csizes, dtables, dst_capacity, max_table_log=12, shared_table=False, dst=None, results=None):
         n = _blocks(csrc, "csrc").shape[0]
-        dst, g = self._dst(n, dst_capacity, csrc.device, zero=True)
-        res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
+        g = None
+        if dst is None:
+            dst, g = self._dst(n, dst_capacity, csrc.device, zero=True)
+        res = torch.zeros(n, dtype=torch.int64, device=csrc.device) if results is None else results
         ps, uni, keep = _sizes_arg(csizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)
         _check(self.lib.FSEHIP_FSE_decompress_usingDTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(res), _ptr(csrc),
@@ -252,12 +256,12 @@ class FseHip:
         return dst, results
 
     # ------------------------------------------------------------------ tables built on the device (g1-g3)
-    def fse_build_ctable_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, header_capacity=512):
+    def fse_build_ctable_batch(self, src, table_log=11, max_symbol_value=255, sizes=None, header_capacity=512, ctables=None):
         """FSE_buildCTable_batch: (ctables (n, FSE_CTABLE_SIZE_U32(max(table_log, 9), 255)) int32, headers (n, header_capacity) uint8, results)"""
         n = _blocks(src, "src").shape[0]
         tl = min(max(table_log or 11, 9), 12)
         ctw = 1 + (1 << (tl - 1)) + 512
-        ct = torch.zeros((n, ctw), dtype=torch.int32, device=src.device)
+        ct = torch.zeros((n, ctw), dtype=torch.int32, device=src.device) if ctables is None else ctables
         hdr, g = self._dst(n, header_capacity, src.device, zero=True)
         res = torch.zeros(n, dtype=torch.int64, device=src.device)
         ws = torch.empty(int(self.lib.FSEHIP_FSE_buildCTable_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=src.device)
@@ -355,12 +359,14 @@ def _huf_methods():
             g.check("HUF_decompress_batch", dst_sizes)
         return dst, results
 
-    def huf_compress4x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
+    def huf_compress4x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False, dst=None, results=None):
         """ctables: (n, 256) int32/uint32 HUF_CElt entries (val | nbBits << 16)"""
         n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
-        dst, g = self._dst(n, cap, src.device, zero=True)
-        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        g = None
+        if dst is None:
+            dst, g = self._dst(n, cap, src.device, zero=True)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device) if results is None else results
         ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_HUF_compress4X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
@@ -370,12 +376,14 @@ def _huf_methods():
             g.check("HUF_compress4X_usingCTable_batch")
         return dst, res
 
-    def huf_compress1x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False):
+    def huf_compress1x_using_ctable_batch(self, src, ctables, sizes=None, dst_capacity=None, shared_table=False, dst=None, results=None):
         """HUF_compress1X_usingCTable over a batch (lib/huf.h:290): one stream per block"""
         n = _blocks(src, "src").shape[0]
         cap = huf_compress_bound(src.shape[1]) if dst_capacity is None else dst_capacity
-        dst, g = self._dst(n, cap, src.device, zero=True)
-        res = torch.zeros(n, dtype=torch.int64, device=src.device)
+        g = None
+        if dst is None:
+            dst, g = self._dst(n, cap, src.device, zero=True)
+        res = torch.zeros(n, dtype=torch.int64, device=src.device) if results is None else results
         ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
         stride = 0 if shared_table else ctables.stride(0)
         _check(self.lib.FSEHIP_HUF_compress1X_usingCTable_batch(_ptr(dst), SZ(dst.stride(0)), SZ(cap), _ptr(res), _ptr(src), SZ(src.stride(0)),
@@ -385,15 +393,19 @@ def _huf_methods():
             g.check("HUF_compress1X_usingCTable_batch")
         return dst, res
 
-    def huf_decompress4x_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False):
+    def huf_decompress4x_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, dst=None, results=None):
         """HUF_decompress4X_usingDTable over a batch: X1 (tableType 0) and X2 (tableType 1) tables, chosen per block"""
-        return self.huf_decompress4x1_using_dtable_batch(csrc, csizes, dtables, dst_sizes, max_table_log, shared_table, _fn="FSEHIP_HUF_decompress4X_usingDTable_batch")
+        return self.huf_decompress4x1_using_dtable_batch(csrc, csizes, dtables, dst_sizes, max_table_log, shared_table, dst=dst, results=results,
+                                                         _fn="FSEHIP_HUF_decompress4X_usingDTable_batch")
 
-    def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, _fn="FSEHIP_HUF_decompress4X1_usingDTable_batch"):
+    def huf_decompress4x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, dst=None, results=None,
+                                             _fn="FSEHIP_HUF_decompress4X1_usingDTable_batch"):
         n = _blocks(csrc, "csrc").shape[0]
-        width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
-        dst, g = self._dst(n, width, csrc.device, zero=not self.guard)
-        res = torch.zeros(n, dtype=torch.int64, device=csrc.device)
+        g = None
+        if dst is None:
+            width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
+            dst, g = self._dst(n, width, csrc.device, zero=not self.guard)
+        res = torch.zeros(n, dtype=torch.int64, device=csrc.device) if results is None else results
         pc, unic, keepc = _sizes_arg(csizes, csrc)
         pd, unid, keepd = _sizes_arg(dst_sizes, csrc)
         stride = 0 if shared_table else dtables.stride(0)

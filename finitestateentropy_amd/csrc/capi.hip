@@ -277,6 +277,7 @@ extern "C" int FSEHIP_FSE_decompress_usingDTable_batch(void* d_dst, size_t dstSt
     a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
     a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.atab = nullptr; a.symtab = nullptr; a.meta = nullptr;
     a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.nBlocks = nBlocks; a.tlMin = 0; a.declineNb0 = 0; a.onlyDeclined = 0;
+    a.symScratch = nullptr; a.slotBitmap = nullptr; a.nSlots = 0; a.scratchSlotBytes = 0;
     return (int)launch_fse_decode(a, (hipStream_t)stream);
 }
 
@@ -419,6 +420,7 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
         e.csrc = cs; e.dtables = nullptr; e.dtStrideU32 = 0; e.atab = atab; e.symtab = symtab; e.meta = meta;
         e.maxTableLog = maxLog; e.G = 0; e.slotU32 = 0; e.nBlocks = nb; e.tlMin = 0; e.declineNb0 = 0; e.onlyDeclined = 0;
+        e.symScratch = nullptr; e.slotBitmap = nullptr; e.nSlots = 0; e.scratchSlotBytes = 0;
         CK(launch_fse_decode_classes(e, lists, counts, s));
     }
     return 0;

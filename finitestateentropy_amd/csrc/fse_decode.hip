@@ -46,6 +46,9 @@
 // the fast ones (bitstream.h:378-388), so it is reconstructed from the cursor when the bulk loop ends.
 // NB0 = some cell of some table staged by this workgroup has nbBits == 0: a v_alignbit by 32 would return the low
 // word, so that one select is made explicit.
+#ifndef FSE_SYM_L1
+#define FSE_SYM_L1 1             // caller tables: the service waves' symbol gathers go through the CU's vector cache (invalidated when the slot is claimed)
+#endif
 #ifndef FSE_DEC_RING
 #define FSE_DEC_RING 64          // per-block LDS state ring: one entry (4 states, 8 bytes) per bulk iteration = four phases.  (Any multiple of
 #endif                           // FSE_CHECK_EVERY works.  Measured with 48 entries, which makes room for a 17th block per workgroup: the lanes of
@@ -254,19 +257,15 @@ DEV void fse_ring_put(u32* rg, int off, u32 w)
 // to ring offset (Stop - 4 - o) mod FSE_IN_RING (Stop = payload size rounded up to 4).  Either way ring byte x <-> payload
 // byte is a bijection on windows of FSE_IN_RING aligned-dword bytes, so the validLo protocol is the same.
 DEV void fse_ring_put_rev(u32* rg, int Sg, int off, u32 w) { fse_ring_put(rg, ((Sg + 3) & ~3) - 4 - off, __brev(w)); }
-template <bool TIMED>
-DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev)
+template <bool TIMED, bool CALLER>
+DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev, u32* flagsSh)
 {
-    const u32 symShift = a.atab ? 0u : 2u;
     const int myG = g0 + (lane < FSE_SRV_G ? lane : 0);      // lane l of this wave keeps the books of block g0 + l
     DecCtl* const ctl = ctlAll + (myG < a.G ? myG : 0);        // (the control area holds G entries)
     // per-block constants live in the registers of lane l of this wave
     const unsigned long long inBits = ((unsigned long long)ctl->inHi << 32) | ctl->inLo;
     const unsigned long long outBits = ((unsigned long long)ctl->outHi << 32) | ctl->outLo;
-    const unsigned long long tabBits = ((unsigned long long)(ctl->symHi & 0xFFFFu) << 32) | ctl->symLo;
-    // bit-reversed cells over a caller-built reference-layout table: the record holds the index rev(state) of the LDS cell, the symbol
-    // sits in the reference cell of `state` itself -- symRev = the table log (0: the symbol table is indexed like the LDS cells)
-    const u32 symRev = ctl->symHi >> 24;
+    const unsigned long long tabBits = ((unsigned long long)ctl->symHi << 32) | ctl->symLo;
     const int S32 = ctl->S32;
     int validLo = ctl->initValidLo;
     u32 flushed = 0, fpos = 0;                               // records flushed so far, and that count modulo the ring size
@@ -334,7 +333,6 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             if (!((fm >> l) & 1ull)) continue;               // uniform
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
             const u8* const tg = (const u8*)(uintptr_t)__shfl(tabBits, l, WAVE);
-            const u32 tlr = (u32)__shfl((int)symRev, l, WAVE);       // (all lanes active here: a shuffle inside the branch below would read lane l disabled when cnt <= l)
             if ((u32)lane < cnt) {
                 // iteration i lives in slot pair (i >> 1): 16 bytes = lane A's {iteration 2p, 2p+1} words, then lane B's
                 u32 ri = fp_g + (u32)lane;
@@ -342,14 +340,16 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
                 const u32* const rw = (const u32*)(ldsb + (size_t)(g0 + l) * slotBytes + ringOff) + 4u * (ri >> 1) + (ri & 1u);
                 uint2 rec; rec.x = rw[0]; rec.y = rw[2];      // x: state 1 before symbols 0 / 2, y: state 2 before symbols 1 / 3
                 // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1+ldsLog)
-                u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.ldsLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.ldsLog);
-                u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.ldsLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.ldsLog);
-                if (tlr) {                                   // uniform per block: state = the index's tlr bits reversed (address bits [1, 1+tlr) / [17, 17+tlr))
-                    const u32 rx = __brev(rec.x), ry = __brev(rec.y);
-                    x0 = __builtin_amdgcn_ubfe(rx, 31u - tlr, tlr); x1 = __builtin_amdgcn_ubfe(rx, 15u - tlr, tlr);
-                    x2 = __builtin_amdgcn_ubfe(ry, 31u - tlr, tlr); x3 = __builtin_amdgcn_ubfe(ry, 15u - tlr, tlr);
-                }
-                yq[l][0] = tg[x0 << symShift]; yq[l][2] = tg[x1 << symShift]; yq[l][1] = tg[x2 << symShift]; yq[l][3] = tg[x3 << symShift];
+                const u32 x0 = __builtin_amdgcn_ubfe(rec.x, 1u, a.ldsLog), x1 = __builtin_amdgcn_ubfe(rec.x, 17u, a.ldsLog);
+                const u32 x2 = __builtin_amdgcn_ubfe(rec.y, 1u, a.ldsLog), x3 = __builtin_amdgcn_ubfe(rec.y, 17u, a.ldsLog);
+#if FSE_SYM_L1
+                yq[l][0] = tg[x0]; yq[l][2] = tg[x1]; yq[l][1] = tg[x2]; yq[l][3] = tg[x3];
+#else
+                if (CALLER) {   // read at the L2
+                    yq[l][0] = __hip_atomic_load(tg + x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); yq[l][2] = __hip_atomic_load(tg + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    yq[l][1] = __hip_atomic_load(tg + x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); yq[l][3] = __hip_atomic_load(tg + x3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else { yq[l][0] = tg[x0]; yq[l][2] = tg[x1]; yq[l][1] = tg[x2]; yq[l][3] = tg[x3]; }
+#endif
             }
         }
         // (3) install the input chunks and publish them
@@ -371,6 +371,11 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         TIMING(const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy;);
     }
     TIMING(if (lane == 0 && g0 == 0) { atomicAdd(&g_decTiming[5], sBusy); atomicAdd(&g_decTiming[6], sIdle); });
+    // caller tables: the last service wave to finish hands the workgroup's slot of the symbol scratch back (only service waves read it)
+    if (CALLER && lane == 0 && atomicAdd(&flagsSh[7], 1u) == FSE_SRV_WAVES - 1) {
+        const u32 slot = flagsSh[6];
+        __hip_atomic_fetch_and(a.slotBitmap + (slot >> 5), ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
@@ -417,7 +422,7 @@ DEV size_t fse_tail(const Cells& t, u32 s1, u32 s2, BitReader& r, u8* out, long 
 // of a block follows its input rate.
 // LDS: G tables A[2^ldsLog] (u16) on table-size aligned addresses | DecCtl[G] | per block: state ring
 // (FSE_DEC_RING x 8 B), input ring (256 + 16 B) | two flag words
-template <bool FAST, bool TIMED>
+template <bool FAST, bool TIMED, bool CALLER>
 __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -452,11 +457,63 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // ---- stage: reference cells {u16 newState; u8 symbol; u8 nbBits} -> compact u16 (uniform control flow, both waves).
     //      A table whose fields do not fit 12+4 bits (cannot come from FSE_buildDTable) is flagged and decoded
     //      by the literal path only.
-    u32* const flagsSh = (u32*)(ldsb + (size_t)a.G * slotBytes);  // behind the slots: [0] any nbBits == 0, [1] unused, [2..3] bad-table mask, [4..5] decline mask
-    if (tid < 6) flagsSh[tid] = 0;
-    __syncthreads();
+    u32* const flagsSh = (u32*)(ldsb + (size_t)a.G * slotBytes);  // behind the slots: [0] any nbBits == 0, [1] some table is this launch's (caller tables), [2..3] bad-table mask, [4..5] decline mask,
+                                                                  // [6] slot of the symbol scratch (caller tables), [7] service waves finished
+    if (tid < 6 || tid == 7) flagsSh[tid] = 0;
+    const bool decWave = wave < FSE_DEC_WAVES;
+    u8* const tlSh = (u8*)(flagsSh + 8);                                  // caller tables: table log of every slot's table, 0xFF = not this launch's
+    if (CALLER) {
+        // Caller tables come without a workspace, and the symbols must not be gathered from the reference cells where they lie: 8 KiB per
+        // block, 33 blocks per CU, 32 CUs per L2 -- 8.6 MB of tables in flight on a 4 MB L2 (measured: 20.5 ms per 100k blocks against
+        // 12.2 with the one-shot path's byte tables).  The staging pass below therefore writes the symbols of the workgroup's tables
+        // into one slot of a small scratch the LIBRARY keeps per device (FseDecArgs::symScratch: 2 x CUs slots of 72 KB, allocated at the
+        // first such call); a slot is claimed here and handed back by the last service wave.  At most one workgroup of this kernel is
+        // resident per CU (160 KB of LDS), so with 2 x CUs slots the search below finds a free one at once.
+        // Meanwhile wave 1 looks at the headers of the workgroup's tables: which of them are this launch's (FseDecArgs: tlMin, ldsLog,
+        // onlyDeclined)?  A workgroup without any returns at once -- the launches for the classes a batch does not contain cost next to nothing.
+        __syncthreads();                                                 // (the flag words are zero)
+        bool mine = false;
+        if (tid >= 64 && tid < 64 + a.G) {
+            const size_t g = (size_t)tid - 64;
+            u32 tl = 0xFFu;
+            if (first + g < nTot) {
+                const size_t bi = slotBlock(g);
+                if (!(a.onlyDeclined && a.results[bi] != FSE_DECLINED)) {
+                    const u32 t0 = a.dtables[bi * a.dtStrideU32] & 0xFFFFu;
+                    if (t0 <= a.ldsLog && t0 >= a.tlMin) tl = t0;
+                    else if (t0 > a.maxTableLog && a.tlMin == 0 && !a.onlyDeclined) a.results[bi] = FERR(tableLog_tooLarge);   // (reported by the first launch)
+                }
+            }
+            tlSh[g] = (u8)tl;
+            mine = tl != 0xFFu;
+        }
+        if (mine) flagsSh[1] = 1u;                                       // (plain stores of the same value; no __syncthreads_or: it brings static LDS)
+        u32 slot = 0;
+        if (tid == 0) {
+            slot = (u32)blockIdx.x % a.nSlots;
+            for (;;) {
+                const u32 bit = 1u << (slot & 31u);
+                const u32 old = __hip_atomic_fetch_or(a.slotBitmap + (slot >> 5), bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(old & bit)) break;
+                slot = slot + 1 == a.nSlots ? 0 : slot + 1;
+            }
+            flagsSh[6] = slot;
+#if FSE_SYM_L1
+            // the slot may have been used from this CU before (by a workgroup long gone): whatever the CU's vector cache still holds of it
+            // is dropped before this workgroup writes and reads it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        }
+        __syncthreads();
+        if (!flagsSh[1]) {                                               // uniform: nothing of this launch's here
+            if (tid == 0) __hip_atomic_fetch_and(a.slotBitmap + (slot >> 5), ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    else __syncthreads();
+    u8* const symSlot = CALLER ? a.symScratch + (size_t)flagsSh[6] * a.scratchSlotBytes : nullptr;   // table g's symbols: symSlot + (g << ldsLog), in the order of its LDS cells
     {   u64 badBits = 0, declBits = 0; bool anyNb0 = false;
-        if (a.atab) {
+        if (!CALLER) {
             // k_fse_dbuild output: already in the LDS format; the first tabStride bytes of every block's global table slot are
             // its LDS image.  Every load is issued before the first store (a lone copy loop would pay the memory latency once
             // per table).
@@ -504,66 +561,106 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             // 113-124) is what the address arithmetic of the bulk loops rests on; a table that fails it is decoded by the literal
             // path alone (bad mask), which does with it whatever the reference does.  A table of log 12 with a cell of nbBits 0
             // (rev(newState) then needs 12 bits) is the plain loop's: marked in the decline mask when this launch may hand it on.
-            // Cells are loaded four tables ahead of their conversion (4-byte coalesced loads; the table starts one word into its
-            // slot), so that a workgroup pays a few memory latencies per 33 tables, not one per table.
+            // Every service wave takes whole tables (wave w: tables w, w + 9, ...): lane l loads the cell quads l, l + 64, ... of the table
+            // (16-byte loads; the table starts one word into its slot, which dwordx4 loads do not mind), all before it converts the first.
+            // The symbols go to the scratch slot in the order of the LDS cells, so that the service loop gathers them by the record's
+            // cell index as it does on the one-shot path (index arithmetic there is paid by every flush: measured +5 % rounds).  For the
+            // bit-reversed cells that order is scattered -- as scattered BYTE stores to global memory it cost 100k cycles per workgroup
+            // (67k write requests at the L2's request rate) -- so the wave first lays the symbol bytes out in the table's own LDS slot,
+            // copies the image to the scratch slot with coalesced 16-byte stores, and only then writes the cells over it (they wait
+            // in registers; LDS operations of one wave execute in order).  No workgroup barrier inside: the decoder waves are at their
+            // readers' set-up below meanwhile.
             const size_t nTab = nTot - first < (size_t)a.G ? nTot - first : (size_t)a.G;
-            constexpr u32 TB = 4;                                        // tables in flight
-            constexpr u32 CPT = ((1u << FSEHIP_FSE_MAX_TABLELOG) + FSE_DEC_THREADS - 1) / FSE_DEC_THREADS;   // cells per thread and table
-            for (u32 gb = 0; gb < (u32)nTab; gb += TB) {
-                u32 cellv[TB][CPT]; u32 tlg[TB];
+            constexpr u32 QL = 2048u / 4u / 64u;                             // cell quads per lane and pass: a table of 2048 cells is one pass
+            if (!decWave) for (u32 g = (u32)wave - FSE_DEC_WAVES; g < (u32)nTab; g += FSE_SRV_WAVES) {
+                const u32 tl = tlSh[g];
+                if (tl == 0xFFu) continue;                                // uniform per wave: not this launch's
+                const u32 ts = 1u << tl;
+                const u32* const t = a.dtables + slotBlock(g) * a.dtStrideU32;
+                u8* const slotB = lds8 + (size_t)g * tabStride;
+                u16* const A = (u16*)slotB;
+                u8* const symOut = symSlot + ((size_t)g << a.ldsLog);
+                bool bad = false, nbz = false;
+                if (FAST && tl >= 4u) {
+                    // the common shape, written for instruction count (a lone wave issues an instruction per ~8 cycles) and for registers
+                    // (eight quads per lane in flight; a table of 4096 cells takes two passes and reads its cells a second time -- from the
+                    // L2 -- when it writes them): the four cells of a quad sit at rev(i0) | rev2(q) << (tl - 2); the checks are OR-ed into
+                    // one word and looked at once
+                    const u32 sR = 32u - tl;
+                    const u32 qo[4] = { 0u, 1u << (tl - 1u), 1u << (tl - 2u), 3u << (tl - 2u) };
+                    const u32 passes = ts > 2048u ? ts / 2048u : 1u;
+                    u32 acc = 0, minNb = 15u;
+                    uint4 cv[QL];
+                    for (u32 h = 0; h < passes; ++h) {
 #pragma unroll
-                for (u32 k = 0; k < TB; ++k) {
-                    const u32 g = gb + k;
-                    tlg[k] = 0xFFFFu;                                     // = not this launch's
-                    if (g >= (u32)nTab) continue;
-                    const size_t bi = slotBlock(g);
-                    if (a.meta && a.meta[bi].state == 0) continue;
-                    if (a.onlyDeclined && a.results[bi] != FSE_DECLINED) continue;
-                    const u32* const t = a.dtables + bi * a.dtStrideU32;
-                    const u32 tl = t[0] & 0xFFFFu;
-                    if (tl > a.ldsLog || tl < a.tlMin) continue;
-                    tlg[k] = tl;
+                        for (u32 j = 0; j < QL; ++j) {
+                            const u32 i0 = 2048u * h + 4u * ((u32)lane + 64u * j);
+                            cv[j] = make_uint4(0, 0, 0, 0);
+                            if (i0 < ts) __builtin_memcpy(&cv[j], t + 1 + i0, 16);
+                        }
 #pragma unroll
-                    for (u32 j = 0; j < CPT; ++j) { const u32 i = (u32)tid + j * FSE_DEC_THREADS; cellv[k][j] = i < (1u << tl) ? t[1 + i] : 0u; }
-                }
+                        for (u32 j = 0; j < QL; ++j) {
+                            const u32 i0 = 2048u * h + 4u * ((u32)lane + 64u * j);
+                            if (i0 >= ts) continue;
+                            const u32 r0 = __brev(i0) >> sR;
+                            const u32 cw[4] = { cv[j].x, cv[j].y, cv[j].z, cv[j].w };
 #pragma unroll
-                for (u32 k = 0; k < TB; ++k) {
-                    const u32 tl = tlg[k];
-                    if (tl == 0xFFFFu) continue;                          // uniform
-                    u16* const A = (u16*)(lds8 + (size_t)(gb + k) * tabStride);
-                    bool bad = false, nbz = false;
+                            for (u32 q = 0; q < 4; ++q) {
+                                const u32 c = cw[q], ns = c & 0xFFFFu, nb = c >> 24;
+                                acc |= (ns >> tl) | ((tl - nb) >> 5) | (ns & ((1u << (nb & 31u)) - 1u));     // newState beyond the table / nbBits beyond tableLog / newState not a multiple of 1 << nbBits
+                                minNb = nb < minNb ? nb : minNb;
+                                slotB[r0 | qo[q]] = (u8)(c >> 16);
+                            }
+                        }
+                    }
+                    { for (u32 off = 16u * (u32)lane; off < ts; off += 1024u) { const uint4 v = *(const uint4*)(slotB + off); *(uint4*)(symOut + off) = v; } }
+                    for (u32 h = 0; h < passes; ++h) {
+                        if (passes > 1u) {
 #pragma unroll
-                    for (u32 j = 0; j < CPT; ++j) {
-                        const u32 i = (u32)tid + j * FSE_DEC_THREADS;
-                        if (i >= (1u << tl)) continue;
-                        const u32 c = cellv[k][j];
+                            for (u32 j = 0; j < QL; ++j) { const u32 i0 = 2048u * h + 4u * ((u32)lane + 64u * j); __builtin_memcpy(&cv[j], t + 1 + i0, 16); }
+                        }
+#pragma unroll
+                        for (u32 j = 0; j < QL; ++j) {
+                            const u32 i0 = 2048u * h + 4u * ((u32)lane + 64u * j);
+                            if (i0 >= ts) continue;
+                            const u32 r0 = __brev(i0) >> sR;
+                            const u32 cw[4] = { cv[j].x, cv[j].y, cv[j].z, cv[j].w };
+#pragma unroll
+                            for (u32 q = 0; q < 4; ++q) {
+                                const u32 c = cw[q];
+                                A[r0 | qo[q]] = (u16)(((__brev(c << 16) >> (16u - tl)) << 5) | ((c >> 24) & 31u));   // (rev over 32 bits of newState << 16 = its 16-bit reversal; down to tl bits)
+                            }
+                        }
+                    }
+                    bad = acc != 0; nbz = minNb == 0;
+                } else {
+                    // tables of fewer than 16 cells, and the plain cells of the register-window loop (a tableLog-12 table with a cell of
+                    // nbBits 0): cell by cell; the symbols of the plain cells sit in state order anyway
+#pragma unroll 2
+                    for (u32 i = (u32)lane; i < ts; i += 64u) {
+                        const u32 c = t[1 + i];
                         const u32 ns = c & 0xFFFFu, nb = c >> 24;
                         bad |= (ns >> tl) != 0 || nb > tl || nb > 15u || (ns & ((1u << (nb & 15u)) - 1u)) != 0;
                         nbz |= nb == 0;
-                        if (FAST) A[__brev(i) >> (32u - tl)] = (u16)((nb & 31u) | ((__brev(ns & ((1u << tl) - 1u)) >> (32u - tl)) << 5));
-                        else A[i] = (u16)((ns & 0xFFFu) | (nb << 12));
+                        const u32 pos = FAST ? __brev(i) >> (32u - tl) : i;
+                        symOut[pos] = (u8)(c >> 16);
+                        if (FAST) A[pos] = (u16)((nb & 31u) | ((__brev(ns & ((1u << tl) - 1u)) >> (32u - tl)) << 5));
+                        else A[pos] = (u16)((ns & 0xFFFu) | (nb << 12));
                     }
-                    if (bad) badBits |= 1ull << (gb + k);
-                    if (FAST && nbz && tl == 12u) declBits |= 1ull << (gb + k);
-                    anyNb0 |= nbz;
                 }
+                if (__any(bad)) badBits |= 1ull << g;
+                if (FAST && tl == 12u && __any(nbz)) declBits |= 1ull << g;
+                anyNb0 |= __any(nbz) != 0;
             }
         }
         if (badBits) { atomicOr(&flagsSh[2], (u32)badBits); atomicOr(&flagsSh[3], (u32)(badBits >> 32)); }
         if (declBits) { atomicOr(&flagsSh[4], (u32)declBits); atomicOr(&flagsSh[5], (u32)(declBits >> 32)); }
         if (anyNb0) atomicOr(&flagsSh[0], 1u);
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the LDS-DMA pieces have landed (lgkmcnt / expcnt fields left at their maxima)
-    __syncthreads();
-    const u64 badMask = (u64)flagsSh[2] | ((u64)flagsSh[3] << 32);
-    const u64 declMask = (u64)flagsSh[4] | ((u64)flagsSh[5] << 32);
-    const bool nb0 = flagsSh[0] != 0;
-
-    // ---- per-block set-up by the decoder wave: lanes 2g and 2g+1 walk block first+g together and both run this set-up
+    // ---- per-block set-up by the decoder waves, BEFORE the staged tables are waited for (the readers' first loads overlap the staging): lanes 2g and 2g+1 walk block first+g together and both run this set-up
     //      (identical values in both; only the even lane publishes, finishes the block and writes its result)
     //      (decoder wave w takes the slots [w * ppw, (w+1) * ppw))
     const int ppw = (a.G + FSE_DEC_WAVES - 1) / FSE_DEC_WAVES;
-    const bool decWave = wave < FSE_DEC_WAVES;
     const int gsl = (decWave ? wave * ppw : 0) + (lane >> 1);
     const u32 half = (u32)lane & 1u, maskB = half ? ~0u : 0u;
     const bool inRange = (lane >> 1) < ppw && gsl < a.G && first + (size_t)gsl < nTot;
@@ -572,22 +669,18 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     u32 hdr = 0;
     if (owner && a.meta) { if (a.meta[b].state == 0) owner = false; else hdr = a.meta[b].hdrSize; }
     u32 tl = 0; bool fast = false;
-    const bool compact = a.atab != nullptr;
+    constexpr bool compact = !CALLER;
     const u32* const gtab = compact ? nullptr : a.dtables + (owner ? b : 0) * a.dtStrideU32;   // reference-layout table in global memory
     if (owner) {
         if (compact) { tl = a.meta[b].tableLog; fast = (a.meta[b].state & 2u) != 0; if (tl > a.ldsLog) { a.results[b] = FERR(tableLog_tooLarge); owner = false; } }
         else {
-            // caller tables: one launch per class over all blocks (FseDecArgs); the first launch (tlMin 0) reports tables beyond the
-            // caller's maxTableLog, a launch that may hand blocks on marks the ones it leaves to the plain-cell launch
+            // caller tables: one launch per class over all blocks (FseDecArgs)
             const u32 h0 = gtab[0]; tl = h0 & 0xFFFFu; fast = (h0 >> 16) != 0;
-            if (a.onlyDeclined) { if (a.results[b] != FSE_DECLINED) owner = false; }
-            else if (tl > a.maxTableLog) { if (a.tlMin == 0 && half == 0) a.results[b] = FERR(tableLog_tooLarge); owner = false; }
-            else if (tl > a.ldsLog || tl < a.tlMin) owner = false;
-            else if (a.declineNb0 && ((declMask >> gsl) & 1ull)) { if (half == 0) a.results[b] = FSE_DECLINED; owner = false; }
+            if (tlSh[gsl] == 0xFFu) owner = false;                       // not this launch's (see the head of the kernel)
         }
     }
     const u32* const cells = compact ? nullptr : gtab + 1;      // literal path: reference cells, or the LDS cells + symbol table
-    const u8* const syms = compact ? a.symtab + ((owner ? b : 0) << a.maxTableLog) : (const u8*)cells + 2;
+    const u8* const syms = compact ? a.symtab + ((owner ? b : 0) << a.maxTableLog) : symSlot + ((size_t)(gsl < a.G ? gsl : 0) << a.ldsLog);
     // absolute LDS byte address of my table: the dynamic LDS segment starts at 0 (no static LDS in this kernel), which the
     // table-size alignment of the FAST address arithmetic relies on
     const u32 ldsBase = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds8;
@@ -610,6 +703,14 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             s2 = r.read(tl); r.reload();
         }
     }
+
+    __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the LDS-DMA pieces have landed (lgkmcnt / expcnt fields left at their maxima)
+    __syncthreads();
+    const u64 badMask = (u64)flagsSh[2] | ((u64)flagsSh[3] << 32);
+    const u64 declMask = (u64)flagsSh[4] | ((u64)flagsSh[5] << 32);
+    const bool nb0 = flagsSh[0] != 0;
+    // a launch that may hand blocks on marks the tables it leaves to the plain-cell launch (tableLog 12 with a cell of nbBits 0)
+    if (CALLER && owner && a.declineNb0 && ((declMask >> gsl) & 1ull)) { if (half == 0) a.results[b] = FSE_DECLINED; owner = false; }
 
     // ---- bulk: iterations of fse_decompress.c:201-218 whose loop-head reload is provably the fast one.
     //      The decoder lane touches only registers and LDS:
@@ -665,11 +766,10 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         ctl->srvFlushed = 0; ctl->srvValidLo = 0x7FFFFFFF;
         ctl->initValidLo = validLo; ctl->S32 = (int)(S < (1ull << 31) ? S + inA : 0);
         const unsigned long long ib = (unsigned long long)(uintptr_t)(in - inA), ob = (unsigned long long)(uintptr_t)out, tb = (unsigned long long)(uintptr_t)syms;
-        ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb;
-        ctl->symHi = ((u32)(tb >> 32) & 0xFFFFu) | ((FAST && !compact ? tl : 0u) << 24);     // (addresses have 48 bits)
+        ctl->inLo = (u32)ib; ctl->inHi = (u32)(ib >> 32); ctl->outLo = (u32)ob; ctl->outHi = (u32)(ob >> 32); ctl->symLo = (u32)tb; ctl->symHi = (u32)(tb >> 32);
     }
     __syncthreads();
-    if (!decWave) { fse_decode_service<TIMED>(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - FSE_DEC_WAVES) * FSE_SRV_G, FAST); return; }
+    if (!decWave) { fse_decode_service<TIMED, CALLER>(a, ldsb, ctlAll, slotBytes, ringOff, inOff, lane, (wave - FSE_DEC_WAVES) * FSE_SRV_G, FAST, flagsSh); return; }
 
     __builtin_amdgcn_s_setprio(3);                   // the decoder wave is the critical path of the workgroup
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < a.G ? gsl : 0) * slotBytes + ringOff) + half;   // my half of every slot pair
@@ -768,7 +868,11 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 
     // ---- literal tail: remaining iterations of :201-218, then :222-235
     size_t result;
-    if (!compact)     result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);     // caller tables: the reference's own cells
+    if (!compact) {   // caller tables: the staged cells and the scratch symbols; a table the staging pass did not vouch for: the reference's own cells
+        if ((badMask >> gsl) & 1ull) result = fse_tail(FseCellsRef{cells}, s1, s2, r, out, op, omax, fast);
+        else if (FAST)               result = fse_tail(FseCellsRev{A, syms, tl, 5u}, s1, s2, r, out, op, omax, fast);
+        else                         result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
+    }
     else if (FAST)    result = fse_tail(FseCellsRev{A, syms, tl, 5u}, s1, s2, r, out, op, omax, fast);
     else              result = fse_tail(FseCellsCompact{A, syms}, s1, s2, r, out, op, omax, fast);
     a.results[b] = result;
@@ -779,7 +883,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
     *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
-    int g = (int)((ldsBytes - 32) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (32 bytes: the flag words)
+    int g = (int)((ldsBytes - 96) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (96 bytes: the flag words and the caller tables' logs)
     if (g > FSE_MAXG) g = FSE_MAXG;
     *G = g;
 }
@@ -792,6 +896,38 @@ size_t fse_decode_blocks_per_round(unsigned maxTableLog)
     return (size_t)G * FSE_WGS_PER_CU * cus;
 }
 
+// The library's symbol scratch for caller-built tables (see the slot claim in k_fse_decode): per device, allocated at the first
+// FSE_decompress_usingDTable batch call on it and kept for the life of the process -- 2 x CUs slots of FSE_SYM_SLOT_BYTES plus the claim
+// bitmap.  (The reference's call takes no workspace, lib/fse.h:247; everything else the batched calls need comes from the caller.)
+#define FSE_SYM_SLOT_BYTES (FSE_MAXG * 2048u)            // 33 tables of 2 KiB (table logs up to 11) or 18 of 4 KiB
+#include <mutex>
+namespace {
+std::mutex g_symMutex;
+struct SymScratch { u8* base = nullptr; u32* bitmap = nullptr; u32 nSlots = 0; };
+SymScratch g_symScratch[64];
+}
+static hipError_t fse_sym_scratch(FseDecArgs& a)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_symMutex);
+    SymScratch& sc = g_symScratch[dev];
+    if (!sc.base) {
+        const u32 nSlots = 2u * (u32)(dev_props().ok ? dev_props().cus : 256);
+        const size_t bitmapBytes = ((nSlots + 31u) / 32u * 4u + 255u) & ~(size_t)255;
+        u8* p = nullptr;
+        e = hipMalloc((void**)&p, bitmapBytes + (size_t)nSlots * FSE_SYM_SLOT_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipMemset(p, 0, bitmapBytes);                          // (first call on this device only: synchronous, before any launch uses it)
+        if (e != hipSuccess) { (void)hipFree(p); return e; }
+        sc.bitmap = (u32*)p; sc.base = p + bitmapBytes; sc.nSlots = nSlots;
+    }
+    a.symScratch = sc.base; a.slotBitmap = sc.bitmap; a.nSlots = sc.nSlots; a.scratchSlotBytes = FSE_SYM_SLOT_BYTES;
+    return hipSuccess;
+}
+
 static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
 {
 #ifdef FSE_DEC_LDS12_KB             // A/B aid: another workgroup size for the classes with 8 KiB tables
@@ -799,17 +935,31 @@ static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
 #else
     const size_t ldsBytes = FSE_DEC_LDS;
 #endif
-    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true, false>, FSE_DEC_LDS);
-        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false, false>, FSE_DEC_LDS);
-        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<true, true>, FSE_DEC_LDS);
+    const bool caller = a.atab == nullptr;
+    {   hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true, false, false>, FSE_DEC_LDS);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<false, false, false>, FSE_DEC_LDS);
+        if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<true, true, false>, FSE_DEC_LDS);
+        if (e == hipSuccess && caller) e = ensure_dyn_lds((const void*)k_fse_decode<true, false, true>, FSE_DEC_LDS);
+        if (e == hipSuccess && caller) e = ensure_dyn_lds((const void*)k_fse_decode<false, false, true>, FSE_DEC_LDS);
+        if (e == hipSuccess && caller) e = fse_sym_scratch(a);
         if (e != hipSuccess) return e;
     }
     fse_decode_geometry(a.ldsLog, ldsBytes, &a.slotU32, &a.G);
     if (a.G < 1) return hipErrorInvalidValue;
+    if (caller && ((size_t)a.G << a.ldsLog) > FSE_SYM_SLOT_BYTES) return hipErrorInvalidValue;
     const size_t groups = (a.nBlocks + a.G - 1) / a.G;
-    if (rev && g_decTimingOn.load(std::memory_order_relaxed)) hipLaunchKernelGGL((k_fse_decode<true, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
-    else if (rev) hipLaunchKernelGGL((k_fse_decode<true, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
-    else          hipLaunchKernelGGL((k_fse_decode<false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    if (caller) {
+        if (rev && g_decTimingOn.load(std::memory_order_relaxed)) {
+            hipError_t e = ensure_dyn_lds((const void*)k_fse_decode<true, true, true>, FSE_DEC_LDS);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_fse_decode<true, true, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+        }
+        else if (rev) hipLaunchKernelGGL((k_fse_decode<true, false, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+        else     hipLaunchKernelGGL((k_fse_decode<false, false, true>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    }
+    else if (rev && g_decTimingOn.load(std::memory_order_relaxed)) hipLaunchKernelGGL((k_fse_decode<true, true, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    else if (rev) hipLaunchKernelGGL((k_fse_decode<true, false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
+    else          hipLaunchKernelGGL((k_fse_decode<false, false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     return hipGetLastError();
 }
 

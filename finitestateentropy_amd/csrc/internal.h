@@ -126,6 +126,8 @@ struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per
     // class, judged from the table's own header -- tableLog in [tlMin, ldsLog]; `declineNb0`: a table with a cell of nbBits 0 is left to
     // the plain-cell launch (marked FSE_DECLINED in results[]); `onlyDeclined`: take exactly the marked blocks
     unsigned tlMin; int declineNb0; int onlyDeclined;
+    // ... and their symbols go through a scratch the library keeps per device (set by the launcher, fse_decode.hip)
+    u8* symScratch; u32* slotBitmap; u32 nSlots; u32 scratchSlotBytes;
 };
 // marker in results[] between the launches of the caller-table batch (no size_t a decoder returns, cf. HUF_DECLINED)
 #define FSE_DECLINED ((size_t)0 - (size_t)0x7001)
