@@ -125,7 +125,8 @@ class FseHip:
                      "FSEHIP_FSE_countU16", "FSEHIP_FSE_compressU16", "FSEHIP_FSE_decompressU16",
                      "FSEHIP_FSE_compressU16_batch_workspaceSize", "FSEHIP_FSE_decompressU16_batch_workspaceSize",
                      "FSEHIP_FSE_buildCTable_batch_workspaceSize", "FSEHIP_FSE_buildDTable_batch_workspaceSize",
-                     "FSEHIP_HUF_buildCTable_batch_workspaceSize", "FSEHIP_HUF_readDTableX1_batch_workspaceSize"):
+                     "FSEHIP_HUF_buildCTable_batch_workspaceSize", "FSEHIP_HUF_readDTableX1_batch_workspaceSize",
+                     "FSEHIP_compact_batch_workspaceSize", "FSEHIP_compact_batch_bound"):
             if hasattr(L, name):
                 getattr(L, name).restype = SZ
         L.FSEHIP_getErrorName.restype = C.c_char_p
@@ -284,6 +285,38 @@ class FseHip:
                                                      C.c_uint(max_log), SZ(n), _ptr(ws), SZ(ws.numel()), _stream()), "FSE_buildDTable_batch")
         return dt, res
 
+    # ------------------------------------------------------------------ packed (variable-length) batches
+    def compact_batch(self, slots, results, src, sizes=None, packed=None, offsets=None):
+        """FSEHIP_compact_batch: (packed uint8 (capacity,), offsets int64 (n + 1,)); offsets[n] = the packed size"""
+        n = _blocks(slots, "slots").shape[0]
+        _blocks(src, "src")
+        if packed is None:
+            packed = torch.empty(max(n * src.shape[1], 1), dtype=torch.uint8, device=src.device)
+        if offsets is None:
+            offsets = torch.empty(n + 1, dtype=torch.int64, device=src.device)
+        self.lib.FSEHIP_compact_batch_workspaceSize.restype = SZ
+        ws = torch.empty(int(self.lib.FSEHIP_compact_batch_workspaceSize(SZ(n))), dtype=torch.uint8, device=src.device)
+        ps, uni, keep = _sizes_arg(src.shape[1] if sizes is None else sizes, src)
+        _check(self.lib.FSEHIP_compact_batch(_ptr(packed), SZ(packed.numel()), _ptr(offsets), _ptr(slots), SZ(slots.stride(0)), _ptr(results),
+                                             _ptr(src), SZ(src.stride(0)), ps, uni, SZ(n), _ptr(ws), SZ(ws.numel()), _stream()), "compact_batch")
+        return packed, offsets
+
+    def fse_decompress_packed_batch(self, packed, offsets, orig_sizes, dst_capacity, max_log=12, dst=None, results=None, workspace=None):
+        n = offsets.numel() - 1
+        g = None
+        if dst is None:
+            dst, g = self._dst(n, dst_capacity, packed.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=packed.device)
+        if workspace is None:
+            workspace = self.fse_workspace(n, max_log, True, packed.device)
+        po, uo, keep = _sizes_arg(orig_sizes, packed)
+        _check(self.lib.FSEHIP_FSE_decompress_packed_batch(_ptr(dst), SZ(dst.stride(0)), SZ(dst_capacity), _ptr(results), _ptr(packed), _ptr(offsets), po, uo,
+                                                           C.c_uint(max_log), SZ(n), _ptr(workspace), SZ(workspace.numel()), _stream()), "FSE_decompress_packed_batch")
+        if g:
+            g.check("FSE_decompress_packed_batch")
+        return dst, results
+
     # ------------------------------------------------------------------ layer 1 (host pointers, reference signatures)
     def _single(self, fname, cap, src, *extra):
         src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -441,6 +474,23 @@ def _huf_methods():
                                                       SZ(n), _ptr(ws), SZ(ws.numel()), _stream()), "HUF_readDTableX1_batch")
         return dt, res
 
+    def huf_decompress_packed_batch(self, packed, offsets, dst_sizes, dst=None, results=None, workspace=None):
+        n = offsets.numel() - 1
+        width = int(dst_sizes) if isinstance(dst_sizes, numbers.Integral) else int(dst_sizes.max().item())
+        g = None
+        if dst is None:
+            dst, g = self._dst(n, width, packed.device)
+        if results is None:
+            results = torch.empty(n, dtype=torch.int64, device=packed.device)
+        if workspace is None:
+            workspace = self.huf_workspace(n, True, packed.device)
+        pd, unid, keepd = _sizes_arg(dst_sizes, packed)
+        _check(self.lib.FSEHIP_HUF_decompress_packed_batch(_ptr(dst), SZ(dst.stride(0)), pd, unid, _ptr(results), _ptr(packed), _ptr(offsets), SZ(n),
+                                                           _ptr(workspace), SZ(workspace.numel()), _stream()), "HUF_decompress_packed_batch")
+        if g:
+            g.check("HUF_decompress_packed_batch", dst_sizes)
+        return dst, results
+
     # layer 1
     def huf_compress2(self, src, max_sv=255, huff_log=11, cap=None):
         return self._single("FSEHIP_HUF_compress2", huf_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(huff_log))
@@ -464,7 +514,7 @@ def _huf_methods():
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_HUF_decompress4X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
 
-    for f in (huf_build_ctable_batch, huf_read_dtable_x1_batch, huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
+    for f in (huf_decompress_packed_batch, huf_build_ctable_batch, huf_read_dtable_x1_batch, huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
               huf_decompress4x1_using_dtable_batch, huf_decompress4x_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
               huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable):
         setattr(FseHip, f.__name__, f)

@@ -149,7 +149,7 @@ extern "C" int FSEHIP_probe_collect(double* totalMs, unsigned* launches)
 
 static inline BlockView mkview(const void* base, size_t stride, const size_t* sizes, size_t uniform)
 {
-    BlockView v; v.base = (const u8*)base; v.stride = stride; v.sizes = sizes; v.uniform = uniform; return v;
+    BlockView v; v.base = (const u8*)base; v.stride = stride; v.sizes = sizes; v.uniform = uniform; v.offsets = nullptr; return v;
 }
 
 // =====================================================================================================
@@ -388,12 +388,20 @@ extern "C" size_t FSEHIP_FSE_decompress_batch_workspaceSize(size_t nBlocks, unsi
     return c * fse_dws_per_block(clamp_maxlog(maxLog)) + WS_SLACK;
 }
 
-extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
-                                           const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
-                                           unsigned maxLog, size_t nBlocks,
-                                           void* d_workspace, size_t workspaceBytes, void* stream)
+static inline BlockView subview(const BlockView& v, size_t b0)      // blocks b0.. of a view
 {
-    hipStream_t s = (hipStream_t)stream;
+    BlockView r = v;
+    if (v.offsets) r.offsets = v.offsets + b0;
+    else { r.base = v.base + b0 * v.stride; r.sizes = v.sizes ? v.sizes + b0 : nullptr; }
+    return r;
+}
+// rawRle: the bench loop's treatment of blocks the compressor declined (programs/bench.c:393-406) -- a record as long as the block is the
+// block itself, a record of one byte is that byte repeated -- applied by k_rawrle_expand (compact.hip); k_fse_dparse then leaves those alone
+hipError_t launch_rawrle_expand(u8* dst, size_t dstStride, size_t dstCapacity, size_t* results, const BlockView& csrc, const size_t* origSizes, size_t uniformOrig,
+                                size_t nBlocks, hipStream_t s);
+static int fse_decompress_impl(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results, const BlockView& csAll, unsigned maxLog, size_t nBlocks,
+                               void* d_workspace, size_t workspaceBytes, hipStream_t s, const size_t* d_origSizes, size_t uniformOrig, int rawRle)
+{
     if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     maxLog = clamp_maxlog(maxLog);
@@ -411,10 +419,12 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
     u32* counts = (u32*)p;                                      // FSE_DCLS_COUNT words (WS_SLACK covers the padding and this)
     for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
         const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
-        const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
+        const BlockView cs = subview(csAll, b0);
+        if (rawRle) CK(launch_rawrle_expand((u8*)d_dst + b0 * dstStride, dstStride, dstCapacity, d_results + b0, cs, d_origSizes ? d_origSizes + b0 : nullptr, uniformOrig, nb, s));
         FseDPrepArgs d;
         d.csrc = cs; d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.lists = lists; d.counts = counts;
         d.results = d_results + b0; d.nBlocks = nb;
+        d.rawRle = rawRle; d.origSizes = d_origSizes ? d_origSizes + b0 : nullptr; d.uniformOrig = uniformOrig;
         CK(launch_fse_dprep(d, s));
         FseDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
@@ -424,6 +434,24 @@ extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t
         CK(launch_fse_decode_classes(e, lists, counts, s));
     }
     return 0;
+}
+extern "C" int FSEHIP_FSE_decompress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                           const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                           unsigned maxLog, size_t nBlocks,
+                                           void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    return fse_decompress_impl(d_dst, dstStride, dstCapacity, d_results, mkview(d_cSrc, cStride, d_cSizes, uniformCSize), maxLog, nBlocks,
+                               d_workspace, workspaceBytes, (hipStream_t)stream, nullptr, 0, 0);
+}
+// FSE_decompress over a PACKED batch (FSEHIP_compact_batch), with the bench loop's treatment of declined blocks
+extern "C" int FSEHIP_FSE_decompress_packed_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                  const void* d_packed, const uint64_t* d_offsets, const size_t* d_origSizes, size_t uniformOrigSize,
+                                                  unsigned maxLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    BlockView v = mkview(d_packed, 0, nullptr, 0);
+    v.offsets = (const u64*)d_offsets;
+    return fse_decompress_impl(d_dst, dstStride, dstCapacity, d_results, v, maxLog, nBlocks, d_workspace, workspaceBytes, (hipStream_t)stream,
+                               d_origSizes, uniformOrigSize, 1);
 }
 
 // =====================================================================================================
@@ -514,7 +542,7 @@ extern "C" int FSEHIP_FSE_buildDTable_batch(FSEHIP_FSE_DTable* d_dtables, size_t
         FseDPrepArgs d;
         d.csrc = mkview((const u8*)d_headers + b0 * headerStride, headerStride, d_headerSizes ? d_headerSizes + b0 : nullptr, uniformHeaderSize);
         d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.lists = lists; d.counts = counts;
-        d.results = d_results + b0; d.nBlocks = nb;
+        d.results = d_results + b0; d.nBlocks = nb; d.rawRle = 0; d.origSizes = nullptr; d.uniformOrig = 0;
         CK(launch_fse_dprep(d, s));
         CK(launch_fse_export_dtables(d, d_dtables + b0 * dtableStrideU32, dtableStrideU32, s));
         CK(launch_hdr_results(meta, sizeof(FseMeta), d_results + b0, nb, s));
@@ -868,11 +896,9 @@ extern "C" size_t FSEHIP_HUF_decompress_batch_workspaceSize(size_t nBlocks)
     return c * HUF_DWS_PER_BLOCK + WS_SLACK;
 }
 
-extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
-                                           size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
-                                           size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+static int huf_decompress_impl(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize, size_t* d_results, const BlockView& csAll,
+                               size_t nBlocks, void* d_workspace, size_t workspaceBytes, hipStream_t s)
 {
-    hipStream_t s = (hipStream_t)stream;
     if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
     if (nBlocks == 0) return 0;
     if (workspaceBytes < HUF_DWS_PER_BLOCK + WS_SLACK) return (int)hipErrorInvalidValue;
@@ -886,7 +912,7 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
     u32* counts = (u32*)p;
     for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
         const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
-        const BlockView cs = mkview((const u8*)d_cSrc + b0 * cStride, cStride, d_cSizes ? d_cSizes + b0 : nullptr, uniformCSize);
+        const BlockView cs = subview(csAll, b0);
         const BlockView ds = mkview(nullptr, 0, d_dstSizes ? d_dstSizes + b0 : nullptr, uniformDstSize);
         HufDPrepArgs d;
         d.csrc = cs; d.dstSizes = ds; d.dst = (u8*)d_dst + b0 * dstStride; d.dstStride = dstStride;
@@ -900,6 +926,39 @@ extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const 
         CK(launch_huf_decode_classes(e, lists, counts, s));
     }
     return 0;
+}
+extern "C" int FSEHIP_HUF_decompress_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                           size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                           size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    return huf_decompress_impl(d_dst, dstStride, d_dstSizes, uniformDstSize, d_results, mkview(d_cSrc, cStride, d_cSizes, uniformCSize), nBlocks,
+                               d_workspace, workspaceBytes, (hipStream_t)stream);
+}
+// HUF_decompress over a PACKED batch (FSEHIP_compact_batch): HUF_decompress itself takes a record as long as the block for the block and
+// a record of one byte for that byte repeated (lib/huf_decompress.c:1063-1066), which is how the compaction stores what HUF_compress declined
+extern "C" int FSEHIP_HUF_decompress_packed_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize, size_t* d_results,
+                                                  const void* d_packed, const uint64_t* d_offsets, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    BlockView v = mkview(d_packed, 0, nullptr, 0);
+    v.offsets = (const u64*)d_offsets;
+    return huf_decompress_impl(d_dst, dstStride, d_dstSizes, uniformDstSize, d_results, v, nBlocks, d_workspace, workspaceBytes, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+//  Packed (variable-length) form of a batch of compressed blocks -- compact.hip
+// =====================================================================================================
+hipError_t launch_compact(u8* packed, size_t packedCapacity, u64* offsets, const u8* slots, size_t slotStride, const size_t* results, const BlockView& src,
+                          size_t nBlocks, u64* partials, hipStream_t s);
+extern "C" size_t FSEHIP_compact_batch_workspaceSize(size_t nBlocks) { return ((nBlocks + 1023) / 1024 + 2) * sizeof(u64) + 256; }
+extern "C" size_t FSEHIP_compact_batch_bound(size_t nBlocks, size_t blockSize) { return nBlocks * blockSize; }
+extern "C" int FSEHIP_compact_batch(void* d_packed, size_t packedCapacity, uint64_t* d_offsets, const void* d_slots, size_t slotStride, const size_t* d_results,
+                                    const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize, size_t nBlocks,
+                                    void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
+    if (workspaceBytes < FSEHIP_compact_batch_workspaceSize(nBlocks)) return (int)hipErrorInvalidValue;
+    return (int)launch_compact((u8*)d_packed, packedCapacity, (u64*)d_offsets, (const u8*)d_slots, slotStride, d_results,
+                               mkview(d_src, srcStride, d_srcSizes, uniformSrcSize), nBlocks, (u64*)d_workspace, (hipStream_t)stream);
 }
 
 // ---- Layer 1, Huff0 ---------------------------------------------------------------------------------

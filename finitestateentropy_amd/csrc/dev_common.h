@@ -24,14 +24,16 @@ DEV u32 ld32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 
 DEV u64 ld64(const u8* p) { return (u64)ld32(p) | ((u64)ld32(p + 4) << 32); }
 
 // A strided batch of byte blocks: block b = base + b*stride, size sizes[b] (or `uniform` when sizes == nullptr).
+// Packed form (FSEHIP_compact_batch): `offsets` (nBlocks + 1 entries) instead -- block b = base + offsets[b], offsets[b+1] - offsets[b] bytes.
 struct BlockView {
     const u8* base;
     size_t stride;
     const size_t* sizes;
     size_t uniform;
+    const u64* offsets;
 };
-DEV size_t view_size(const BlockView& v, size_t b) { return v.sizes ? v.sizes[b] : v.uniform; }
-DEV const u8* view_ptr(const BlockView& v, size_t b) { return v.base + b * v.stride; }
+DEV size_t view_size(const BlockView& v, size_t b) { return v.offsets ? (size_t)(v.offsets[b + 1] - v.offsets[b]) : v.sizes ? v.sizes[b] : v.uniform; }
+DEV const u8* view_ptr(const BlockView& v, size_t b) { return v.offsets ? v.base + v.offsets[b] : v.base + b * v.stride; }
 
 // 64-lane reductions (wave64; DPP/bpermute via __shfl_xor)
 DEV u32 wave_max_u32(u32 v)

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
         const u8* const in = view_ptr(a.csrc, b);
         const size_t cSize = view_size(a.csrc, b);
         size_t result = 0;
-        do {
+        bool done = false;                                                 // a raw / RLE record of a packed batch: regenerated by k_rawrle_expand, result written there
+        if (a.rawRle) { const size_t orig = a.origSizes ? a.origSizes[b] : a.uniformOrig; done = cSize == orig || cSize == 1; }
+        if (!done) do {
             u32 tl = 0, maxSV = 255;
             s16* const norm = a.norms + b * 256;
             const size_t h = ncount_read<1>(norm, &maxSV, &tl, in, cSize);     // fse_decompress.c:264
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
             m.state = 1u | ((u32)cls << 2); m.hdrSize = (u32)h; m.tableLog = tl; m.maxSV = maxSV;
         } while (0);
         a.meta[b] = m;
-        if (m.state == 0) a.results[b] = result;
+        if (m.state == 0 && !done) a.results[b] = result;
     }
     // append my block to the list of its class and size bin: one atomic per list and wave
     if (cls >= 0) { const size_t bin = view_size(a.csrc, b) >> FSE_DBIN_LOG; cls = cls * FSE_DBINS + (int)(bin < FSE_DBINS - 1 ? bin : FSE_DBINS - 1); }

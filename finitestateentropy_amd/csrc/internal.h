@@ -105,6 +105,9 @@ struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCo
     u32* counts;                 // their lengths (zeroed by the launcher)
     size_t* results;
     size_t nBlocks;
+    // packed batches with the bench loop's semantics (programs/bench.c:393-406): a record as long as the block (origSizes / uniformOrig)
+    // or of one byte is not a compressed block -- k_rawrle_expand has regenerated it; the parser leaves it alone
+    int rawRle; const size_t* origSizes; size_t uniformOrig;
 };
 hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s);
 

@@ -228,6 +228,28 @@ FSEHIP_API int FSEHIP_HUF_readDTableX1_batch(FSEHIP_HUF_DTable* d_dtables, size_
                                              const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize,
                                              size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
 
+/* ---- Packed (variable-length) batches.  The batched compressors write fixed-stride slots like the reference bench's buffers
+ * (programs/bench.c:514-516); what the reference's container stores (programs/fileio.c:343-400) and what is worth moving between GPUs
+ * or to the host is every block at its real size.  FSEHIP_compact_batch turns slots + results into records back to back:
+ *   record b = the compressed bytes (d_results[b] > 1) | the block itself, srcSize bytes (d_results[b] == 0: programs/bench.c:393-396) |
+ *              its first byte (d_results[b] == 1: :397-400) | nothing (d_results[b] an error code),
+ * d_offsets[b] = where record b starts, d_offsets[nBlocks] = the packed size (nBlocks + 1 entries).  A device exclusive scan and one
+ * coalesced copy; if the packed size exceeds packedCapacity the records that do not fit are not written and d_offsets[nBlocks] tells.
+ * FSEHIP_compact_batch_bound(nBlocks, blockSize) = nBlocks * blockSize always suffices for blocks of at most blockSize bytes.
+ * The decoders of a packed batch read the records where they lie and tell the three kinds apart by size, as HUF_decompress itself does
+ * (lib/huf_decompress.c:1063-1066): a record as long as the block is the block, a record of one byte that byte repeated, anything else
+ * goes through FSE_decompress / HUF_decompress.  d_origSizes / d_dstSizes: the regenerated size of every block. */
+FSEHIP_API size_t FSEHIP_compact_batch_workspaceSize(size_t nBlocks);
+FSEHIP_API size_t FSEHIP_compact_batch_bound(size_t nBlocks, size_t blockSize);
+FSEHIP_API int FSEHIP_compact_batch(void* d_packed, size_t packedCapacity, uint64_t* d_offsets, const void* d_slots, size_t slotStride, const size_t* d_results,
+                                    const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize, size_t nBlocks,
+                                    void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API int FSEHIP_FSE_decompress_packed_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                                  const void* d_packed, const uint64_t* d_offsets, const size_t* d_origSizes, size_t uniformOrigSize,
+                                                  unsigned maxLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+FSEHIP_API int FSEHIP_HUF_decompress_packed_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize, size_t* d_results,
+                                                  const void* d_packed, const uint64_t* d_offsets, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+
 /* Workload generator of the reference's benchmark (programs/probaGenerator.c:70-74,95-126), on the
  * device: block b = generate(blockSize bytes, table, seed = firstSeed + b).  h_table4096 is the
  * HOST 4096-entry symbol table built by FSEHIP_probagen_table(); it is consumed before the call returns (the
