@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--cfg5-blocks", type=int, default=125000, help="blocks per GPU of the weak-scaling config-5 record (1M / 8)")
     ap.add_argument("--cfg5-total", type=int, default=1000000, help="blocks of the fixed config-5 corpus (strong scaling; BASELINE configs[4])")
     ap.add_argument("--comm-passes", type=int, default=3, help="timed passes of the with-comm variant (after one untimed pass)")
+    ap.add_argument("--comm-pieces", type=int, default=4, help="pieces per shard of the pipelined with-comm variant")
     ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
     ap.add_argument("--parity-blocks", type=int, default=0, help="blocks whose encoder bytes are compared with the CPU reference, untimed (0 = every block of the "
                                                                  "headline and of configs 2-4; the mixed 1M-block configurations use --cfg5-parity-blocks)")
@@ -176,6 +177,14 @@ class Codec:
         else:
             self.ws_c = hip.huf_workspace(nb, False, dev)
             self.ws_d = hip.huf_workspace(nb, True, dev)
+
+    def piece(self, lo, hi):
+        """the same codec over rows [lo, hi) of the batch (views of the same buffers, the same workspaces): shard.sharded_codec_job_pipelined"""
+        import copy
+        pc = copy.copy(self)
+        pc.src = self.src[lo:hi] if self.src is not None else None
+        pc.dst, pc.res, pc.out, pc.dres = self.dst[lo:hi], self.res[lo:hi], self.out[lo:hi], self.dres[lo:hi]
+        return pc
 
     def encode(self):
         if self.name == "fse":
@@ -881,6 +890,54 @@ def with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, bar
         mx = reduce_max([ph[k] for k in keys])
         phases.append(dict(zip(keys, mx)))
     okv = reduce_max([0.0 if ok else 1.0])[0] == 0.0
+    # ---- the same job pipelined and with variable-length results (shard.sharded_codec_job_pipelined): every shard in `--comm-pieces`
+    #      pieces -- scatter of piece k + 1, codecs of piece k and gather of piece k - 1 overlap -- and what travels back is the packed
+    #      records of FSEHIP_compact_batch (every block at its real size) plus their offsets instead of fixed-stride slots
+    pipe = None
+    try:
+        def compact_fn(pc, piece_src):
+            return hip.compact_batch(pc.dst, pc.res, piece_src)
+        packed_out = offsets_out = None
+        if rank == 0:
+            packed_out = [torch.empty(total * BLOCK, dtype=torch.uint8, device=dev) for _ in cds5]
+            offsets_out = [torch.empty(total + 1, dtype=torch.int64, device=dev) for _ in cds5]
+        ptimes, stats, pok = [], None, True
+        for p in range(args.comm_passes + 1):
+            barrier()
+            t0 = time.perf_counter()
+            mine, packed_g, stats = shard.sharded_codec_job_pipelined(corpus, total, BLOCK, rank, world, dev, cds5, compact_fn, pieces=args.comm_pieces,
+                                                                      shard_out=shard_out, packed_out=packed_out, offsets_out=offsets_out)
+            barrier()
+            t = reduce_max([time.perf_counter() - t0])[0]
+            if p == 0:                                            # untimed pass: every rank's round trip, and the root decodes what it gathered
+                pok = all(bool((cd.dres == BLOCK).all()) and torch.equal(cd.out, mine) for cd in cds5)
+                if rank == 0:
+                    order = torch.tensor(stats["order"], device=dev)
+                    for cd, (pk, of) in zip(cds5, packed_g):
+                        for a0 in range(0, total, 65536):         # the packed stream decoded where it lies, 64k records at a time
+                            a1 = min(a0 + 65536, total)
+                            sub = of[a0:a1 + 1]
+                            if cd.name == "fse":
+                                o, r = hip.fse_decompress_packed_batch(pk, sub, BLOCK, BLOCK, max_log=cd.max_log)
+                            else:
+                                o, r = hip.huf_decompress_packed_batch(pk, sub, BLOCK)
+                            pok = pok and bool((r == BLOCK).all()) and torch.equal(o, corpus[order[a0:a1]])
+                            del o, r
+                continue
+            ptimes.append(t)
+        pokv = reduce_max([0.0 if pok else 1.0])[0] == 0.0
+        pmean = sum(ptimes) / len(ptimes)
+        pipe = {"value": round(total * BLOCK / 2.0 ** 20 / pmean, 1), "ms": round(pmean * 1e3, 2), "best_ms": round(min(ptimes) * 1e3, 2), "passes": len(ptimes),
+                "pieces_per_shard": args.comm_pieces, "roundtrip_ok": bool(pokv),
+                "scatter_bytes": stats["scatter_bytes"], "gather_bytes": stats["gather_bytes"], "payload_bytes": stats["payload_bytes"],
+                "fixed_stride_gather_bytes": (total - n) * sum(cd.cap + 8 for cd in cds5) if rank == 0 else 0,
+                "what": "the same job in %d pieces per shard, transfers posted without waiting (scatter of piece k + 1, codecs of piece k, gather of piece k - 1 "
+                        "overlap); the gather ships the packed records of FSEHIP_compact_batch -- every block at its real size, sizes exchanged first -- "
+                        "plus 8 bytes per record offset; on the untimed pass the root decodes the gathered packed streams where they lie and compares them "
+                        "with the corpus" % args.comm_pieces}
+        del packed_out, offsets_out
+    except Exception as e:
+        pipe = {"value": None, "error": repr(e)}
     mean = sum(times) / len(times)
     avg_ph = {k: round(sum(p_[k] for p_ in phases) / len(phases) * 1e3, 2) for k in phases[0]}
     scatter_bytes = (total - n) * BLOCK if rank == 0 else 0
@@ -893,6 +950,7 @@ def with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, bar
            "what": "rank 0 holds %d blocks: grouped scatter (one transfer per peer) + FSE and Huff0 encode+decode of every shard + grouped gather of both "
                    "codecs' fixed-stride compressed slots and sizes; 1 untimed pass (communicator set-up), then %d timed passes; value from their mean; "
                    "phase_ms = max over ranks of each phase, measured with a device synchronize between phases" % (total, len(times))}
+    rec["pipelined_packed"] = pipe
     del corpus, gather_out
     return rec
 

@@ -101,6 +101,204 @@ def gather_blocks(slots_mine, sizes_mine, n_blocks, rank, world, root=0, group=N
     return None, None
 
 
+def _post(ops, group=None):
+    """like _grouped, but returns at once: (requests, landing copies to make after they complete).  With RCCL a request's wait() makes the
+    current stream wait for the transfer (no host block), so compute queued before the wait overlaps the transfers in flight."""
+    if not ops:
+        return [], []
+    stage = _staged(group)
+    p2p, landing = [], []
+    for kind, t, peer in ops:
+        if kind == "send":
+            p2p.append(dist.P2POp(dist.isend, t.cpu() if (t.is_cuda and stage) else t, peer, group))
+        elif t.is_cuda and stage:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            landing.append((t, h))
+            p2p.append(dist.P2POp(dist.irecv, h, peer, group))
+        else:
+            p2p.append(dist.P2POp(dist.irecv, t, peer, group))
+    return dist.batch_isend_irecv(p2p), landing
+
+
+def _finish(posted):
+    reqs, landing = posted
+    for q in reqs:
+        q.wait()
+    for t, h in landing:
+        t.copy_(h)
+
+
+def all_totals(value, device, world, group=None):
+    """every rank's int64 `value` on every rank (a list of python ints): the sizes that have to be known before variable-length
+    transfers can be posted ("size exchange: ncclAllGather of one uint64")"""
+    if world == 1:
+        return [int(value)]
+    stage = _staged(group)
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if stage else device)
+    out = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return [int(x.item()) for x in out]
+
+
+def _total_later(offsets):
+    """the packed size offsets[-1] as a host integer, without draining the stream: a non-blocking copy into pinned memory and an event
+    recorded behind it now, the wait when the value is asked for (by then the device is busy with the next piece)"""
+    if not offsets.is_cuda:
+        return lambda: int(offsets[-1].item())
+    host = torch.empty(1, dtype=torch.int64).pin_memory()
+    host.copy_(offsets[-1:], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+
+    def ready():
+        ev.synchronize()
+        return int(host.item())
+    return ready
+
+
+def piece_ranges(lo, hi, pieces):
+    """[lo, hi) cut into `pieces` contiguous ranges of nearly equal length (empty ones when there are fewer blocks than pieces)"""
+    n = hi - lo
+    return [(lo + (n * k) // pieces, lo + (n * (k + 1)) // pieces) for k in range(pieces)]
+
+
+def post_gather_packed(packed_mine, offsets_mine, total_mine, totals, rows, rank, world, packed_root, offsets_root, base, root=0, group=None):
+    """One variable-length gather, posted without waiting: every rank's packed records (`total_mine` bytes) and record offsets
+    (rows[r] + 1 int64 each) land on the root -- bytes at packed_root[base + sum(totals[:r]) ...], offsets in scratch tensors.
+    Returns (posted, fix) -- `fix()` after _finish(posted) rebases the offsets into offsets_root[row0 : row0 + rows[r]] per rank and
+    returns the bytes this call moved over the links (payload + 8 per offset entry)."""
+    wire = 0
+    if rank == root:
+        ops, scratch, pos = [], [], base
+        for r in range(world):
+            if r == root:
+                scratch.append(None)
+            else:
+                tmp = torch.empty(rows[r][1] - rows[r][0] + 1, dtype=torch.int64, device=offsets_root.device)
+                scratch.append(tmp)
+                if totals[r]:
+                    ops.append(("recv", packed_root[pos:pos + totals[r]], r))
+                ops.append(("recv", tmp, r))
+                wire += totals[r] + 8 * tmp.numel()
+            pos += totals[r]
+        posted = _post(ops, group)
+
+        def fix():
+            pos = base
+            for r in range(world):
+                r0, r1 = rows[r]
+                if r == root:
+                    packed_root[pos:pos + totals[r]].copy_(packed_mine[:totals[r]])
+                    offsets_root[r0:r1].copy_(offsets_mine[:r1 - r0] + pos)
+                else:
+                    offsets_root[r0:r1].copy_(scratch[r][:r1 - r0] + pos)
+                pos += totals[r]
+            return wire
+        return posted, fix
+    ops = []
+    if total_mine:
+        ops.append(("send", packed_mine[:total_mine], root))
+    ops.append(("send", offsets_mine, root))
+    return _post(ops, group), (lambda: 0)
+
+
+def sharded_codec_job_pipelined(corpus_root, n_blocks, block_bytes, rank, world, device, codecs, compact_fn, pieces=4, root=0, group=None,
+                                shard_out=None, packed_out=None, offsets_out=None):
+    """BASELINE config 5 with the corpus on one rank, PIPELINED and with variable-length results: every rank's shard is cut into `pieces`
+    contiguous pieces; the root's scatter of piece k + 1, every rank's codecs on piece k and the gather of piece k - 1 overlap (transfers
+    are posted without waiting; with RCCL they run on the communicator's streams beside the compute stream).  What travels back is not
+    fixed-stride slots but the packed records of FSEHIP_compact_batch plus their offsets: `compact_fn(codec_piece, src_piece) ->
+    (packed uint8, offsets int64 (rows + 1))`; before a gather the ranks exchange their packed sizes (one int64 each).
+    `codecs`: objects with .piece(lo, hi) -> an object for rows [lo, hi) of this rank's shard with .src (assignable), .encode(), .decode(),
+    .dst, .res, .out, .dres.  Returns (my shard, [(packed, offsets) per codec on the root | (None, None)], stats) where offsets has
+    n_blocks + 1 entries (global block order inside every piece round: pieces are gathered rank after rank) and stats counts the bytes
+    the root moved: scatter_bytes, gather_bytes, payload_bytes."""
+    lo, hi = shard_range(n_blocks, rank, world)
+    mine = shard_out if shard_out is not None else torch.empty((hi - lo, block_bytes), dtype=torch.uint8, device=device)
+    ranges = [piece_ranges(*shard_range(n_blocks, r, world), pieces) for r in range(world)]      # [rank][piece] -> global rows
+    stats = {"scatter_bytes": 0, "gather_bytes": 0, "payload_bytes": 0}
+
+    def post_scatter(k):
+        if world == 1:
+            g0, g1 = ranges[0][k]
+            mine[g0 - lo:g1 - lo].copy_(corpus_root[g0:g1])
+            return [], []
+        ops = []
+        if rank == root:
+            for r in range(world):
+                g0, g1 = ranges[r][k]
+                if r == root:
+                    mine[g0 - lo:g1 - lo].copy_(corpus_root[g0:g1])
+                elif g1 > g0:
+                    ops.append(("send", corpus_root[g0:g1], r))
+                    stats["scatter_bytes"] += (g1 - g0) * block_bytes
+        else:
+            g0, g1 = ranges[rank][k]
+            if g1 > g0:
+                ops.append(("recv", mine[g0 - lo:g1 - lo], root))
+        return _post(ops, group)
+
+    gathered = None
+    if rank == root:
+        gathered = []
+        for i in range(len(codecs)):
+            pk = packed_out[i] if packed_out is not None else torch.empty(n_blocks * block_bytes, dtype=torch.uint8, device=device)
+            of = offsets_out[i] if offsets_out is not None else torch.empty(n_blocks + 1, dtype=torch.int64, device=device)
+            gathered.append((pk, of))
+    bases = [0] * len(codecs)                                       # bytes of every codec's packed stream gathered so far
+    row_base = 0                                                    # rows of the packed order gathered so far
+    order = []                                                      # global block index of every row of the packed order (root)
+
+    def gather_piece(k, packs):
+        """exchange sizes, post the variable-length transfers of piece k, finish them"""
+        nonlocal row_base
+        rows, r0 = [], row_base
+        for r in range(world):
+            g0, g1 = ranges[r][k]
+            rows.append((r0, r0 + (g1 - g0))); r0 += g1 - g0
+        fixes = []
+        for i, (packed, offsets, tot_ready) in enumerate(packs):
+            total = tot_ready()
+            totals = all_totals(total, device, world, group)
+            pk, of = gathered[i] if rank == root else (None, None)
+            posted, fix = post_gather_packed(packed, offsets, total, totals, rows, rank, world, pk, of, bases[i], root, group)
+            fixes.append((posted, fix, sum(totals)))
+        for i, (posted, fix, tot) in enumerate(fixes):
+            _finish(posted)
+            stats["gather_bytes"] += fix()
+            bases[i] += tot
+            stats["payload_bytes"] += tot
+        if rank == root:
+            for r in range(world):
+                order.extend(range(*ranges[r][k]))
+        row_base = r0
+
+    posted_in = post_scatter(0)
+    pending = None                                                  # (piece, packs) whose gather has not been posted yet
+    for k in range(pieces):
+        nxt = post_scatter(k + 1) if k + 1 < pieces else None
+        _finish(posted_in)
+        g0, g1 = ranges[rank][k]
+        packs = []
+        for cd in codecs:
+            pc = cd.piece(g0 - lo, g1 - lo)
+            pc.src = mine[g0 - lo:g1 - lo]
+            pc.encode(); pc.decode()
+            packed, offsets = compact_fn(pc, pc.src)
+            packs.append((packed, offsets, _total_later(offsets)))
+        if pending is not None:
+            gather_piece(*pending)                                  # (its sizes are long known: the device is busy with piece k meanwhile)
+        pending = (k, packs)
+        posted_in = nxt
+    gather_piece(*pending)
+    if rank == root:
+        for i in range(len(codecs)):
+            gathered[i][1][n_blocks] = bases[i]
+        stats["order"] = order
+        return mine, gathered, stats
+    return mine, [(None, None)] * len(codecs), stats
+
+
 def max_over_ranks(values, device, world, group=None):
     """bench.py timing rule: the slowest rank defines the step time."""
     t = torch.tensor(values, dtype=torch.float64, device=device)

@@ -71,6 +71,13 @@ def test_bench_two_ranks_start_from_gpus_flag():
     wc = strong["with_comm"]
     assert wc["roundtrip_ok"] is True and wc["passes"] == 2 and wc["value"] > 0
     assert set(wc["phase_ms"]) == {"1_scatter", "2_codecs", "3_gather"}
+    # the pipelined variant ships packed records: what comes back over the link is the peers' payload plus 8 bytes per record offset
+    pp = wc["pipelined_packed"]
+    assert pp.get("error") is None and pp["roundtrip_ok"] is True and pp["passes"] == 2 and pp["value"] > 0
+    n_peer = 8001 - 4001
+    assert pp["scatter_bytes"] == n_peer * 32768
+    assert pp["payload_bytes"] < 2 * 8001 * 32768 * 0.75 and pp["gather_bytes"] < pp["payload_bytes"]
+    assert pp["gather_bytes"] - 8 * 2 * (n_peer + pp["pieces_per_shard"]) > 0 and pp["gather_bytes"] < 0.7 * pp["fixed_stride_gather_bytes"]
 
 
 def test_bench_one_gpu_line_has_the_contract_fields():

@@ -63,6 +63,43 @@ def _worker(rank, world, port, n_blocks, block_bytes, q):
         job_ok = job_ok and all(g == (None, None) for g in gathered)
     assert job_ok
 
+    # the pipelined variant with variable-length (packed) results: pieces of every shard, sizes exchanged before each gather
+    def cpu_compact(pc, src):
+        recs = []
+        for b in range(src.shape[0]):
+            r = int(pc.res[b])
+            recs.append(src[b].numpy() if r == 0 else src[b].numpy()[:1] if r == 1 else pc.dst[b].numpy()[:r])
+        lens = np.array([len(x) for x in recs], np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        return torch.from_numpy(np.concatenate(recs) if len(recs) else np.zeros(0, np.uint8)), torch.from_numpy(offs)
+
+    class CpuPieces(CpuCodec):
+        def piece(self, lo, hi):
+            return CpuCodec(self.codec)
+    for pieces in (1, 4, 7):
+        cdp = [CpuPieces(0), CpuPieces(1)]
+        mine2, packed_g, stats = shard.sharded_codec_job_pipelined(blocks_root, n_blocks, block_bytes, rank, world, "cpu", cdp, cpu_compact, pieces=pieces)
+        assert torch.equal(mine2, mine)
+        if rank == 0:
+            payload = 0
+            for codec, (pk, of) in zip((0, 1), packed_g):
+                _, sres, sdst = orc.compress_batch(codec, blocks_root.numpy(), table_log=11, nthreads=1)
+                of = of.numpy(); pk = pk.numpy()
+                assert of[0] == 0 and len(stats["order"]) == n_blocks and sorted(stats["order"]) == list(range(n_blocks))
+                for row, b in enumerate(stats["order"]):                 # the records of the packed order, byte for byte
+                    r = int(sres[b])
+                    rec = blocks_root[b].numpy() if r == 0 else blocks_root[b].numpy()[:1] if r == 1 else sdst[b][:r]
+                    assert of[row + 1] - of[row] == len(rec) and (pk[of[row]:of[row + 1]] == rec).all(), (pieces, codec, b)
+                payload += int(of[n_blocks])
+            lo0, hi0 = shard.shard_range(n_blocks, 0, world)
+            own = sum(int(of_[n_blocks]) for _, of_ in packed_g)
+            assert stats["payload_bytes"] == payload
+            assert stats["scatter_bytes"] == (n_blocks - (hi0 - lo0)) * block_bytes
+            # what crossed the links on the way back: the peers' records plus 8 bytes per offset entry (rows + 1 per peer, piece and codec)
+            assert stats["gather_bytes"] <= payload + 8 * 2 * (n_blocks + pieces * world) and stats["gather_bytes"] >= 8 * 2 * (n_blocks - (hi0 - lo0))
+        else:
+            assert all(g == (None, None) for g in packed_g)
+
     g_slots, g_sizes, g_back, g_res = shard.sharded_roundtrip(blocks_root, n_blocks, block_bytes, rank, world, "cpu", comp, decomp)
     t = shard.max_over_ranks([float(rank + 1), 0.5], "cpu", world)
     assert t == [float(world), 0.5]
