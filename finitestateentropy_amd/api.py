@@ -118,6 +118,7 @@ class FseHip:
                      "FSEHIP_FSE_compress", "FSEHIP_FSE_compress2", "FSEHIP_FSE_decompress",
                      "FSEHIP_HUF_compress1X_usingCTable", "FSEHIP_HUF_compress4X_usingCTable",
                      "FSEHIP_HUF_decompress4X_usingDTable", "FSEHIP_HUF_decompress4X1_usingDTable",
+                     "FSEHIP_HUF_decompress1X_usingDTable", "FSEHIP_HUF_decompress1X1_usingDTable",
                      "FSEHIP_HUF_compress", "FSEHIP_HUF_compress2", "FSEHIP_HUF_decompress",
                      "FSEHIP_FSE_compress_batch_workspaceSize", "FSEHIP_FSE_decompress_batch_workspaceSize",
                      "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize",
@@ -491,6 +492,23 @@ def _huf_methods():
             g.check("HUF_decompress_packed_batch", dst_sizes)
         return dst, results
 
+    def huf_decompress1x1_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, dst=None, results=None):
+        """HUF_decompress1X1_usingDTable over a batch: one stream per block"""
+        return self.huf_decompress4x1_using_dtable_batch(csrc, csizes, dtables, dst_sizes, max_table_log, shared_table, dst=dst, results=results,
+                                                         _fn="FSEHIP_HUF_decompress1X1_usingDTable_batch")
+
+    def huf_decompress1x_using_dtable_batch(self, csrc, csizes, dtables, dst_sizes, max_table_log=12, shared_table=False, dst=None, results=None):
+        return self.huf_decompress4x1_using_dtable_batch(csrc, csizes, dtables, dst_sizes, max_table_log, shared_table, dst=dst, results=results,
+                                                         _fn="FSEHIP_HUF_decompress1X_usingDTable_batch")
+
+    def huf_decompress1x1_using_dtable(self, csrc, dt, dst_size):
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        return self._single("FSEHIP_HUF_decompress1X1_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
+
+    def huf_decompress1x_using_dtable(self, csrc, dt, dst_size):
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        return self._single("FSEHIP_HUF_decompress1X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
+
     # layer 1
     def huf_compress2(self, src, max_sv=255, huff_log=11, cap=None):
         return self._single("FSEHIP_HUF_compress2", huf_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(huff_log))
@@ -514,7 +532,8 @@ def _huf_methods():
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_HUF_decompress4X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
 
-    for f in (huf_decompress_packed_batch, huf_build_ctable_batch, huf_read_dtable_x1_batch, huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
+    for f in (huf_decompress1x1_using_dtable_batch, huf_decompress1x_using_dtable_batch, huf_decompress1x1_using_dtable, huf_decompress1x_using_dtable,
+              huf_decompress_packed_batch, huf_build_ctable_batch, huf_read_dtable_x1_batch, huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
               huf_decompress4x1_using_dtable_batch, huf_decompress4x_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
               huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable):
         setattr(FseHip, f.__name__, f)

@@ -833,6 +833,35 @@ extern "C" int FSEHIP_HUF_decompress4X_usingDTable_batch(void* d_dst, size_t dst
     return (int)launch_huf_decode(a, (hipStream_t)stream);
 }
 
+// HUF_decompress1X1_usingDTable / HUF_decompress1X_usingDTable over a batch (lib/huf.h:318-320; lib/huf_decompress.c:239-260,367-375,961-975):
+// one stream per block -- what HUF_compress1X_usingCTable writes
+static int huf_1x_dtable_batch(int acceptX2, void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                               size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                               const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog, size_t nBlocks, void* stream)
+{
+    if (maxTableLog == 0 || maxTableLog > FSEHIP_HUF_TABLELOG_MAX) maxTableLog = FSEHIP_HUF_TABLELOG_MAX;
+    HufDecArgs a;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
+    a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
+    a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 1; a.acceptX2 = acceptX2; a.onlyDeclined = 0; a.nBlocks = nBlocks;
+    return (int)launch_huf_decode(a, (hipStream_t)stream);
+}
+extern "C" int FSEHIP_HUF_decompress1X1_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                          size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                          const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                          size_t nBlocks, void* stream)
+{
+    return huf_1x_dtable_batch(0, d_dst, dstStride, d_dstSizes, uniformDstSize, d_results, d_cSrc, cStride, d_cSizes, uniformCSize, d_dtables, dtableStrideU32, maxTableLog, nBlocks, stream);
+}
+extern "C" int FSEHIP_HUF_decompress1X_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                         size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                         const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                         size_t nBlocks, void* stream)
+{
+    return huf_1x_dtable_batch(1, d_dst, dstStride, d_dstSizes, uniformDstSize, d_results, d_cSrc, cStride, d_cSizes, uniformCSize, d_dtables, dtableStrideU32, maxTableLog, nBlocks, stream);
+}
+
 // =====================================================================================================
 //  one-shot Huff0 block API over a batch
 // =====================================================================================================
@@ -993,7 +1022,7 @@ extern "C" size_t FSEHIP_HUF_compress4X_usingCTable(void* dst, size_t dstSize, c
     return huf_using_ctable_host(4, dst, dstSize, src, srcSize, CTable);
 }
 
-static size_t huf_using_dtable_host(bool acceptX2, void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+static size_t huf_using_dtable_host(bool acceptX2, void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable, int streams = 4)
 {
     const u32 desc = DTable[0];
     const unsigned type = (desc >> 8) & 0xFF;
@@ -1006,7 +1035,8 @@ static size_t huf_using_dtable_host(bool acceptX2, void* dst, size_t maxDstSize,
     HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(maxDstSize)); HK(ddt.alloc(words * 4)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
     HK(hipMemcpy(ddt.p, DTable, words * 4, hipMemcpyHostToDevice));
-    HK((hipError_t)(acceptX2 ? FSEHIP_HUF_decompress4X_usingDTable_batch : FSEHIP_HUF_decompress4X1_usingDTable_batch)(
+    HK((hipError_t)(streams == 1 ? (acceptX2 ? FSEHIP_HUF_decompress1X_usingDTable_batch : FSEHIP_HUF_decompress1X1_usingDTable_batch)
+                                 : (acceptX2 ? FSEHIP_HUF_decompress4X_usingDTable_batch : FSEHIP_HUF_decompress4X1_usingDTable_batch))(
         ddst.p, maxDstSize, nullptr, maxDstSize, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize, (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
@@ -1021,6 +1051,15 @@ extern "C" size_t FSEHIP_HUF_decompress4X_usingDTable(void* dst, size_t maxDstSi
 {
     // lib/huf_decompress.c:980-997 dispatches on tableType: single-symbol (X1) cells -> k_huf_decode, double-symbol (X2) cells -> k_huf_decode_x2
     return huf_using_dtable_host(true, dst, maxDstSize, cSrc, cSrcSize, DTable);
+}
+
+extern "C" size_t FSEHIP_HUF_decompress1X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+{
+    return huf_using_dtable_host(false, dst, maxDstSize, cSrc, cSrcSize, DTable, 1);
+}
+extern "C" size_t FSEHIP_HUF_decompress1X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable)
+{
+    return huf_using_dtable_host(true, dst, maxDstSize, cSrc, cSrcSize, DTable, 1);
 }
 
 extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)

@@ -488,6 +488,46 @@ __global__ __launch_bounds__(64) void k_huf_decode_x2(HufDecArgs a)
     a.results[b] = result;
 }
 
+// ---- HUF_decompress1X1_usingDTable / HUF_decompress1X_usingDTable, the literal path (lib/huf_decompress.c:239-260, 724-747, 955-975):
+// the block is ONE stream.  The stream-parallel decoder takes it first (huf_decode_par.hip, a.streams == 1: the stream in pieces); this
+// kernel -- one lane per block, the reference's reader state and loops, tables in global memory -- is for what it declines: tiny,
+// irregular and corrupt blocks, and whatever the reference makes of a damaged table.
+__global__ __launch_bounds__(64) void k_huf_decode_1x(HufDecArgs a)
+{
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.nBlocks) return;
+    if (a.onlyDeclined && a.results[b] != HUF_DECLINED) return;                           // decoded by the stream-parallel decoder
+    const u32* const gt = a.dtables + b * a.dtStrideU32;
+    const u32 desc = gt[0];
+    const u32 tableType = (desc >> 8) & 0xFFu, dtLog = (desc >> 16) & 0xFFu;
+    const u8* const in = view_ptr(a.csrc, b);
+    const size_t cSize = view_size(a.csrc, b), dstSize = view_size(a.dstSizes, b);
+    u8* const ostart = a.dst + b * a.dstStride;
+    size_t result;
+    do {
+        if (tableType != 0 && !(a.acceptX2 && tableType == 1)) { result = FERR(GENERIC); break; }   // :367-369 (the 1X1 entry point)
+        if (dtLog > a.maxTableLog) { result = FERR(tableLog_tooLarge); break; }
+        if (dtLog < 1) { result = FERR(corruption_detected); break; }                    // no table has tableLog 0 (the look-up would shift by 64)
+        if (tableType == 0) {
+            const u16* const cells = (const u16*)(gt + 1);
+            BitReader r;
+            const size_t e = r.init(in, cSize); if (is_err(e)) { result = e; break; }     // :252
+            size_t p = 0;                                                                 // HUF_decodeStreamX1, :214-237
+            while ((r.reload() == BR_UNFINISHED) & ((long)p < (long)dstSize - 3)) {
+                for (u32 q4 = 0; q4 < 4; ++q4) ostart[p++] = (u8)hufx1_step(r, cells, dtLog);
+            }
+            while (p < dstSize) ostart[p++] = (u8)hufx1_step(r, cells, dtLog);
+            result = (r.at == 0 && r.used == 64) ? dstSize : FERR(corruption_detected);   // :256-258
+        } else {
+            X2Stream st; st.op = ostart;
+            const size_t e = st.r.init(in, cSize); if (is_err(e)) { result = e; break; }  // :735
+            x2_finish(st, ostart + dstSize, gt + 1, dtLog);                               // HUF_decodeStreamX2, :692-722
+            result = (st.r.at == 0 && st.r.used == 64) ? dstSize : FERR(corruption_detected);
+        }
+    } while (0);
+    a.results[b] = result;
+}
+
 static int huf_decode_G(size_t ldsBytes, unsigned ldsLog)
 {
     const size_t perBlock = (2u << ldsLog) + 4 * (HD_STREAM_AUX + sizeof(HdCtl));
@@ -518,10 +558,15 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
     a.onlyDeclined = 0;
     probe_before(PK_HUF_DECODE, s);
     hipError_t e = hipSuccess;
-    if (a.streams == 4 && !a.meta) {
+    if (!a.meta) {
         e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
         if (e == hipSuccess && a.acceptX2) e = launch_huf_decode_par_x2(a, s);
         a.onlyDeclined = 1;
+    }
+    if (a.streams == 1) {                               // HUF_decompress1X[1]_usingDTable: one stream per block
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_huf_decode_1x, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a); e = hipGetLastError(); }
+        probe_after(PK_HUF_DECODE, s);
+        return e;
     }
     if (e == hipSuccess) e = huf_decode_launch(a, s);
     if (e == hipSuccess && a.acceptX2) {                 // HUF_decompress4X_usingDTable: blocks whose table is a double-symbol one

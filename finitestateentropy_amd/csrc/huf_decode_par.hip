@@ -153,19 +153,23 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     bool ok = (tableType == 0 || (X2CAP && tableType == 1 && a.acceptX2 && !a.meta)) && dtLog >= 1 && dtLog <= a.ldsLog && dtLog <= a.maxTableLog
               && cSize >= 10 && cSize < (1u << 28) && dstSize >= 64 && dstSize < (1u << 28);
     u32 len[4] = { 0, 0, 0, 0 }, T0[4] = { 0, 0, 0, 0 };
-    const u32 seg = (u32)((dstSize + 3) / 4);
-    if (ok) {
+    const int nStreams = a.streams == 1 ? 1 : 4;                         // HUF_decompress1X1_usingDTable: the block is ONE stream, no jump table
+    const u32 seg = nStreams == 4 ? (u32)((dstSize + 3) / 4) : (u32)dstSize;
+    const u32 jump = nStreams == 4 ? 6u : 0u;
+    if (ok && nStreams == 4) {
         len[0] = ld16(in); len[1] = ld16(in + 2); len[2] = ld16(in + 4);
         const size_t used = (size_t)len[0] + len[1] + len[2] + 6;
         if (used > cSize) ok = false; else len[3] = (u32)(cSize - used);
         if (3 * (size_t)seg >= dstSize) ok = false;
     }
+    if (ok && nStreams == 1) len[0] = (u32)cSize;
     if (ok) {
-        const u8* sp = in + 6;
+        const u8* sp = in + jump;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (q >= nStreams) break;
             const u32 last = len[q] ? sp[len[q] - 1] : 0;
-            if (len[q] < 8 || len[q] + 96 > DATA || last == 0) ok = false;
+            if (len[q] < 8 || last == 0) ok = false;                      // (a stream beyond the LDS budget is staged and decoded in pieces, below)
             else T0[q] = 8u * (len[q] - 1) + hibit32(last);              // unread bits under the end mark (bitstream.h:285-290)
             if (T0[q] < HPAR_MIN_BITS) ok = false;
             sp += len[q];
@@ -274,97 +278,120 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     const u32 mask2 = ((1u << dtLog) - 1u) << 1;
     const u32 arr = tabOff + (2u << a.ldsLog);
 
-    const u8* sp = in + 6;
+    const u8* sp = in + jump;
     bool good = true;
     HST(unsigned long long stRounds = 0, stBad = 0, tStage = 0, tP1 = 0, tRep = 0, tP2 = 0, tA = __builtin_readcyclecounter();)
+    // A stream longer than the LDS budget is taken in PIECES of PDW dwords: lane 63 of a piece ends on an exact boundary, which is where
+    // lane 0 of the next piece starts (no speculation across pieces: they run one after the other), and the piece's 16 dwords of slack
+    // hold the stream's next dwords instead of zeros.  One piece is the common case (the classes of k_huf_dprep fit their streams).
+    constexpr u32 PDW = DATA / 4u - 24u;                                 // dwords of a piece: DATA bytes hold them, 16 dwords of slack and rounding to units
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {                                        // uniform: stream after stream
+    for (int q = 0; q < nStreams; ++q) {                                 // uniform: stream after stream
         const u32 L = len[q], Sd = (L + 3) / 4;
-        __syncthreads();                                                 // (table staged / previous stream done)
-        // consumption order: array dword m = bit-reversed stream dword Sd-1-m; zeros behind the end (= below the stream's first bit).
-        // Units of four dwords, one 16-byte load each, all loads of a lane issued before the first LDS store; the top unit (its
-        // last dword may be partial) and the bottom one (the stream rarely starts on a unit boundary) go dword by dword.
-        {   const u32 units = (Sd + 3) / 4 + 4;                          // + 16 dwords of zeros
-            constexpr u32 MAXU = (DATA / 16 + 63) / 64;
-            uint4 buf[MAXU];
+        const u32 want = nStreams == 1 ? (u32)dstSize : (q < 3 ? seg : (u32)dstSize - 3 * seg);
+        const u32 Cend = 32u * Sd;                                       // global cursor (bits consumed from the top of dword Sd-1) at the stream's first bit
+        u32 Cstart = Cend - T0[q];                                       // ... and at the first code bit (above it: padding, end mark); later: where the next piece starts
+        u32 outBase = 0;                                                 // symbols regenerated by the pieces so far
+        const u32 warm = T0[q] > 6u * want ? HPAR_WARM + HPAR_WARM / 2 : HPAR_WARM;   // long codes resynchronise later (measured on 8-bit data: 128 -> 192 bits saves 4 %)
+#pragma unroll 1
+        while (good && Cstart < Cend) {                                  // uniform: piece after piece
+            const u32 mTop = (Cstart - 1u) >> 5;                         // array dword 0 = global dword mTop = stream dword Sd - 1 - mTop; the local cursor stays >= 1
+                                                                         // (the loops address the bit BELOW the cursor: Q = C - 1; Cstart >= 1: the end mark)
+            const u32 nd = Sd - mTop < PDW ? Sd - mTop : PDW;            // dwords of this piece
+            const bool lastPiece = mTop + nd == Sd;
+            __syncthreads();                                             // (table staged / previous piece done)
+            // consumption order: array dword m = bit-reversed stream dword dTop - m; zeros below the stream's first bit.
+            // Units of four dwords, one 16-byte load each, all loads of a lane issued before the first LDS store; units that touch
+            // either end of the stream go dword by dword.
+            {   const int dTop = (int)Sd - 1 - (int)mTop;
+                const u32 units = (nd + 3) / 4 + 4;                      // + 16 dwords of slack (the stream goes on there, or zeros)
+                constexpr u32 MAXU = (DATA / 16 + 63) / 64;
+                uint4 buf[MAXU];
 #pragma unroll
-            for (u32 t = 0; t < MAXU; ++t) {
-                const u32 u = lane + 64 * t;
-                buf[t] = make_uint4(0, 0, 0, 0);
-                if (u >= units) continue;
-                const int dLo = (int)Sd - 4 - 4 * (int)u;                // lowest stream dword of the unit
-                if (u > 0 && dLo >= 0) __builtin_memcpy(&buf[t], sp + 4 * dLo, 16);
-                else {
-                    u32 w[4] = { 0, 0, 0, 0 };
-                    for (int i = 0; i < 4; ++i) {
-                        const int d = dLo + i;
-                        if (d < 0 || d >= (int)Sd) continue;
-                        if (4 * (u32)d + 4 <= L) __builtin_memcpy(&w[i], sp + 4 * d, 4);
-                        else for (u32 b8 = 4 * (u32)d; b8 < L; ++b8) w[i] |= (u32)sp[b8] << (8 * (b8 & 3u));
+                for (u32 t = 0; t < MAXU; ++t) {
+                    const u32 u = lane + 64 * t;
+                    buf[t] = make_uint4(0, 0, 0, 0);
+                    if (u >= units) continue;
+                    const int dLo = dTop - 3 - 4 * (int)u;               // lowest stream dword of the unit
+                    if (dLo >= 0 && 4 * ((u32)dLo + 4) <= L) __builtin_memcpy(&buf[t], sp + 4 * dLo, 16);
+                    else {
+                        u32 w[4] = { 0, 0, 0, 0 };
+                        for (int i = 0; i < 4; ++i) {
+                            const int d = dLo + i;
+                            if (d < 0 || d >= (int)Sd) continue;
+                            if (4 * (u32)d + 4 <= L) __builtin_memcpy(&w[i], sp + 4 * d, 4);
+                            else for (u32 b8 = 4 * (u32)d; b8 < L; ++b8) w[i] |= (u32)sp[b8] << (8 * (b8 & 3u));
+                        }
+                        buf[t] = make_uint4(w[0], w[1], w[2], w[3]);
                     }
-                    buf[t] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+#pragma unroll
+                for (u32 t = 0; t < MAXU; ++t) {
+                    const u32 u = lane + 64 * t;
+                    if (u < units) ((uint4*)data)[u] = make_uint4(__brev(buf[t].w), __brev(buf[t].z), __brev(buf[t].y), __brev(buf[t].x));
                 }
             }
-#pragma unroll
-            for (u32 t = 0; t < MAXU; ++t) {
-                const u32 u = lane + 64 * t;
-                if (u < units) ((uint4*)data)[u] = make_uint4(__brev(buf[t].w), __brev(buf[t].z), __brev(buf[t].y), __brev(buf[t].x));
+            __syncthreads();
+            HST({ const unsigned long long tB = __builtin_readcyclecounter(); tStage += tB - tA; tA = tB; })
+            // cursors below are local to the piece's array: local = global - 32 * mTop
+            const u32 C0 = Cstart - 32u * mTop;                          // exact: the stream's first code bit, or where the piece before ended
+            const u32 CendL = (lastPiece ? Cend : 32u * (mTop + nd)) - 32u * mTop;
+            const u32 Tp = CendL - C0;                                   // bits of this piece
+            const u32 stepA = (Tp + 63u) / 64u;
+            const u32 aLo = lane * stepA < Tp ? lane * stepA : Tp;
+            const u32 aHi = (lane + 1) * stepA < Tp ? (lane + 1) * stepA : Tp;
+            const u32 cLo = C0 + aLo, cHi = C0 + aHi;
+            // ---- pass 1: warm up to my start, then my range
+            u32 S = C0;
+            if (lane > 0) { u32 C = aLo > warm ? cLo - warm : C0; (void)hpar_run(arr, C, cLo, tabOff, mask2); S = C; }
+            u32 E = S;
+            u32 n = hpar_run(arr, E, cHi, tabOff, mask2);
+            HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
+            // ---- verify / repair.  A code that never falls into step (say 256 equal weights: every code 8 bits, a lane dropped off the
+            //      byte grid stays off it) gains one exact lane per round -- the serial walk at the price of a wave.  Real data needs
+            //      0..2 rounds; beyond HPAR_MAX_REPAIR the block is the serial decoder's (crafted input cannot pin a wave to a block).
+            for (u32 round = 0;; ++round) {
+                const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
+                const bool bad = lane > 0 && S != prevE;
+                if (!__any(bad)) break;
+                if (round == HPAR_MAX_REPAIR) { good = false; break; }              // uniform
+                HST(++stRounds; stBad += __builtin_popcountll(__ballot(bad));)
+                if (bad) { S = prevE; E = S; n = hpar_run(arr, E, cHi, tabOff, mask2); }
             }
-        }
-        __syncthreads();
-        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tStage += tB - tA; tA = tB; })
-        const u32 C0 = 32u * Sd - T0[q];                                 // cursor of the first code bit (bits above it: padding, end mark)
-        const u32 want = q < 3 ? seg : (u32)dstSize - 3 * seg;
-        const u32 stepA = (T0[q] + 63u) / 64u;
-        const u32 aLo = lane * stepA < T0[q] ? lane * stepA : T0[q];
-        const u32 aHi = (lane + 1) * stepA < T0[q] ? (lane + 1) * stepA : T0[q];
-        const u32 cLo = C0 + aLo, cHi = C0 + aHi;
-        // ---- pass 1: warm up to my start, then my range
-        u32 S = C0;
-        const u32 warm = T0[q] > 6u * want ? HPAR_WARM + HPAR_WARM / 2 : HPAR_WARM;   // long codes resynchronise later (measured on 8-bit data: 128 -> 192 bits saves 4 %)
-        if (lane > 0) { u32 C = aLo > warm ? cLo - warm : C0; (void)hpar_run(arr, C, cLo, tabOff, mask2); S = C; }
-        u32 E = S;
-        u32 n = hpar_run(arr, E, cHi, tabOff, mask2);
-        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
-        // ---- verify / repair.  A code that never falls into step (say 256 equal weights: every code 8 bits, a lane dropped off the
-        //      byte grid stays off it) gains one exact lane per round -- the serial walk at the price of a wave.  Real data needs
-        //      0..2 rounds; beyond HPAR_MAX_REPAIR the block is the serial decoder's (crafted input cannot pin a wave to a block).
-        for (u32 round = 0;; ++round) {
-            const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
-            const bool bad = lane > 0 && S != prevE;
-            if (!__any(bad)) break;
-            if (round == HPAR_MAX_REPAIR) { good = false; break; }              // uniform
-            HST(++stRounds; stBad += __builtin_popcountll(__ballot(bad));)
-            if (bad) { S = prevE; E = S; n = hpar_run(arr, E, cHi, tabOff, mask2); }
+            if (!good) break;
+            HST({ const unsigned long long tB = __builtin_readcyclecounter(); tRep += tB - tA; tA = tB; })
+            // ---- verdict for this piece
+            u32 incl = n;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
+            const u32 total = (u32)__shfl((int)incl, 63, WAVE), endC = (u32)__shfl((int)E, 63, WAVE);
+            // the last piece must regenerate exactly what is left of the segment and end exactly on the stream's first bit; a piece before
+            // it must leave symbols to regenerate
+            if (lastPiece ? (outBase + total != want || endC != CendL) : (outBase + total >= want)) { good = false; break; }   // uniform: not a stream the reference accepts as is
+            // ---- pass 2: my symbols again, stored sixteen at a time
+            {   u8* p = out + (size_t)q * seg + outBase + (incl - n);
+                u32 left = n, C = S;
+                while (left && ((uintptr_t)p & 3u)) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
+                if (left >= 16) {
+                    HparBulk bk; bk.open(arr, C);
+                    do {
+                        u32 w[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) w[t] = bk.iter(tabOff, mask2);
+                        __builtin_memcpy(p, w, 16);
+                        p += 16; left -= 16;
+                    } while (left >= 16);
+                    while (left >= 4) { const u32 w = bk.iter(tabOff, mask2); __builtin_memcpy(p, &w, 4); p += 4; left -= 4; }
+                    C = bk.cursor();
+                }
+                while (left) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
+            }
+            outBase += total;
+            Cstart = endC + 32u * mTop;
+            HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP2 += tB - tA; tA = tB; })
         }
         if (!good) break;
-        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tRep += tB - tA; tA = tB; })
-        // ---- verdict for this stream
-        u32 incl = n;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
-        const u32 total = (u32)__shfl((int)incl, 63, WAVE), endC = (u32)__shfl((int)E, 63, WAVE);
-        if (total != want || endC != C0 + T0[q]) { good = false; break; }   // uniform: not a stream the reference accepts as is
-        // ---- pass 2: my symbols again, stored sixteen at a time
-        {   u8* p = out + (size_t)q * seg + (incl - n);
-            u32 left = n, C = S;
-            while (left && ((uintptr_t)p & 3u)) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
-            if (left >= 16) {
-                HparBulk bk; bk.open(arr, C);
-                do {
-                    u32 w[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) w[t] = bk.iter(tabOff, mask2);
-                    __builtin_memcpy(p, w, 16);
-                    p += 16; left -= 16;
-                } while (left >= 16);
-                while (left >= 4) { const u32 w = bk.iter(tabOff, mask2); __builtin_memcpy(p, &w, 4); p += 4; left -= 4; }
-                C = bk.cursor();
-            }
-            while (left) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
-        }
         sp += L;
-        HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP2 += tB - tA; tA = tB; })
     }
     HST(if (lane == 0 && slot < 4096) { unsigned long long* t = g_hparStats + 8 * slot; t[0] = stRounds; t[1] = stBad; t[2] = tStage; t[3] = tP1; t[4] = tRep; t[5] = tP2; })
     if (!good) { decline(); return; }

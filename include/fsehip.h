@@ -100,6 +100,10 @@ FSEHIP_API size_t FSEHIP_HUF_compress4X_usingCTable(void* dst, size_t dstSize, c
  * HUF_decompress4X1_usingDTable rejects an X2 table with GENERIC exactly as the reference does (lib/huf_decompress.c:411-412). */
 FSEHIP_API size_t FSEHIP_HUF_decompress4X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
 FSEHIP_API size_t FSEHIP_HUF_decompress4X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
+/* lib/huf.h:318-320: single-stream blocks, what HUF_compress1X_usingCTable writes (lib/huf_decompress.c:239-260, 961-975).  The 1X1 form
+ * rejects a double-symbol table with GENERIC (:367-369), the 1X form takes both table types like its 4X sibling. */
+FSEHIP_API size_t FSEHIP_HUF_decompress1X_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
+FSEHIP_API size_t FSEHIP_HUF_decompress1X1_usingDTable(void* dst, size_t maxDstSize, const void* cSrc, size_t cSrcSize, const FSEHIP_HUF_DTable* DTable);
 /* lib/huf.h:66, :95, :82 */
 FSEHIP_API size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 FSEHIP_API size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);
@@ -180,6 +184,16 @@ FSEHIP_API int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t ds
  * reference's HUF_readDTableX2: 4 bytes per cell, 1 + (1 << tableLog) words) an acceptance path with the reference's lock-step
  * semantics.  The 4X1 call above rejects tableType 1 with GENERIC exactly like HUF_decompress4X1_usingDTable. */
 FSEHIP_API int FSEHIP_HUF_decompress4X_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                         size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                         const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                         size_t nBlocks, void* stream);
+/* HUF_decompress1X1_usingDTable / HUF_decompress1X_usingDTable over a batch: one stream per block (the inverse of FSEHIP_HUF_compress1X_usingCTable_batch).
+ * The stream is split across the 64 lanes of a wave like the streams of the 4X layout, in pieces when it exceeds the LDS budget. */
+FSEHIP_API int FSEHIP_HUF_decompress1X1_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
+                                                          size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
+                                                          const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
+                                                          size_t nBlocks, void* stream);
+FSEHIP_API int FSEHIP_HUF_decompress1X_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
                                                          size_t* d_results, const void* d_cSrc, size_t cStride, const size_t* d_cSizes, size_t uniformCSize,
                                                          const FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog,
                                                          size_t nBlocks, void* stream);
@@ -349,6 +363,8 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define HUF_compress4X_usingCTable FSEHIP_HUF_compress4X_usingCTable
 #define HUF_decompress4X_usingDTable FSEHIP_HUF_decompress4X_usingDTable
 #define HUF_decompress4X1_usingDTable FSEHIP_HUF_decompress4X1_usingDTable
+#define HUF_decompress1X_usingDTable FSEHIP_HUF_decompress1X_usingDTable
+#define HUF_decompress1X1_usingDTable FSEHIP_HUF_decompress1X1_usingDTable
 #endif
 #ifdef FSEHIP_DROPIN_U16_NAMES       /* separate switch: programs/fuzzer.c declares FSE_countU16 with another (stale) prototype */
 #define FSE_countU16 FSEHIP_FSE_countU16

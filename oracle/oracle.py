@@ -363,6 +363,16 @@ class Ref(_Base):
         assert (out[dst_size:] == 0xA5).all()
         return int(r), out[:dst_size]
 
+    def huf_decompress1x_using_dtable(self, csrc, dt, dst_size):
+        """HUF_decompress1X_usingDTable: one stream, dispatches on the table type (lib/huf_decompress.c:961-975)"""
+        csrc, ps = _u8(csrc)
+        dt = np.ascontiguousarray(dt, dtype=np.uint32)
+        out = np.zeros(max(dst_size, 1) + 16, dtype=np.uint8)
+        out[dst_size:] = 0xA5
+        r = self._call("HUF_decompress1X_usingDTable", self.sz, out.ctypes.data_as(self.vp), self.sz(dst_size), ps, self.sz(csrc.size), dt.ctypes.data_as(self.vp))
+        assert (out[dst_size:] == 0xA5).all()
+        return int(r), out[:dst_size]
+
     # FSE for 16-bit symbols (lib/fseU16.c): only the compiled reference has it (a side path: SURVEY 8(f) rank 4)
     def fse_count_u16(self, src, max_sv=286):
         src = np.ascontiguousarray(src, dtype=np.uint16)

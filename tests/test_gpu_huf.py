@@ -493,3 +493,94 @@ def test_huf_x1_damaged_tables(hip, ref):
             assert rg == r, (size, i, rg, r)
             if not is_error(r):
                 assert (og[:r] == exp[:r]).all(), (size, i)
+
+
+@pytest.mark.parametrize("size", [1, 8, 100, 1001, 4097, 32767, 32768, 65536, 131072])
+def test_huf_1x_decode_using_dtable(hip, ref, size):
+    """HUF_decompress1X1_usingDTable / HUF_decompress1X_usingDTable (lib/huf.h:318-320, lib/huf_decompress.c:239-260,724-747,961-975) over a
+    batch and on host pointers: single-stream blocks written by HUF_compress1X_usingCTable, single- and double-symbol tables, several
+    destination sizes, truncated and corrupted streams -- results and bytes against the compiled reference.  Streams of 32 KB blocks
+    exceed the stream-parallel decoder's LDS budget and are decoded in pieces."""
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    rng = np.random.default_rng(size)
+    W = 1 + (1 << 12)
+    blocks, t1, t2, streams = [], [], [], []
+    for i, P in enumerate((14, 2, 80, 50, 20, 14, 2, 80, 14, 5)):
+        blk = orc.probagen_batch(P, 1, max(size, 64), 500 + i)[0][:size] if size >= 1 else np.zeros(0, np.uint8)
+        big = orc.probagen_batch(P, 1, 32768, 500 + i)[0]              # the table comes from a full block of the distribution
+        cs, c = ref.huf_compress2(big)
+        assert cs > 1
+        h, x1 = ref.huf_read_dtable_x1(c[:cs], 11)
+        h2, x2 = ref.huf_read_dtable_x2(c[:cs])
+        assert not is_error(h) and not is_error(h2)
+        # the matching code table, to write the stream with the reference's HUF_compress1X_usingCTable
+        mx, msv, cnt = ref.hist_count(big)
+        hl = ref.fse_optimal_tablelog(11, 32768, msv, 1)
+        mb, celt = ref.huf_build_ctable(cnt, msv, hl)
+        if int(blk.max(initial=0)) > msv:
+            continue
+        r, out = ref.huf_compress1x_using_ctable(blk, celt)
+        if r == 0:
+            continue
+        blocks.append(blk); streams.append(out[:r].copy())
+        t1.append(np.pad(x1, (0, max(W - len(x1), 0)))[:W].copy()); t2.append(np.pad(x2, (0, max(W - len(x2), 0)))[:W].copy())
+    if not blocks:
+        pytest.skip("nothing compressible at this size")
+    n = len(blocks)
+    cbuf = np.zeros((n, max(len(s) for s in streams) + 8), np.uint8); csz = np.zeros(n, np.int64)
+    for i, s in enumerate(streams):
+        cbuf[i, :len(s)] = s; csz[i] = len(s)
+    d_c = torch.from_numpy(cbuf).cuda(); d_sz = torch.from_numpy(csz).cuda()
+    for tabs, kind in ((t1, "x1"), (t2, "x2")):
+        d_dt = torch.from_numpy(np.stack(tabs).view(np.int32)).cuda()
+        for dst_size in sorted({size, max(size - 1, 1), size + 3}):
+            for fn_name in ("huf_decompress1x1_using_dtable_batch", "huf_decompress1x_using_dtable_batch"):
+                out, res = getattr(hip, fn_name)(d_c, d_sz, d_dt, dst_size)
+                out, res = out.cpu().numpy(), res.cpu().numpy()
+                for i in range(n):
+                    if kind == "x2" and "1x1" in fn_name:
+                        assert res[i] == -1, (size, i, res[i]); continue         # lib/huf_decompress.c:367-369
+                    r, exp = ref.huf_decompress1x_using_dtable(streams[i], tabs[i], dst_size)
+                    assert res[i] == s64(r), (size, kind, dst_size, fn_name, i, res[i], r)
+                    if not is_error(r):
+                        assert (out[i][:r] == exp[:r]).all(), (size, kind, dst_size, i)
+                        if dst_size == size:
+                            assert (out[i][:size] == blocks[i]).all()
+        # damaged streams through the single-block calls
+        for trial in range(9):
+            i = trial % n
+            bad = streams[i].copy()
+            if len(bad) < 3:
+                continue
+            if trial % 3 == 0:
+                bad = bad[:max(1, len(bad) - int(rng.integers(1, 20)))]
+            elif trial % 3 == 1:
+                pos = rng.integers(0, len(bad), 3); bad[pos] ^= rng.integers(1, 256, 3).astype(np.uint8)
+            else:
+                bad[-1] = 0
+            r, exp = ref.huf_decompress1x_using_dtable(bad, tabs[i], size)
+            rg, og = hip.huf_decompress1x_using_dtable(bad, tabs[i], size)
+            assert rg == r, (size, kind, trial, rg, r)
+            if not is_error(r):
+                assert (og[:r] == exp[:r]).all(), (size, kind, trial)
+
+
+def test_huf_1x_roundtrip_on_the_device_full_size(hip, oracle):
+    """the library reads what its own 1X encoder writes: 2,000 x 32 KB blocks, tables built on the device, HUF_compress1X_usingCTable_batch ->
+    HUF_decompress1X1_usingDTable_batch; and 64 KB / 128 KB blocks through the 4-stream calls (streams beyond the LDS budget: pieces)"""
+    src = hip.probagen_mixed((2, 14, 80), 2000)
+    ct, hdr, hres = hip.huf_build_ctable_batch(src)
+    dt, dres = hip.huf_read_dtable_x1_batch(hdr, hres, max_table_log=11)
+    assert bool((hres > 1).all()) and bool((dres == hres).all())
+    comp, cres = hip.huf_compress1x_using_ctable_batch(src, ct)
+    assert bool((cres > 0).all())
+    out, res = hip.huf_decompress1x1_using_dtable_batch(comp, cres, dt, 32768, max_table_log=11)
+    assert bool((res == 32768).all()) and torch.equal(out, src)
+    for size in (65536, 131072):
+        big = hip.probagen_mixed((14, 80, 2), 96, block_size=size)
+        c4, r4 = hip.huf_compress_batch(big)
+        o4, q4 = hip.huf_decompress_batch(c4, r4, size)
+        assert bool((q4 == size).all()) and torch.equal(o4, big), size
+        _, ores, odst = oracle.compress_batch(1, big.cpu().numpy()[:8])
+        assert (r4.cpu().numpy()[:8] == ores.astype(np.int64)).all()
