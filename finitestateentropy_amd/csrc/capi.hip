@@ -735,7 +735,7 @@ extern "C" size_t FSEHIP_FSE_decompress_usingDTable(void* dst, size_t dstCapacit
     HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
     HK(hipMemcpy(ddt.p, dt, words * 4, hipMemcpyHostToDevice));
     HK((hipError_t)FSEHIP_FSE_decompress_usingDTable_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
-                                                           (const unsigned*)ddt.p, 0, FSEHIP_FSE_MAX_TABLELOG, 1, nullptr));
+                                                           (const unsigned*)ddt.p, 0, tl ? tl : 1, 1, nullptr));   // (the table's own log: one launch, its class)
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
