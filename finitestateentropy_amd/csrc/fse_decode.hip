@@ -790,6 +790,79 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // Everything between two phases is paid by all chains of the wave (a wave issues an instruction per ~8 cycles whatever it
     // does), so the round is kept short: one LDS load, one LDS store, 32-bit counters, one wave vote.
     int grp = groups > (1 << 30) ? (1 << 30) : (int)groups;                 // groups of four output bytes that fit (beyond 2^30: the literal path goes on)
+    if constexpr (FAST) {
+        // ---- the bit-reversed loop's rounds, WAVE-UNIFORM control flow.  With a divergent `if (ready) { phase }` the compiler merges every
+        //      loop-carried register of the round through copies on both sides of the branch and juggles exec masks around it: 75
+        //      instructions between two phases, 19 of them v_mov (620 of a round's 4190 cycles; a lone wave issues an instruction per ~8).
+        //      Here ALL lanes run every phase: a lane whose block cannot take one (finished, or no block at all) decodes on as a "zombie"
+        //      -- its table and ring addresses stay inside its own LDS slot whatever bits it reads (the address arithmetic of
+        //      fse_bulk_phase_rev), its records go to a dummy ring -- and its real state is kept by selects.  A lane that has to wait for
+        //      its service wave (ring full / input not there yet) makes the wave poll instead of sitting a round out: the lagging chain
+        //      sets the pace either way, but it no longer costs the others a whole extra round at the end.
+        uint2* const dummyRing = (uint2*)(flagsSh + 32) + half;          // 128 bytes behind the flag words: a phase's records of the zombies
+        // (the lanes beyond the wave's lane pairs never have a block: they stay out altogether -- one branch for the whole bulk, so that the
+        //  LDS instructions of a phase serve 34 lanes, not 64)
+        if ((lane >> 1) < ppw) {
+        for (;;) {
+            // room for 16 more records, and the lowest byte this phase can read is in the ring: its last iteration starts at most
+            // 15 * 48 bits further down (23 dwords) and reads the three dwords from there -> 92 bytes below q.  Nothing below the
+            // stream start is ever consumed: once the ring reaches down to it (validLo <= 0) the phase may run.
+            const int lowest = (int)bs.q - 4 * ((48 * (FSE_CHECK_EVERY - 1) + 31) / 32);
+            const int need = lowest > 0 ? lowest : 0;
+            bool rdy;
+            do {                                                                 // uniform: poll until every chain of the wave may run
+                const u32 fl = (u32)srvNext;
+                const int vlo = (int)(u32)(srvNext >> 32);
+                srvNext = ctl_peek2(&ctl->srvFlushed);
+                rdy = !can | ((iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) & (need >= vlo));
+                TIMING(if (!__all(rdy)) { const unsigned long long tB = __builtin_readcyclecounter(); tWait += tB - tA; ++nWait; tA = tB; });
+            } while (!__all(rdy));
+            if (!__any(can)) break;                                              // uniform
+            uint2* const ring = can ? myRing + rpos : dummyRing;
+            u32 sN = bs.s, Pn = P, PhN = Phead;
+            unsigned long long tI = 0; (void)tI;
+            TIMING(tI = __builtin_readcyclecounter(););
+            fse_bulk_phase_rev<FSE_CHECK_EVERY>(sN, Pn, PhN, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+            TIMING(tInner += __builtin_readcyclecounter() - tI;);
+            bs.s = can ? sN : bs.s; P = can ? Pn : P; Phead = can ? PhN : Phead;
+            const u32 adv = can ? (u32)FSE_CHECK_EVERY : 0u;
+            rpos = (rpos + adv) & (FSE_DEC_RING - 1);
+            iters += adv; grp -= (int)adv;
+            const u32 B = R8 - P;
+            bs.q = 4u * (B >> 5) - 8u;
+            const u32 Bp = B - inA8;                                          // unread bits of the payload proper
+            const bool canN = can & (Bp >= 65u + 48u * (FSE_CHECK_EVERY - 1)) & (grp >= FSE_CHECK_EVERY);
+            const bool more = canN | ((Bp >= 65u + 48u * (FSE_FINISH_EVERY - 1)) & (grp >= FSE_FINISH_EVERY));     // finishing phases to come
+            if (can & (half == 0)) ctl_store2(&ctl->pubIters, iters, more ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+            can = canN;
+            TIMING(const unsigned long long tB = __builtin_readcyclecounter(); tRun += tB - tA; ++nRun; tA = tB;);
+        }
+        {   const u32 B = R8 - P; bs.bq = B & 31u;
+            can2 = bulkOk & (B - inA8 >= 65u + 48u * (FSE_FINISH_EVERY - 1)) & (grp >= FSE_FINISH_EVERY); }
+        can2 = can2 & bulkOk;
+        for (;;) {                                   // ---- finishing phases of FSE_FINISH_EVERY iterations (every lane is through with the long ones)
+            const u32 fl = (u32)srvNext;
+            const int vlo = (int)(u32)(srvNext >> 32);
+            srvNext = ctl_peek2(&ctl->srvFlushed);
+            const int lowest = (int)bs.q - 8;                                    // the second iteration's window starts at most two dwords further down
+            const bool rdy = !can2 | ((iters + FSE_FINISH_EVERY - fl <= FSE_DEC_RING) & ((lowest > 0 ? lowest : 0) >= vlo));
+            if (!__all(rdy)) { TIMING(const unsigned long long tB = __builtin_readcyclecounter(); tWait += tB - tA; ++nWait; tA = tB;); continue; }
+            if (!__any(can2)) break;
+            uint2* const ring = can2 ? myRing + rpos : dummyRing;
+            u32 sN = bs.s, Pn = P, PhN = Phead;
+            fse_bulk_phase_rev<FSE_FINISH_EVERY>(sN, Pn, PhN, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+            bs.s = can2 ? sN : bs.s; P = can2 ? Pn : P; Phead = can2 ? PhN : Phead;
+            rpos = can2 ? (rpos + FSE_FINISH_EVERY) & (FSE_DEC_RING - 1) : rpos;
+            iters += can2 ? FSE_FINISH_EVERY : 0u; grp -= can2 ? FSE_FINISH_EVERY : 0;
+            const u32 B = R8 - P;
+            bs.q = 4u * (B >> 5) - 8u; bs.bq = B & 31u;
+            const bool can2N = can2 & (B - inA8 >= 65u + 48u * (FSE_FINISH_EVERY - 1)) & (grp >= FSE_FINISH_EVERY);
+            if (can2 & (half == 0)) ctl_store2(&ctl->pubIters, iters, can2N ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
+            can2 = can2N;
+            TIMING(const unsigned long long tB = __builtin_readcyclecounter(); tFin += tB - tA; ++nFin; tA = tB;);
+        }
+        }
+    } else {
     while (__any(can)) {                             // ---- phases of FSE_CHECK_EVERY iterations
         const u32 fl = (u32)srvNext;
         const int vlo = (int)(u32)(srvNext >> 32);
@@ -827,7 +900,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         }
         TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tRun += tB - tA; ++nRun; } else { tWait += tB - tA; ++nWait; } tA = tB;);
     }
-    if (FAST) while (__any(can2)) {                  // ---- finishing phases of FSE_FINISH_EVERY iterations (every lane is through with the long ones)
+    if (false) while (__any(can2)) {                  // ---- finishing phases of FSE_FINISH_EVERY iterations (every lane is through with the long ones)
         const u32 fl = (u32)srvNext;
         const int vlo = (int)(u32)(srvNext >> 32);
         srvNext = ctl_peek2(&ctl->srvFlushed);
@@ -844,6 +917,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             if (half == 0) ctl_store2(&ctl->pubIters, iters, can2 ? bs.q + 8u : ((bs.q + 8u) | 0x80000000u));
         }
         TIMING(const unsigned long long tB = __builtin_readcyclecounter(); if (__any(ready)) { tFin += tB - tA; ++nFin; } else { tWait += tB - tA; ++nWait; } tA = tB;);
+    }
     }
     TIMING(if (lane == 0) { atomicAdd(&g_decTiming[0], tRun); atomicAdd(&g_decTiming[1], tWait); atomicAdd(&g_decTiming[2], nRun); atomicAdd(&g_decTiming[3], nWait); atomicAdd(&g_decTiming[4], 1ull);
                             atomicAdd(&g_decTiming[13], tBulk0 - tBorn); atomicAdd(&g_decTiming[15], tFin); atomicAdd(&g_decTiming[10], nFin); atomicAdd(&g_decTiming[7], tInner); });
@@ -883,7 +957,7 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
 static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)
 {
     *slotU32 = (FSE_DEC_RING * 8 + FSE_IN_RING + FSE_IN_MIRROR + 16) / 4;  // rings (16-byte multiples: records are written in pairs)
-    int g = (int)((ldsBytes - 96) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (96 bytes: the flag words and the caller tables' logs)
+    int g = (int)((ldsBytes - 256) / ((2u << ldsLog) + *slotU32 * 4 + sizeof(DecCtl)));   // (256 bytes: the flag words, the caller tables' logs, the zombies' dummy ring)
     if (g > FSE_MAXG) g = FSE_MAXG;
     *G = g;
 }
