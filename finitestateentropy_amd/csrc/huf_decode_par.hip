@@ -44,6 +44,9 @@
 
 typedef const __attribute__((address_space(3))) u16* hpar_lds_u16;
 typedef const __attribute__((address_space(3))) u32* hpar_lds_u32;
+// (A/B, round 4: the cell through an aligned 8-byte read -- 64 LDS banks instead of the 32 that 2- and 4-byte reads use -- and a 64-bit
+//  shift: 3.42 instead of 3.20 ms per 100k P14 blocks in the same run, 5.29 instead of 4.87 on P02: the two extra dependent operations
+//  per symbol cost more than the conflicts they avoid.  Not kept.)
 DEV u32 hpar_cell(u32 win, u32 mask2, u32 tabOff) { return *(hpar_lds_u16)(uintptr_t)((win & mask2) | tabOff); }
 
 // one symbol at cursor C (consumed bits); returns the cell (nbBits | byte << 8)
