@@ -750,11 +750,11 @@ def main():
     configs = {}
     if not args.no_configs:
 
-        def case(key, proba, names, n, first_block, table_log=args.table_log, max_log=args.max_log, desc="", total=None, n_check=None):
+        def case(key, proba, names, n, first_block, table_log=args.table_log, max_log=args.max_log, desc="", total=None, n_check=None, traffic_tag=None):
             s = gen(proba, n, first_block)
             cds = [Codec(hip, nm, s, pools, table_log, max_log) for nm in names]
             rr = run_case(hip, cds, cs, cw, barrier, rank, n_check=args.parity_blocks if n_check is None else n_check)
-            rec, _ = summarize(rr, cds, n, cs, world, reduce_max, total_blocks=total)
+            rec, _ = summarize(rr, cds, n, cs, world, reduce_max, total_blocks=total, traffic_tag=traffic_tag)
             rec["workload"] = desc
             configs[key] = rec
             return s, cds
@@ -763,9 +763,9 @@ def main():
             case("fse_maxlog11", args.proba, ("fse",), nb, rank * nb, max_log=max(args.table_log, 9),
                  desc="headline workload decoded with FSE_decompress_wksp(maxLog = 11) (caller promises tableLog <= 11)")
         if want("cfg3_p80_fse"):
-            case("cfg3_p80_fse", 80, ("fse",), nb, rank * nb, desc="BASELINE configs[2]: probagen Proba80, %d x 32KB blocks per GPU, FSE encode+decode" % nb)
+            case("cfg3_p80_fse", 80, ("fse",), nb, rank * nb, traffic_tag="_p80", desc="BASELINE configs[2]: probagen Proba80, %d x 32KB blocks per GPU, FSE encode+decode" % nb)
         if want("cfg4_p14_huf"):
-            case("cfg4_p14_huf", 14, ("huf",), nb, rank * nb, desc="BASELINE configs[3]: probagen Proba14, %d x 32KB blocks per GPU, Huff0 4-stream encode + HUF_decompress" % nb)
+            case("cfg4_p14_huf", 14, ("huf",), nb, rank * nb, traffic_tag="", desc="BASELINE configs[3]: probagen Proba14, %d x 32KB blocks per GPU, Huff0 4-stream encode + HUF_decompress" % nb)
         if want("fse_tl12"):
             case("fse_tl12", 14, ("fse",), nb, rank * nb, table_log=12, desc="Proba14, FSE with tableLog 12 (what `fse -b` requests, programs/bench.c:113)")
         if want("huf_tl12"):

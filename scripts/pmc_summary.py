@@ -1,6 +1,6 @@
 """Turn rocprofv3 outputs (gpurun_out/<run>/{trace,pmc_fetch,pmc_write}) into the committed summaries under profiles/.
 
-usage: python scripts/pmc_summary.py gpurun_out/r1 r01 <blocks_in_pmc_run>
+usage: python scripts/pmc_summary.py gpurun_out/r1 r01 <blocks_in_pmc_run> [traffic-file suffix, e.g. _p80]
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc.md and
 profiles/traffic_<kernel>.json (HBM bytes per block, read by bench.py for roofline.traffic).
 
@@ -36,6 +36,7 @@ def agg(path, counter=None):
 
 def main():
     run, tag, nblocks = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    suffix = sys.argv[4] if len(sys.argv) > 4 else ""             # traffic_<kernel><suffix>.json: records of a configuration other than the headline's
     os.makedirs("profiles", exist_ok=True)
     shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
     fetch = agg(os.path.join(run, "pmc_fetch", "bench_counter_collection.csv"))
@@ -90,7 +91,7 @@ def main():
                "fetch_KiB_raw_total": f[1], "write_KiB_total": w[1], "blocks": nblocks, "passes": passes, "source": tag}
         if rb is not None:
             rec["request_size_bytes_per_block"] = {"read": round(rb / (nblocks * passes), 1), "write": round(wb / (nblocks * passes), 1)}
-        json.dump(rec, open("profiles/traffic_%s.json" % k, "w"))
+        json.dump(rec, open("profiles/traffic_%s%s.json" % (k, suffix), "w"))
     # kernel-trace run (scripts/profile.sh: bench.py --steps 5 --warmup 2 = 7 passes): durations per pass, the figure bench.py's
     # kernel_ms_per_step / roofline.avg_launch_ms report from HIP events.  A kernel that is launched once per decoder class shows
     # more calls than passes in rocprofv3's table -- the launches over classes without blocks return at once (a few microseconds)

@@ -26,4 +26,20 @@ for codec in fse huf; do
     timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq2 -o bench -- $B $P > $O/sq2.log 2>&1
     tail -1 $O/trace.log | cut -c1-300
 done
-find $R/gpurun_out/${RUN}_fse $R/gpurun_out/${RUN}_huf -name "*.csv" | head -40
+# BASELINE config 3 (Proba80, FSE): kernel trace + HBM traffic passes;  16-bit symbols and the using-table calls: kernel traces (their
+# kernels run beside the headline's in one bench run; the rows are told apart by kernel name / call count)
+O=$R/gpurun_out/${RUN}_p80
+mkdir -p $O
+B="python $R/bench.py --codec fse --proba 80 --no-configs --plain"
+P="--steps 2 --warmup 1 --blocks 20000"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $B --steps 5 --warmup 2 > $O/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B $P > $O/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/pmc_rd -o bench -- $B $P > $O/rd.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O/pmc_wr -o bench -- $B $P > $O/wr.log 2>&1
+for extra in fse_u16 using_tables; do
+    O=$R/gpurun_out/${RUN}_$extra
+    mkdir -p $O
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --codec fse --configs $extra --plain --steps 5 --warmup 2 > $O/trace.log 2>&1
+done
+find $R/gpurun_out/${RUN}_fse $R/gpurun_out/${RUN}_huf $R/gpurun_out/${RUN}_p80 -name "*.csv" | head -60
