@@ -8,6 +8,7 @@ from finitestateentropy_amd.api import FseHip
 from oracle.oracle import Checker as Oracle
 from test_gpu_fse import _random_blocks, s64, is_error
 
+FseHip.guard = 64 + 3 * (int(sys.argv[2]) % 2 if len(sys.argv) > 2 else 0)      # guard gaps behind every destination (tests/conftest.py), odd on odd first seeds
 hip = FseHip()
 oracle = Oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -22,12 +23,16 @@ while time.time() - t0 < budget:
     tl = int(rng.choice([5, 6, 7, 8, 9, 10, 11, 11, 11, 12]))
     blocks = _random_blocks(rng, 48, size)
     src = torch.from_numpy(blocks).cuda()
-    dst, res = hip.fse_compress_batch(src, table_log=tl)
+    # maxSymbolValue: the default, generous limits, the batch's own largest byte (exact fit) and one below it (maxSymbolValue_tooSmall
+    # for the blocks that use it: lib/hist.c:128,169-170)
+    top = int(blocks.max())
+    msv = int(rng.choice([255, 255, 254, top, max(top - 1, 1), min(top + 1, 255), int(rng.integers(1, 256))]))
+    dst, res = hip.fse_compress_batch(src, table_log=tl, max_symbol_value=msv)
     dst, res = dst.cpu().numpy(), res.cpu().numpy()
-    _, ores, odst = oracle.compress_batch(0, blocks, table_log=tl)
+    _, ores, odst = oracle.compress_batch(0, blocks, table_log=tl, max_sv=msv)
     for b in range(len(blocks)):
         r = int(ores[b])
-        assert res[b] == s64(r), ("fse size", seed, size, tl, b, res[b], r)
+        assert res[b] == s64(r), ("fse size", seed, size, tl, msv, b, res[b], r)
         if not is_error(r) and r > 1:
             assert (dst[b][:r] == odst[b][:r]).all(), ("fse bytes", seed, size, tl, b)
     ok = np.array([(not is_error(int(r))) and int(r) > 1 for r in ores])
@@ -73,12 +78,13 @@ while time.time() - t0 < budget:
                 assert (outh[i][:r] == o[:r]).all(), ("fse damaged bytes", seed, size, tl, i)
     # Huff0 on the same blocks
     htl = int(rng.choice([11, 11, 12, 8, 6]))
-    hdst, hres = hip.huf_compress_batch(src, table_log=htl)
+    hmsv = int(rng.choice([255, 255, top, max(top - 1, 1), int(rng.integers(1, 256))]))
+    hdst, hres = hip.huf_compress_batch(src, table_log=htl, max_symbol_value=hmsv)
     hdst, hres = hdst.cpu().numpy(), hres.cpu().numpy()
-    _, ohres, ohdst = oracle.compress_batch(1, blocks, table_log=htl)
+    _, ohres, ohdst = oracle.compress_batch(1, blocks, table_log=htl, max_sv=hmsv)
     for b in range(len(blocks)):
         r = int(ohres[b])
-        assert hres[b] == s64(r), ("huf size", seed, size, htl, b, hres[b], r)
+        assert hres[b] == s64(r), ("huf size", seed, size, htl, hmsv, b, hres[b], r)
         if not is_error(r) and r > 1:
             assert (hdst[b][:r] == ohdst[b][:r]).all(), ("huf bytes", seed, size, htl, b)
     okh = np.array([(not is_error(int(r))) and int(r) > 1 and int(r) < size for r in ohres])
@@ -92,5 +98,25 @@ while time.time() - t0 < budget:
         assert (dres.cpu().numpy() == want).all(), ("huf dsize", seed, size, htl)
         good = want == size
         assert (out.cpu().numpy()[:, :size][good] == blocks[okh][good]).all(), ("huf dbytes", seed, size, htl)
+    # the using-table calls over tables built on the device, and the packed form, on the same blocks
+    ct, hdr, hres_t = hip.fse_build_ctable_batch(src, table_log=tl if tl >= 5 else 11)
+    built = (hres_t > 1).nonzero().flatten()
+    if built.numel():
+        sub = src[built].contiguous()
+        comp_t, cres_t = hip.fse_compress_using_ctable_batch(sub, ct[built].contiguous(), max_table_log=12)
+        dt, dres_t = hip.fse_build_dtable_batch(hdr[built].contiguous(), hres_t[built], max_log=12)
+        okt = ((cres_t > 0) & (dres_t > 1)).nonzero().flatten()
+        if okt.numel():
+            out_t, ores_t = hip.fse_decompress_using_dtable_batch(comp_t[okt].contiguous(), cres_t[okt].contiguous(), dt[okt].contiguous(), size, max_table_log=12)
+            oh, rh, ch, szh, dth = out_t.cpu().numpy(), ores_t.cpu().numpy(), comp_t[okt].cpu().numpy(), cres_t[okt].cpu().numpy(), dt[okt].cpu().numpy().view(np.uint32)
+            for i in range(0, len(rh), 5):
+                r, o = oracle.fse_decompress_using_dtable(ch[i][:szh[i]], dth[i], size)
+                assert rh[i] == s64(r), ("using dtable", seed, size, tl, i, rh[i], r)
+                if not is_error(r):
+                    assert (oh[i][:r] == o[:r]).all(), ("using dtable bytes", seed, size, tl, i)
+    slots_p, res_p = hip.fse_compress_batch(src, table_log=11)
+    packed, offsets = hip.compact_batch(slots_p, res_p, src)
+    out_p, dres_p = hip.fse_decompress_packed_batch(packed, offsets, size, size)
+    assert bool((dres_p == size).all()) and torch.equal(out_p, src), ("packed", seed, size)
     nblocks += len(blocks)
 print("soak ok: seeds %d..%d, %d blocks, %.0f s" % (seed0 + 1, seed, nblocks, time.time() - t0))
