@@ -305,7 +305,16 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
     dec = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(steps)) * 1e-3
     elapsed, enc, dec = reduce_max([elapsed, enc, dec])
     total = world * n_blocks * BLOCK * steps
-    return {"value": round(total / 2.0 ** 20 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "blocks_per_gpu": n_blocks,
+    pmc = {}
+    for k in ("k_u16_cprep", "k_u16_encode_wave", "k_u16_dprep", "k_u16_decode_lds"):          # the builder's PMC passes (scripts/profile.sh), a cross-reference
+        tp = os.path.join(ROOT, "profiles", "traffic_%s_u16run.json" % k)
+        if os.path.exists(tp):
+            try:
+                pmc[k] = json.load(open(tp)).get("hbm_bytes_per_block")
+            except Exception:
+                pass
+    return {"pmc_hbm_bytes_per_block": pmc or None,
+            "value": round(total / 2.0 ** 20 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "blocks_per_gpu": n_blocks,
             "encode_GBps": round(total / enc / 1e9, 2), "decode_GBps": round(total / dec / 1e9, 2),
             "compressed_bytes_per_block": round(float(cres.sum().item()) / n_blocks, 1), "parity": parity,
             "workload": "16-bit symbols (lib/fseU16.c): %d x 16384 symbols per GPU, 287-symbol alphabet (fuzzerU16's generator, p = 0.08), "
@@ -781,7 +790,7 @@ def main():
             configs["using_tables"] = ut
         if want("cfg5_mixed_shard"):
             n5 = args.cfg5_blocks
-            s5, cds5 = case("cfg5_mixed_shard", "mixed", ("fse", "huf"), n5, rank * n5, n_check=args.cfg5_parity_blocks,
+            s5, cds5 = case("cfg5_mixed_shard", "mixed", ("fse", "huf"), n5, rank * n5, n_check=args.cfg5_parity_blocks, traffic_tag="_mixed",
                             desc="BASELINE configs[4]'s mix at a fixed %d x 32KB blocks per GPU (%d in all): probagen mixed {P02,P14,P80} (block g: P[g mod 3], "
                                  "seed g+1), FSE and Huff0 round trip of every block, contiguous block ranges, no collective" % (n5, n5 * world))
             configs["cfg5_mixed_shard"]["scaling"] = "weak"
@@ -789,7 +798,7 @@ def main():
             del s5, cds5
         if want("cfg5_mixed_1M"):
             total = args.cfg5_total
-            s5, cds5 = case("cfg5_mixed_1M", "mixed", ("fse", "huf"), n5s, lo5, total=total, n_check=args.cfg5_parity_blocks,
+            s5, cds5 = case("cfg5_mixed_1M", "mixed", ("fse", "huf"), n5s, lo5, total=total, n_check=args.cfg5_parity_blocks, traffic_tag="_mixed",
                             desc="BASELINE configs[4] as named: probagen mixed {P02,P14,P80} (block g: P[g mod 3], seed g+1), %d x 32KB blocks in all, "
                                  "FSE and Huff0 round trip of every block, rank r codes shard_range(%d, r, %d) (this run: %d blocks per GPU); compute-only "
                                  "(each rank generates its shard, no collective)" % (total, total, world, n5s))

@@ -37,6 +37,20 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o be
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/pmc_rd -o bench -- $B $P > $O/rd.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O/pmc_wr -o bench -- $B $P > $O/wr.log 2>&1
+# BASELINE config 5's mix as the corpus (20k mixed P02 / P14 / P80 blocks through both codecs): HBM traffic of the mixed workload
+O=$R/gpurun_out/${RUN}_mixed
+mkdir -p $O
+B="python $R/bench.py --codec both --workload mixed --no-configs --plain"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B $P > $O/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $B --steps 5 --warmup 2 > $O/trace.log 2>&1
+# the 16-bit-symbol coder: its kernels (k_u16_*) beside the headline's in one run
+O=$R/gpurun_out/${RUN}_u16pmc
+mkdir -p $O
+B="python $R/bench.py --codec fse --configs fse_u16 --u16-blocks 20000 --plain"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B $P > $O/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $B --steps 5 --warmup 2 > $O/trace.log 2>&1
 for extra in fse_u16 using_tables; do
     O=$R/gpurun_out/${RUN}_$extra
     mkdir -p $O
