@@ -275,7 +275,11 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_encTiming(uns
 // Lanes per block.  A range must be long compared with the time two encoders need to merge (P14: ~90 symbols per chain,
 // so with 64 ranges of 512 symbols over half of the speculated starts fail and the repair rounds cost as much as the
 // counting pass); 32 lanes per block = two blocks per wave, ranges twice as long, half as many links to verify.
+// (Measured again in round 4 with the per-chain counting pass, -DWV_LANES=64u: twice the waves per CU, but 4.07 instead of 3.89 ms per
+// 100k P14 blocks.)
+#ifndef WV_LANES
 #define WV_LANES 32u
+#endif
 #define WV_BPW (64u / WV_LANES)      // blocks per wave
 template <bool TT4>
 __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArgs a, u32 slotWords, u32 tableWords)
