@@ -103,3 +103,45 @@ def test_u16_batched_calls_replay_from_a_hip_graph(hip):
         assert torch.equal(cres, er) and torch.equal(_valid(cdst, cres), _valid(ed, er)), seed
         assert bool((dres == nsym).all()) and torch.equal(out[:, :nsym], src), seed
         _ = src[:2].cpu()                                                     # (a host synchronisation between the replays)
+
+
+def test_using_table_and_packed_calls_replay_from_a_hip_graph(hip):
+    """the round-4 calls captured too: tables built on the device, the using-table hot loops (the caller-table FSE decoder claims a slot of the
+    library's symbol scratch per workgroup: allocated by the warm-up call, before the capture), compaction, the packed decoder"""
+    from finitestateentropy_amd.api import FseHip, fse_compress_bound
+    n, size = 96, 32768
+    old = FseHip.guard
+    FseHip.guard = 0                                      # (the guard's check synchronises: not inside a capture)
+    try:
+        src = hip.probagen_batch(14, n, size, first_seed=21).clone()
+        cap = fse_compress_bound(size)
+        comp = torch.empty((n, cap), dtype=torch.uint8, device="cuda"); cres = torch.empty(n, dtype=torch.int64, device="cuda")
+        out = torch.empty((n, size), dtype=torch.uint8, device="cuda"); ores = torch.empty(n, dtype=torch.int64, device="cuda")
+        out2 = torch.empty((n, size), dtype=torch.uint8, device="cuda"); ores2 = torch.empty(n, dtype=torch.int64, device="cuda")
+        packed = torch.empty(n * size, dtype=torch.uint8, device="cuda"); offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        dws = hip.fse_workspace(n, 12, True)
+
+        def work():
+            ct, hdr, hres = hip.fse_build_ctable_batch(src, table_log=11)
+            hip.fse_compress_using_ctable_batch(src, ct, max_table_log=11, dst=comp, results=cres)
+            dt, _ = hip.fse_build_dtable_batch(hdr, hres, max_log=11)
+            hip.fse_decompress_using_dtable_batch(comp, cres, dt, size, max_table_log=12, dst=out, results=ores)
+            hip.compact_batch(comp, cres, src, packed=packed, offsets=offsets)
+            return hdr, hres
+        work(); torch.cuda.synchronize()                  # warm-up outside the capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            hdr, hres = work()
+        for trial, (proba, seed) in enumerate(((14, 510), (80, 910), (2, 1310), (14, 77))):
+            src.copy_(hip.probagen_batch(proba, n, size, first_seed=seed))
+            comp.zero_(); out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            ok = cres > 0
+            assert bool((ores[ok] == size).all()) and torch.equal(out[ok], src[ok]), trial
+            ed, er = hip.fse_compress_batch(src, table_log=11)   # header || payload = the one-shot block
+            assert bool(((hres + cres == er) | ~ok | (er <= 1)).all()), trial
+            assert int(offsets[n].item()) == int(torch.where(cres > 1, cres, torch.where(cres == 0, torch.full_like(cres, size), cres)).sum().item()), trial
+            _ = src[:2].cpu()
+    finally:
+        FseHip.guard = old
