@@ -814,7 +814,7 @@ extern "C" int FSEHIP_HUF_decompress4X1_usingDTable_batch(void* d_dst, size_t ds
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
     a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
     a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
-    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.acceptX2 = 0; a.onlyDeclined = 0; a.nBlocks = nBlocks;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.acceptX2 = 0; a.onlyDeclined = 0; a.classLo = 0; a.nBlocks = nBlocks;
     return (int)launch_huf_decode(a, (hipStream_t)stream);
 }
 
@@ -829,7 +829,7 @@ extern "C" int FSEHIP_HUF_decompress4X_usingDTable_batch(void* d_dst, size_t dst
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
     a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
     a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
-    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.acceptX2 = 1; a.onlyDeclined = 0; a.nBlocks = nBlocks;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 4; a.acceptX2 = 1; a.onlyDeclined = 0; a.classLo = 0; a.nBlocks = nBlocks;
     return (int)launch_huf_decode(a, (hipStream_t)stream);
 }
 
@@ -844,7 +844,7 @@ static int huf_1x_dtable_batch(int acceptX2, void* d_dst, size_t dstStride, cons
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.dstSizes = mkview(nullptr, 0, d_dstSizes, uniformDstSize);
     a.results = d_results; a.csrc = mkview(d_cSrc, cStride, d_cSizes, uniformCSize);
     a.dtables = d_dtables; a.dtStrideU32 = dtableStrideU32; a.meta = nullptr;
-    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 1; a.acceptX2 = acceptX2; a.onlyDeclined = 0; a.nBlocks = nBlocks;
+    a.maxTableLog = maxTableLog; a.G = 0; a.slotU32 = 0; a.streams = 1; a.acceptX2 = acceptX2; a.onlyDeclined = 0; a.classLo = 0; a.nBlocks = nBlocks;
     return (int)launch_huf_decode(a, (hipStream_t)stream);
 }
 extern "C" int FSEHIP_HUF_decompress1X1_usingDTable_batch(void* d_dst, size_t dstStride, const size_t* d_dstSizes, size_t uniformDstSize,
@@ -951,7 +951,7 @@ static int huf_decompress_impl(void* d_dst, size_t dstStride, const size_t* d_ds
         HufDecArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstSizes = ds; e.results = d_results + b0;
         e.csrc = cs; e.dtables = dtables; e.dtStrideU32 = dtU32; e.meta = meta;
-        e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.acceptX2 = 0; e.onlyDeclined = 0; e.nBlocks = nb;
+        e.maxTableLog = FSEHIP_HUF_TABLELOG_MAX; e.G = 0; e.slotU32 = 0; e.streams = 4; e.acceptX2 = 0; e.onlyDeclined = 0; e.classLo = 0; e.nBlocks = nb;
         CK(launch_huf_decode_classes(e, lists, counts, s));
     }
     return 0;

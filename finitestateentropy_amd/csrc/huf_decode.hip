@@ -559,7 +559,13 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
     probe_before(PK_HUF_DECODE, s);
     hipError_t e = hipSuccess;
     if (!a.meta) {
-        e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
+        a.classLo = 0;
+        e = launch_huf_decode_par(a, HPAR_DATA_TINY, nullptr, nullptr, s);
+        a.classLo = HPAR_DATA_TINY;
+        if (e == hipSuccess) e = launch_huf_decode_par(a, HPAR_DATA_SMALL, nullptr, nullptr, s);
+        a.classLo = HPAR_DATA_SMALL;
+        if (e == hipSuccess) e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
+        a.classLo = 0;
         if (e == hipSuccess && a.acceptX2) e = launch_huf_decode_par_x2(a, s);
         a.onlyDeclined = 1;
     }

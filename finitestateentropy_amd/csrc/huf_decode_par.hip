@@ -178,6 +178,12 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
             sp += len[q];
         }
     }
+    // caller tables: one launch per LDS budget over all blocks, every block taken by the smallest budget that holds its longest stream
+    // (the waves per CU follow the budget: 25 / 18 / 12); a block of another class leaves at once -- its launch has marked or will take it
+    if (ok && !a.meta && !a.list) {
+        const u32 mx = max(max(len[0], len[1]), max(len[2], len[3])) + 96u;
+        if (mx <= a.classLo || (mx > DATA && DATA != HPAR_DATA_LARGE)) return;      // uniform
+    }
     // declined: the serial decoder's block -- on its list (one-shot path) or marked in results[] (caller tables: no workspace)
     auto decline = [&]() { if (lane == 0) { if (fbList) fbList[atomicAdd(fbCount, 1u)] = (u32)b; else a.results[b] = HUF_DECLINED; } };
     if (!ok) { decline(); return; }                                      // uniform (rare: k_huf_dprep has looked at the jump table)

@@ -215,6 +215,8 @@ struct HufDecArgs {              // a5: HUF_decompress4X1_usingDTable, 4 lanes p
     int streams;                 // 4 (4X1) or 1 (1X1)
     int acceptX2;                // usingDTable batch only: blocks with a double-symbol table (tableType 1) are decoded instead of failing
     int onlyDeclined;            // usingDTable batch only: decode just the blocks whose result is HUF_DECLINED (left by the stream-parallel decoder)
+    unsigned classLo;            // usingDTable batch only (no workspace, hence no class lists): a launch of the stream-parallel decoder takes the blocks whose
+                                 // longest stream needs more than classLo bytes of LDS (and fits its own budget, or it is the largest class)
     size_t nBlocks;
 };
 // The caller-table batch has no workspace for a list of declined blocks: the stream-parallel decoder marks a block it declines with
