@@ -338,7 +338,9 @@ def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warm
     if fse:
         ct, hdr, hres = hip.fse_build_ctable_batch(src, table_log=table_log)
         dt, dtres = hip.fse_build_dtable_batch(hdr, hres, max_log=table_log)
-        dec_maxlog = int(os.environ.get("FSEHIP_BENCH_UT_MAXLOG", "12"))      # what the caller promises about its tables (12 = nothing: FSE_MAX_TABLELOG)
+        # maxTableLog of the decode call = what the caller promises about its tables: it built them with `table_log`, so that is the bound (one launch;
+        # FSEHIP_BENCH_UT_MAXLOG=12 = no promise, FSE_MAX_TABLELOG: two more launches look for tableLog-12 tables, +0.4 ms per 100k blocks)
+        dec_maxlog = int(os.environ.get("FSEHIP_BENCH_UT_MAXLOG", str(table_log)))
     else:
         ct, hdr, hres = hip.huf_build_ctable_batch(src, table_log=table_log)
         dt, dtres = hip.huf_read_dtable_x1_batch(hdr, hres, max_table_log=table_log)
@@ -392,6 +394,7 @@ def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warm
     rec = {"value": round(total / 2.0 ** 20 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3), "best_step_ms": round(best * 1e3, 3), "steps": steps,
            "blocks_per_gpu": nb, "encode_GBps": round(total / enc / 1e9, 2), "decode_GBps": round(total / dec / 1e9, 2),
            "payload_bytes_per_block": round(payload, 1), "header_bytes_per_block": round(float(hres.sum().item()) / nb, 1),
+           "decode_maxTableLog": dec_maxlog if fse else table_log,
            "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in per.items()}, "parity": parity, "parity_blocks_checked": checked,
            "functions": ("FSEHIP_FSE_compress_usingCTable_batch + FSEHIP_FSE_decompress_usingDTable_batch" if fse else
                          "FSEHIP_HUF_compress4X_usingCTable_batch + FSEHIP_HUF_decompress4X1_usingDTable_batch"),
