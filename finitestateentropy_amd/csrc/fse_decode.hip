@@ -802,7 +802,12 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         uint2* const dummyRing = (uint2*)(flagsSh + 32) + half;          // 128 bytes behind the flag words: a phase's records of the zombies
         // (the lanes beyond the wave's lane pairs never have a block: they stay out altogether -- one branch for the whole bulk, so that the
         //  LDS instructions of a phase serve 34 lanes, not 64)
-        if ((lane >> 1) < ppw) {
+        // Likewise the pairs that never run a phase (no block, an early error, a table the staging pass did not vouch for): a zombie is only
+        // ever a chain that WAS decoding -- its table is sound, so every address it forms stays inside its slot.
+        // (Measured and not kept, round 4: cells with nbBits in the top four bits and rev(newState) << 1 below -- every use of nbBits clean
+        //  without masks, the table part of the address one v_and_or: two instructions per iteration fewer, but the shift that extracts
+        //  nbBits sits on the dependent chain cell -> offset -> bits -> address: 11.08 instead of 10.76 ms per 100k P14 blocks.)
+        if ((lane >> 1) < ppw && everBulk) {
         for (;;) {
             // room for 16 more records, and the lowest byte this phase can read is in the ring: its last iteration starts at most
             // 15 * 48 bits further down (23 dwords) and reads the three dwords from there -> 92 bytes below q.  Nothing below the
