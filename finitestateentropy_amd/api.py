@@ -122,7 +122,7 @@ class FseHip:
                      "FSEHIP_HUF_compress", "FSEHIP_HUF_compress2", "FSEHIP_HUF_decompress",
                      "FSEHIP_FSE_compress_batch_workspaceSize", "FSEHIP_FSE_decompress_batch_workspaceSize",
                      "FSEHIP_HUF_compress_batch_workspaceSize", "FSEHIP_HUF_decompress_batch_workspaceSize",
-                     "FSEHIP_frame_compressBound", "FSEHIP_frame_compress", "FSEHIP_frame_decompress",
+                     "FSEHIP_frame_compressBound", "FSEHIP_frame_compress", "FSEHIP_frame_decompress", "FSEHIP_frame_compress_batch", "FSEHIP_frame_decompress_batch",
                      "FSEHIP_FSE_countU16", "FSEHIP_FSE_compressU16", "FSEHIP_FSE_decompressU16",
                      "FSEHIP_FSE_compressU16_batch_workspaceSize", "FSEHIP_FSE_decompressU16_batch_workspaceSize",
                      "FSEHIP_FSE_buildCTable_batch_workspaceSize", "FSEHIP_FSE_buildDTable_batch_workspaceSize",
@@ -555,7 +555,36 @@ def _frame_methods():
     def frame_decompress(self, frame, cap):
         return self._single("FSEHIP_frame_decompress", cap, frame)
 
-    for f in (frame_compress, frame_decompress):
+    def _frames(self, fname, srcs, caps, n_threads, *extra):
+        # many frames per call: arrays of host pointers / sizes; every destination carries a 0xA5 tail like _single's
+        srcs = [np.ascontiguousarray(x, dtype=np.uint8) for x in srcs]
+        n = len(srcs)
+        outs = [np.zeros(max(c, 1) + 16, dtype=np.uint8) for c in caps]
+        for o, c in zip(outs, caps):
+            o[c:] = 0xA5
+        PA, SA = C.c_void_p * max(n, 1), C.c_size_t * max(n, 1)
+        dsts = PA(*[o.ctypes.data for o in outs]); dcap = SA(*caps)
+        sp = PA(*[x.ctypes.data for x in srcs]); ssz = SA(*[x.size for x in srcs])
+        res = SA()
+        fn = getattr(self.lib, fname)
+        fn.restype = C.c_size_t
+        r = int(fn(dsts, dcap, sp, ssz, res, SZ(n), *extra, C.c_uint(n_threads)))
+        assert r == 0, "%s: %#x" % (fname, r)
+        for o, c in zip(outs, caps):
+            assert (o[c:] == 0xA5).all(), "%s wrote past dstCapacity" % fname
+        return [(int(res[i]), outs[i][:caps[i]]) for i in range(n)]
+
+    def frame_compress_batch(self, srcs, block_size_id=5, codec=0, caps=None, n_threads=0):
+        self.lib.FSEHIP_frame_compressBound.restype = C.c_size_t
+        if caps is None:
+            caps = [int(self.lib.FSEHIP_frame_compressBound(SZ(np.asarray(x).size), C.c_uint(block_size_id))) for x in srcs]
+            caps = [c if c < (1 << 62) else 16 for c in caps]
+        return self._frames("FSEHIP_frame_compress_batch", srcs, caps, n_threads, C.c_uint(block_size_id), C.c_int(codec))
+
+    def frame_decompress_batch(self, frames, caps, n_threads=0):
+        return self._frames("FSEHIP_frame_decompress_batch", frames, caps, n_threads)
+
+    for f in (_frames, frame_compress_batch, frame_decompress_batch, frame_compress, frame_decompress):
         setattr(FseHip, f.__name__, f)
 
 

@@ -287,6 +287,16 @@ FSEHIP_API int FSEHIP_probagen_batch_ex(void* d_dst, size_t dstStride, size_t bl
 FSEHIP_API size_t FSEHIP_frame_compressBound(size_t srcSize, unsigned blockSizeId);
 FSEHIP_API size_t FSEHIP_frame_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned blockSizeId, int codec);
 FSEHIP_API size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+/* Many frames per call (no counterpart in the tool, which walks its files one by one: programs/fileio.c:286-432 per file).  Frame i
+ * is coded from srcs[i] / srcSizes[i] into dsts[i] / dstCapacities[i] exactly as the single-frame call would code it -- same bytes,
+ * same result, in results[i] -- by a pool of nThreads host threads (0: half the host's hardware threads, at most 4; never more than
+ * nFrames), each with a device stream and a scratch arena of its own: one frame is bound by one host thread's XXH32 and its copies,
+ * many frames are not.  All pointers are HOST pointers.  Returns 0, or an error code when the call itself cannot run (null arrays,
+ * no device); a frame's own failure is in its results entry only. */
+FSEHIP_API size_t FSEHIP_frame_compress_batch(void* const* dsts, const size_t* dstCapacities, const void* const* srcs, const size_t* srcSizes,
+                                              size_t* results, size_t nFrames, unsigned blockSizeId, int codec, unsigned nThreads);
+FSEHIP_API size_t FSEHIP_frame_decompress_batch(void* const* dsts, const size_t* dstCapacities, const void* const* srcs, const size_t* srcSizes,
+                                                size_t* results, size_t nFrames, unsigned nThreads);
 
 /* ---- FSE for 16-bit symbols (lib/fseU16.h:62-80, lib/fseU16.c) -- SURVEY 8(f) rank 4.  Alphabets of up to
  * FSEHIP_FSEU16_MAX_SYMBOL_VALUE + 1 symbols, table logs up to 13 (default 12), ONE tANS state per stream: a different format from

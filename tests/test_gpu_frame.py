@@ -95,3 +95,54 @@ def test_large_frames_take_the_pipelined_reader(hip, oracle):
     r, out = oracle.frame_compress(mixed, 0, 0)
     r2, o2 = hip.frame_decompress(out[:r], len(mixed))
     assert r2 == len(mixed) and (o2[:r2] == mixed).all()
+
+
+def test_frame_batch_calls_match_the_single_frame_calls(hip, oracle):
+    """FSEHIP_frame_compress_batch / _decompress_batch: every frame of a batch gets the bytes and the result of the single-frame
+    call (= the oracle's, pinned against the tool), whatever the pool size -- empty and tiny inputs, ragged tails, a frame large
+    enough for the pipelined reader, raw and RLE blocks, and on the way back damaged frames, short destinations and non-frames"""
+    rng = np.random.default_rng(5)
+    srcs = [np.zeros(0, np.uint8), np.array([7], np.uint8), np.full(40000, 3, np.uint8),
+            rng.integers(0, 256, 70000, dtype=np.uint8)]
+    for i, (p, n) in enumerate(((14, 100000), (80, 33000), (2, 32768 * 3), (14, 2500 * 1024), (50, 1 << 20), (14, 777))):
+        srcs.append(oracle.probagen_batch(p, 1, n, 100 + i)[0])
+    for bsid, codec in ((5, 0), (5, 1), (0, 0), (2, 1)):
+        want = [oracle.frame_compress(x, bsid, codec) for x in srcs]
+        for nthreads in (1, 3, 0):
+            got = hip.frame_compress_batch(srcs, bsid, codec, n_threads=nthreads)
+            for (r, out), (rg, og) in zip(want, got):
+                assert rg == r and (og[:r] == out[:r]).all(), (bsid, codec, nthreads)
+        frames = [out[:r] for r, out in want]
+        caps = [len(x) for x in srcs]
+        # the way back: intact frames; then every second one damaged / cut short / given a short destination
+        bad, bcaps = [], []
+        for i, (f, c) in enumerate(zip(frames, caps)):
+            f = f.copy()
+            kind = i % 5
+            if kind == 1 and len(f) > 12:
+                f[int(rng.integers(5, len(f) - 3))] ^= 0x10
+            elif kind == 2:
+                f = f[:max(len(f) - 2, 0)]
+            elif kind == 3:
+                c = max(c - 1, 0)
+            elif kind == 4:
+                f[0] ^= 0xFF
+            bad.append(f); bcaps.append(c)
+        for fs, cs in ((frames, caps), (bad, bcaps)):
+            wantd = [oracle.frame_decompress(f, c) for f, c in zip(fs, cs)]
+            for nthreads in (1, 4, 0):
+                gotd = hip.frame_decompress_batch(fs, cs, n_threads=nthreads)
+                for i, ((ro, oo), (rg, og)) in enumerate(zip(wantd, gotd)):
+                    assert rg == ro or (is_error(rg) and is_error(ro) and s64(rg) == s64(ro)), (bsid, codec, nthreads, i, rg, ro)
+                    if not is_error(ro):
+                        assert (og[:ro] == oo[:ro]).all(), (bsid, codec, nthreads, i)
+    # a short destination for one frame of a compress batch fails that frame only
+    caps = [int(hip.lib.FSEHIP_frame_compressBound(x.size, 5)) for x in srcs]
+    caps[4] = 100
+    got = hip.frame_compress_batch(srcs, 5, 0, caps=caps, n_threads=2)
+    want = [oracle.frame_compress(x, 5, 0) for x in srcs]
+    assert is_error(got[4][0])
+    for i, ((r, out), (rg, og)) in enumerate(zip(want, got)):
+        if i != 4:
+            assert rg == r and (og[:r] == out[:r]).all()
+    assert hip.frame_compress_batch([], 5, 0) == []
