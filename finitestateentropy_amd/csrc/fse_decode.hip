@@ -179,6 +179,69 @@ DEV u32 lshl_or(u32 v, u32 sh, u32 o) { u32 r; __asm__("v_lshl_or_b32 %0, %1, %2
 DEV u32 ring_dword(u32 P) { u32 r; __asm__("v_bfe_u32 %0, %1, 5, %2" : "=v"(r) : "v"(P), "n"(FSE_IN_RING_LOG - 2)); return r; }              // (P >> 5) mod ring dwords
 // PheadRef: the cursor at the head of the phase's LAST iteration (the reference's reader state between two loop-head reloads is
 // fixed by the bits unread at the last reload and the bits unread now: k_fse_decode rebuilds it from the two).
+#ifndef FSE_SCHED
+#define FSE_SCHED 1
+#endif
+#if FSE_SCHED
+// The phase with its issue order written out (sched_barrier between the groups) -- the compiler's own schedule (FSE_SCHED 0, below)
+// requested a cell only after the window reads and waited for the window behind a cursor update that itself waited for the cell.
+// Per iteration there are two LDS round trips nothing can hide (cell of symbol pair 1 -> cell of pair 2 -> next iteration's cell); the
+// rest is arranged around them:
+//   * a cell is requested the moment its address exists, and only the six instructions that need it (v_and_b32_dpp, v_bfe, v_sub,
+//     v_lshrrev, v_or, v_lshl_or) stand between its arrival and the next request;
+//   * the window is off the chain: the four dwords the NEXT iteration may need are requested as soon as the first symbol pair's bit
+//     count is known (position P1; the second pair moves the cursor by < 32 bits more, so the next window starts in the dword of P1
+//     or in the one after it) and the iteration picks its three by selects -- five more VALU instructions, all issued while a cell
+//     is on its way, and no LDS round trip between the cursor and the window.
+// Per 100k Proba14 blocks (decode call = dparse + dbuild + this kernel): compiler's schedule 11.59 ms; cell requested early, cell-only
+// work before the window wait 11.27; with the window requested one iteration ahead 10.72.
+#define SB __builtin_amdgcn_sched_barrier(0)
+template <int NITER>
+DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
+{
+    u32 s = sMine, P = Pref;
+    u32 prev = 0;
+    __asm__ volatile("" : "+v"(myIn));
+    u32 c = lds_cell(s);
+    u32 Pw = P;
+    lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (ring_dword(P) << 2));
+    u32 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+#pragma unroll FSE_PHASE_UNROLL
+    for (int it = 0; it < NITER; ++it) {
+        if (it == NITER - 1) PheadRef = P;
+        // (while the cell is on its way) this iteration's window out of the dwords requested at Pw
+        const bool k = ((P ^ Pw) & 32u) != 0;
+        const u32 e0 = k ? w1 : w0, e1 = k ? w2 : w1, e2 = k ? w3 : w2;
+        u32 lo = __builtin_amdgcn_alignbit(e1, e0, P);
+        u32 hi = __builtin_amdgcn_alignbit(e2, e1, P);
+        __asm__ volatile("" : "+v"(lo), "+v"(hi));
+        SB;
+        const u32 sStart = s;
+        s = lshl_or(__builtin_amdgcn_ubfe(lo, dpp_swap_and(c, maskB), c), K - c, (c >> cellShift) | tabOff);
+        const u32 c2 = lds_cell(s);
+        SB;
+        const u32 n1 = dpp_swap_add(c, c);
+        const u32 P1 = P + (n1 & 31u);
+        if (it + 1 < NITER) {
+            Pw = P1;
+            wp = (lds_u32_ptr)(uintptr_t)(myIn + (ring_dword(P1) << 2));
+            w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; w3 = wp[3];
+        }
+        u32 lo2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+        u32 rec = __builtin_amdgcn_perm(s, sStart, 0x05040100u);
+        __asm__ volatile("" : "+v"(lo2), "+v"(rec));
+        if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
+        SB;
+        s = lshl_or(__builtin_amdgcn_ubfe(lo2, dpp_swap_and(c2, maskB), c2), K - c2, (c2 >> cellShift) | tabOff);
+        if (it + 1 < NITER) c = lds_cell(s);
+        SB;
+        const u32 n2 = dpp_swap_add(c2, c2);
+        P = P1 + (n2 & 31u);
+    }
+    sMine = s; Pref = P;
+}
+#undef SB
+#else
 template <int NITER>
 DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
 {
@@ -208,6 +271,8 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
     }
     sMine = s; Pref = P;
 }
+
+#endif
 
 // Per-block control words in LDS: the decoder wave and the service wave of a workgroup talk through these only.
 struct DecCtl {

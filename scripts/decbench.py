@@ -1,0 +1,26 @@
+"""development aid: FSE one-shot decode time per batch (dparse + dbuild + k_fse_decode) for A/B runs of differently configured builds
+(FSEHIP_LIB=finitestateentropy_amd/csrc/variants/x/libfsehip.so python scripts/decbench.py [blocks [P [tableLog]]])"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from finitestateentropy_amd.api import FseHip
+
+hip = FseHip()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+tl = int(sys.argv[3]) if len(sys.argv) > 3 else 11
+src = hip.probagen_batch(P, n, 32768, 1)
+dst, res = hip.fse_compress_batch(src, tl)
+ws = hip.fse_workspace(n, max(tl, 11), True)
+out = torch.empty((n, 32768), dtype=torch.uint8, device="cuda"); dres = torch.empty(n, dtype=torch.int64, device="cuda")
+run = lambda: hip.fse_decompress_batch(dst, res, 32768, max(tl, 11), dst=out, results=dres, workspace=ws)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+ts = []
+for _ in range(12):
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record(); run(); t1.record(); torch.cuda.synchronize()
+    ts.append(t0.elapsed_time(t1))
+ts.sort()
+print("%s: P%02d tl%d %d blocks: decode best %.3f ms, median %.3f ms, ok=%s" % (os.environ.get("FSEHIP_LIB", "base"), P, tl, n, ts[0], ts[len(ts) // 2], bool(torch.equal(out, src)) and bool((dres == 32768).all())))
