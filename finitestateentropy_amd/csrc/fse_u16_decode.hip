@@ -107,14 +107,18 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
     bool live = lane < U16D_SRV_G && myG < G && !(ctl->pubPofs >> 31);
     const int grp = lane / 16, sub = lane % 16;
     const int SgK = __shfl(S32, grp, WAVE);
-    const u8* const igK = (const u8*)(uintptr_t)__shfl(inBits, grp, WAVE);
+    // (global-address-space pointers: a flat_* access would count on lgkmcnt too and every LDS wait of this wave would wait for the
+    //  symbol gathers in flight -- fse_decode.hip)
+    typedef const __attribute__((address_space(1))) u8* g_u8; typedef const __attribute__((address_space(1))) u16* g_u16;
+    typedef u32 __attribute__((aligned(1))) u32_u; typedef unsigned long long __attribute__((aligned(1))) u64_u;
+    const g_u8 igK = (g_u8)(uintptr_t)__shfl(inBits, grp, WAVE);
     u32* const rgK = (u32*)(ldsb + (size_t)(g0 + grp) * slotBytes + U16D_RING * 8);
     {   const bool liveK = (__ballot(live) >> grp) & 1ull;
         const int vlo = __shfl(validLo, grp, WAVE);
 #pragma unroll
         for (int c = 0; c < (int)(U16D_IN_RING / U16D_IN_CHUNK); ++c) {
             const int off = liveK ? vlo + (int)U16D_IN_CHUNK * c + 4 * sub : -1;
-            if (off >= 0 && off + 4 <= SgK) { u32 w; __builtin_memcpy(&w, igK + off, 4); u16d_ring_put(rgK, off, w); }
+            if (off >= 0 && off + 4 <= SgK) { const u32 w = *(const __attribute__((address_space(1))) u32_u*)(igK + off); u16d_ring_put(rgK, off, w); }
             else if (off >= 0 && off < SgK) { u32 w = 0; for (int i = 0; i < 3; ++i) if (off + i < SgK) w |= (u32)igK[off + i] << (8 * i); u16d_ring_put(rgK, off, w); }
         }
         if (live) u16d_store(&ctl->srvValidLo, validLo);
@@ -143,13 +147,13 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
         if (rm) {
             fillOff = __shfl(validLo, grp, WAVE) - (int)U16D_IN_CHUNK + 4 * sub;
             pend = 0;
-            if (fillK && fillOff >= 0 && fillOff + 4 <= SgK) __builtin_memcpy(&pend, igK + fillOff, 4);
+            if (fillK && fillOff >= 0 && fillOff + 4 <= SgK) pend = *(const __attribute__((address_space(1))) u32_u*)(igK + fillOff);
         }
 #pragma unroll
         for (int l = 0; l < U16D_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
-            const u16* const tg = (const u16*)(uintptr_t)__shfl(symBits, l, WAVE);
+            const g_u16 tg = (g_u16)(uintptr_t)__shfl(symBits, l, WAVE);
             if ((u32)lane < cnt) {
                 const u32 ri = (fp_g + (u32)lane) & (U16D_RING - 1);
                 const uint2 rec = *(const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + 8u * ri);
@@ -165,10 +169,10 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
         for (int l = 0; l < U16D_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
-            u8* const og = (u8*)(uintptr_t)__shfl(outBits, l, WAVE) + 8ull * fl_g;
+            __attribute__((address_space(1))) u8* const og = (__attribute__((address_space(1))) u8*)(uintptr_t)(__shfl(outBits, l, WAVE) + 8ull * fl_g);
             if ((u32)lane < cnt) {
                 const uint2 w = make_uint2(yq[l][0] | (yq[l][1] << 16), yq[l][2] | (yq[l][3] << 16));
-                __builtin_memcpy(og + 8u * lane, &w, 8);
+                *(__attribute__((address_space(1))) u64_u*)(og + 8u * lane) = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
             }
         }
         if (wantFlush) { fpos = (fpos + (it - flushed)) & (U16D_RING - 1); flushed = it; }

@@ -137,6 +137,9 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
     int validLo = ctl->initValidLo;
     u32 flushed = 0;
     bool live = lane < HD_SRV_S && myS < nStreams && !(ctl->pubPofs >> 31);
+    // (global-address-space pointers: a flat_* access would count on lgkmcnt too and every LDS wait of this wave would wait for the
+    //  global loads in flight -- fse_decode.hip)
+    typedef const __attribute__((address_space(1))) u8* hd_g_u8; typedef u32 __attribute__((aligned(1))) hd_u32_u;
     const int half = lane >> 5, l32 = lane & 31;             // input refills: 32 lanes per stream, two streams per instruction
 
     // initial fill: both chunks of every live stream (the topmost dword may straddle the end of the stream), then publish
@@ -145,10 +148,10 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
         for (int l = 0; l < HD_SRV_S; ++l) {
             if (!((am >> l) & 1ull)) continue;               // uniform
             const int vlo = __shfl(validLo, l, WAVE), Sg = __shfl(S32, l, WAVE);
-            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
+            const hd_g_u8 ig = (hd_g_u8)(uintptr_t)__shfl(inBits, l, WAVE);
             u32* const rg = (u32*)(aux + (size_t)(s0 + l) * HD_STREAM_AUX);
             const int off = vlo + 4 * lane;                  // 64 lanes x 4 bytes = the whole ring
-            if (off >= 0 && off + 4 <= Sg) { u32 w; __builtin_memcpy(&w, ig + off, 4); hd_ring_put(rg, Sg, off, w); }
+            if (off >= 0 && off + 4 <= Sg) { const u32 w = *(const __attribute__((address_space(1))) hd_u32_u*)(ig + off); hd_ring_put(rg, Sg, off, w); }
             else if (off >= 0 && off < Sg) {
                 u32 w = 0;
                 for (int i = 0; i < 3; ++i) if (off + i < Sg) w |= (u32)ig[off + i] << (8 * i);
@@ -186,9 +189,9 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
             const bool on = (rm >> l) & 1ull;
             const int off = __shfl(validLo, l, WAVE) - HD_IN_CHUNK + 4 * l32;
             const int Sg = __shfl(S32, l, WAVE);
-            const u8* const ig = (const u8*)(uintptr_t)__shfl(inBits, l, WAVE);
+            const hd_g_u8 ig = (hd_g_u8)(uintptr_t)__shfl(inBits, l, WAVE);
             u32 w = 0;
-            if (on && off >= 0 && off + 4 <= Sg) __builtin_memcpy(&w, ig + off, 4);
+            if (on && off >= 0 && off + 4 <= Sg) w = *(const __attribute__((address_space(1))) hd_u32_u*)(ig + off);
             pend[p] = w;
         }
         // (2) read the output words of every stream with enough of them: at most 32 words each, so streams 2p and 2p+1 of
@@ -221,8 +224,8 @@ DEV void hd_service(int nStreams, u8* aux, HdCtl* ctlAll, int lane, int s0)
             const int l = 2 * p + half;
             const bool on = (fm >> l) & 1ull;
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl = (u32)__shfl((int)flushed, l, WAVE);
-            u8* const og = (u8*)(uintptr_t)__shfl(outBits, l, WAVE) + 4ull * fl;
-            if (on && (u32)l32 < cnt) __builtin_memcpy(og + 4u * l32, &outw[p], 4);
+            __attribute__((address_space(1))) u8* const og = (__attribute__((address_space(1))) u8*)(uintptr_t)(__shfl(outBits, l, WAVE) + 4ull * fl);
+            if (on && (u32)l32 < cnt) *(__attribute__((address_space(1))) hd_u32_u*)(og + 4u * l32) = outw[p];
         }
         if (wantFlush) flushed = it;
     }

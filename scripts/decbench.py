@@ -24,3 +24,14 @@ for _ in range(12):
     ts.append(t0.elapsed_time(t1))
 ts.sort()
 print("%s: P%02d tl%d %d blocks: decode best %.3f ms, median %.3f ms, ok=%s" % (os.environ.get("FSEHIP_LIB", "base"), P, tl, n, ts[0], ts[len(ts) // 2], bool(torch.equal(out, src)) and bool((dres == 32768).all())))
+if os.environ.get("DECBENCH_TIMING"):
+    import ctypes as C
+    L = hip.lib
+    L.FSEHIP_debug_decodeTiming(1, None)
+    run(); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    L.FSEHIP_debug_decodeTiming(0, buf)
+    t = [int(x) for x in buf]
+    rounds = max(t[2], 1)
+    print("  decoder wave: %.0f cycles per productive round (%.1f per iteration, %.1f inside the phase), waiting rounds %.1f%% of the time; "
+          "service wave 0 busy %.0f%%" % (t[0] / rounds, t[0] / rounds / 16, t[7] / rounds / 16, 100.0 * t[1] / max(t[0] + t[1], 1), 100.0 * t[5] / max(t[5] + t[6], 1)))
