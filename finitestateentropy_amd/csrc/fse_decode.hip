@@ -165,8 +165,9 @@ DEV void fse_bulk_phase(u32& sMine, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn,
 }
 
 // ---- bit-reversed bulk loop (tables from k_fse_dbuild) -------------------------------------------------------------
-// A lone wave is bound by the number of instructions it issues (about one per 7 cycles), so this variant is laid out to
-// need as few as possible: 6 VALU per symbol and 11 per iteration for the bit cursor.
+// A block's chain is two LDS round trips per iteration plus whatever stands between a cell's arrival and the next request, so this
+// variant is laid out to need as little as possible there: 6 VALU per symbol, the bit cursor and the window off the chain (the
+// issue order is written out in fse_bulk_phase_rev below).
 //   * The input ring holds the stream in CONSUMPTION order: ring dword m = bit-reversed payload dword (Stop/4 - 1 - m)
 //     (Stop = payload size rounded up to 4), written that way by the service waves.  The cursor is one number,
 //     P = 8*Stop - (unread bits): the next bit to read is bit P & 31 of ring dword P >> 5, and bits are taken from the
