@@ -369,7 +369,11 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         if (live) ctl_store(&ctl->srvValidLo, validLo);
     }
 
+    // The chunk a block will ask for next is requested AHEAD (the input is read-only, its position is known): when the decoder has moved
+    // far enough the refill is an LDS store of data that arrived long ago, and a round that only refills does not wait for memory.
+    int nextOff = __shfl(validLo, grp, WAVE) - FSE_IN_CHUNK + 4 * sub;     // my dword of my block's next chunk [validLo - CHUNK, validLo)
     u32 pend = 0;
+    if (((__ballot(live) >> grp) & 1ull) && nextOff >= 0 && nextOff + 4 <= SgK) pend = gbl_load_u32(igK + nextOff);
     u32 yq[FSE_SRV_G][4];
 #pragma unroll
     for (int l = 0; l < FSE_SRV_G; ++l) { yq[l][0] = yq[l][1] = yq[l][2] = yq[l][3] = 0; }
@@ -394,13 +398,16 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             TIMING(const unsigned long long sB = __builtin_readcyclecounter(); sIdle += sB - sA; sA = sB;);
             continue;
         }
-        // (1) request the next input chunk of every block that is about to need it
+        // (1) install the input chunks that are asked for (requested ahead: see above), publish them, request the ones below them
         const bool fillK = (rm >> grp) & 1ull;
-        int fillOff = -1;
         if (rm) {                                            // uniform
-            fillOff = __shfl(validLo, grp, WAVE) - FSE_IN_CHUNK + 4 * sub;
-            pend = 0;
-            if (fillK && fillOff >= 0 && fillOff + 4 <= SgK) pend = gbl_load_u32(igK + fillOff);
+            if (fillK) { if (rev) fse_ring_put_rev(rgK, SgK, nextOff, pend); else fse_ring_put(rgK, nextOff, pend); }
+            if (wantFill) { validLo -= FSE_IN_CHUNK; ctl_store(&ctl->srvValidLo, validLo); }
+            if (fillK) {
+                nextOff -= FSE_IN_CHUNK;
+                pend = 0;
+                if (nextOff >= 0 && nextOff + 4 <= SgK) pend = gbl_load_u32(igK + nextOff);
+            }
         }
         // (2) issue the symbol gathers of every block with enough records
 #pragma unroll
@@ -427,9 +434,6 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 #endif
             }
         }
-        // (3) install the input chunks and publish them
-        if (fillK) { if (rev) fse_ring_put_rev(rgK, SgK, fillOff, pend); else fse_ring_put(rgK, fillOff, pend); }
-        if (wantFill) { validLo -= FSE_IN_CHUNK; ctl_store(&ctl->srvValidLo, validLo); }
         // (4) the ring records are in registers now: hand the slots back, then pack and store the symbols
         if (wantFlush) { ctl_store(&ctl->srvFlushed, it); }
 #pragma unroll
