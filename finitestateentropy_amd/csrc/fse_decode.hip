@@ -370,7 +370,8 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
     }
 
     // The chunk a block will ask for next is requested AHEAD (the input is read-only, its position is known): when the decoder has moved
-    // far enough the refill is an LDS store of data that arrived long ago, and a round that only refills does not wait for memory.
+    // far enough the refill is an LDS store of data that arrived long ago, and a round that only refills does not wait for memory
+    // (decoder-wave waiting 4.2 -> 0.9 % of its time; decode call per 100k blocks P14 10.52 -> 10.40 ms, P02 12.95 -> 12.30).
     int nextOff = __shfl(validLo, grp, WAVE) - FSE_IN_CHUNK + 4 * sub;     // my dword of my block's next chunk [validLo - CHUNK, validLo)
     u32 pend = 0;
     if (((__ballot(live) >> grp) & 1ull) && nextOff >= 0 && nextOff + 4 <= SgK) pend = gbl_load_u32(igK + nextOff);
