@@ -689,13 +689,16 @@ extern "C" int FSEHIP_releaseScratch(void)
 // result transport for one block: returns GENERIC when the device path itself fails
 #define HK(x) do { if ((x) != hipSuccess) return FSEHIP_ERROR(GENERIC); } while (0)
 
-extern "C" size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize)
+static size_t hist_count_host(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize, int trustInput)
 {
     DevBuf dsrc, dcnt, dmsv, dres;
     HK(dsrc.alloc(srcSize)); HK(dcnt.alloc(1024)); HK(dmsv.alloc(4)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
     HK(hipMemcpy(dmsv.p, maxSymbolValuePtr, 4, hipMemcpyHostToDevice));
-    HK((hipError_t)FSEHIP_HIST_count_batch((unsigned*)dcnt.p, (unsigned*)dmsv.p, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize, 1, nullptr));
+    HistArgs a;
+    a.counts = (unsigned*)dcnt.p; a.maxSVs = (unsigned*)dmsv.p; a.uniformMaxSV = 255; a.useUniformIn = 0; a.trustInput = trustInput;
+    a.results = (size_t*)dres.p; a.src = mkview(dsrc.p, srcSize, nullptr, srcSize); a.nBlocks = 1;
+    HK(launch_hist(a, nullptr));
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (FSEHIP_isError(r)) return r;
@@ -704,6 +707,25 @@ extern "C" size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr
     HK(hipMemcpy(count, dcnt.p, nOut * 4, hipMemcpyDeviceToHost));
     HK(hipMemcpy(maxSymbolValuePtr, dmsv.p, 4, hipMemcpyDeviceToHost));
     return r;
+}
+extern "C" size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize)
+{
+    return hist_count_host(count, maxSymbolValuePtr, src, srcSize, 0);
+}
+// lib/hist.h:46 (lib/hist.c:163-173): the workspace is validated exactly as the reference validates it and then left alone -- the counting
+// happens in the kernel's LDS
+extern "C" size_t FSEHIP_HIST_count_wksp(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize, void* workSpace, size_t workSpaceSize)
+{
+    if ((size_t)workSpace & 3) return FSEHIP_ERROR(GENERIC);
+    if (workSpaceSize < FSEHIP_HIST_WKSP_SIZE) return FSEHIP_ERROR(workSpace_tooSmall);
+    return hist_count_host(count, maxSymbolValuePtr, src, srcSize, 0);
+}
+// lib/hist.h:54 (lib/hist.c:141-159): the unchecked variant.  A limit below 255 bounds the entries written to count[] but a larger symbol in
+// src is not an error: the result and *maxSymbolValuePtr are taken over all 256 symbols (HIST_count_parallel_wksp with trustInput, :120-131).
+// Below 1500 bytes the reference runs HIST_count_simple, which writes beyond count[] for such input; the defined behaviour is kept at every size.
+extern "C" size_t FSEHIP_HIST_countFast(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize)
+{
+    return hist_count_host(count, maxSymbolValuePtr, src, srcSize, 1);
 }
 
 extern "C" size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const FSEHIP_FSE_CTable* ct)
@@ -773,6 +795,65 @@ extern "C" size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const voi
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
+    return r;
+}
+
+// lib/fse.h:315 (lib/fse_compress.c:632-677).  The workspace is checked as the reference checks it -- its size in BYTES against
+// FSE_WKSP_SIZE_U32(tableLog, maxSymbolValue), the comparison of :646 as written, on the arguments as passed (before 0 -> 255 / default) --
+// and then left alone: tables and counters live in device memory.  A table log above FSE_MAX_TABLELOG is not refused here (FSE_compress2
+// refuses it, :691): FSE_optimalTableLog clamps it to 12 (:340), so it codes like 12.
+extern "C" size_t FSEHIP_FSE_compress_wksp(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog,
+                                           void* workSpace, size_t wkspSize)
+{
+    (void)workSpace;
+    // 1 << (tableLog - 1) with tableLog 0 is undefined in the reference's macro (x86: 1 << 31); such a call cannot pass the check
+    if (tableLog == 0 || tableLog > 31) return FSEHIP_ERROR(tableLog_tooLarge);
+    const unsigned long long need = 1ull + (1ull << (tableLog - 1)) + 2ull * ((unsigned long long)maxSymbolValue + 1) + (tableLog > 12 ? (1ull << (tableLog - 2)) : 1024ull);
+    if (wkspSize < need) return FSEHIP_ERROR(tableLog_tooLarge);
+    return FSEHIP_FSE_compress2(dst, dstSize, src, srcSize, maxSymbolValue, tableLog > FSEHIP_FSE_MAX_TABLELOG ? FSEHIP_FSE_MAX_TABLELOG : tableLog);
+}
+
+// lib/fse.h:335 (lib/fse_decompress.c:255-274): FSE_decompress with the caller's table-log limit.  The reference builds its DTable in
+// `workSpace` (FSE_DTABLE_SIZE_U32(maxLog) words); when one is given it receives the same table here (built on the device in the reference's
+// layout), so a caller that looks at it afterwards finds what it expects.  Limits above FSE_MAX_TABLELOG count as 12, the library's
+// build-time limit (a stream with a larger table log: tableLog_tooLarge).
+extern "C" size_t FSEHIP_FSE_decompress_wksp(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize, FSEHIP_FSE_DTable* workSpace, unsigned maxLog)
+{
+    const unsigned ml = maxLog > FSEHIP_FSE_MAX_TABLELOG ? FSEHIP_FSE_MAX_TABLELOG : maxLog;
+    if (ml == 0) {      // no table log fits: FSE_readNCount's own errors first, then tableLog_tooLarge (every valid header has tableLog >= 5)
+        const size_t wsB = FSEHIP_FSE_buildDTable_batch_workspaceSize(1, FSEHIP_FSE_MAX_TABLELOG);
+        DevBuf dsrc, ddt, dws, dres;
+        HK(dsrc.alloc(cSrcSize)); HK(ddt.alloc(4 * (size_t)FSEHIP_FSE_DTABLE_SIZE_U32(FSEHIP_FSE_MAX_TABLELOG))); HK(dws.alloc(wsB)); HK(dres.alloc(8));
+        HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+        HK((hipError_t)FSEHIP_FSE_buildDTable_batch((unsigned*)ddt.p, FSEHIP_FSE_DTABLE_SIZE_U32(FSEHIP_FSE_MAX_TABLELOG), (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize,
+                                                    FSEHIP_FSE_MAX_TABLELOG, 1, dws.p, wsB, nullptr));
+        size_t r = 0;
+        HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+        return FSEHIP_isError(r) ? r : FSEHIP_ERROR(tableLog_tooLarge);
+    }
+    const size_t wsBytes = FSEHIP_FSE_decompress_batch_workspaceSize(1, ml);
+    DevBuf dsrc, ddst, dws, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstCapacity)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_decompress_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize, ml, 1, dws.p, wsBytes, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstCapacity ? r : dstCapacity, hipMemcpyDeviceToHost));
+    if (workSpace) {    // the table the reference leaves in the workspace (whenever the header parsed and its table log fits)
+        const size_t wsB = FSEHIP_FSE_buildDTable_batch_workspaceSize(1, ml);
+        const size_t dtU32 = FSEHIP_FSE_DTABLE_SIZE_U32(ml);
+        DevBuf ddt, dws2, dres2;
+        HK(ddt.alloc(4 * dtU32)); HK(dws2.alloc(wsB)); HK(dres2.alloc(8));
+        HK((hipError_t)FSEHIP_FSE_buildDTable_batch((unsigned*)ddt.p, dtU32, (size_t*)dres2.p, dsrc.p, cSrcSize, nullptr, cSrcSize, ml, 1, dws2.p, wsB, nullptr));
+        size_t hr = 0;
+        HK(hipMemcpy(&hr, dres2.p, 8, hipMemcpyDeviceToHost));
+        if (!FSEHIP_isError(hr)) {
+            u32 h0 = 0;
+            HK(hipMemcpy(&h0, ddt.p, 4, hipMemcpyDeviceToHost));
+            const unsigned tl = h0 & 0xFFFFu;
+            if (tl <= ml) HK(hipMemcpy(workSpace, ddt.p, 4 * ((size_t)1 + ((size_t)1 << tl)), hipMemcpyDeviceToHost));
+        }
+    }
     return r;
 }
 
@@ -874,10 +955,10 @@ extern "C" size_t FSEHIP_HUF_compress_batch_workspaceSize(size_t nBlocks)
     return c * HUF_CWS_PER_BLOCK + HUF_CWS_NODE_PAD + WS_SLACK;
 }
 
-extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
-                                         const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
-                                         unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
-                                         void* d_workspace, size_t workspaceBytes, void* stream)
+static int huf_compress_impl(int streams, void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                             const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                             unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                             void* d_workspace, size_t workspaceBytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;          // include/fsehip.h: workspaces are 256-byte aligned; checked before anything else
@@ -911,10 +992,19 @@ extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t d
         CK(launch_huf_cprep(c, s, nodes));
         HufEncArgs e;
         e.dst = (u8*)d_dst + b0 * dstStride; e.dstStride = dstStride; e.dstCapacity = dstCapacity; e.results = d_results + b0;
-        e.src = src; e.ctables = ctables; e.ctStrideU32 = 256; e.meta = meta; e.streams = 4; e.split1X = 0; e.nBlocks = nb;
+        e.src = src; e.ctables = ctables; e.ctStrideU32 = 256; e.meta = meta; e.streams = streams; e.split1X = 0; e.nBlocks = nb;
         CK(launch_huf_encode(e, s));
     }
     return 0;
+}
+
+extern "C" int FSEHIP_HUF_compress_batch(void* d_dst, size_t dstStride, size_t dstCapacity, size_t* d_results,
+                                         const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
+                                         unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks,
+                                         void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    return huf_compress_impl(4, d_dst, dstStride, dstCapacity, d_results, d_src, srcStride, d_sizes, uniformSize, maxSymbolValue, tableLog, nBlocks,
+                             d_workspace, workspaceBytes, stream);
 }
 
 static const size_t HUF_DWS_PER_BLOCK = sizeof(HufMeta) + 4 * (size_t)FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1) + HUF_DCLS_COUNT * sizeof(u32);
@@ -1062,7 +1152,7 @@ extern "C" size_t FSEHIP_HUF_decompress1X_usingDTable(void* dst, size_t maxDstSi
     return huf_using_dtable_host(true, dst, maxDstSize, cSrc, cSrcSize, DTable, 1);
 }
 
-extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)
+static size_t huf_compress_host(int streams, void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)
 {
     // argument checks in the reference's order (huf_compress.c:654-660)
     if (!srcSize) return 0;
@@ -1074,11 +1164,68 @@ extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void
     DevBuf dsrc, ddst, dws, dres;
     HK(dsrc.alloc(srcSize)); HK(ddst.alloc(dstCapacity)); HK(dws.alloc(wsBytes)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
-    HK((hipError_t)FSEHIP_HUF_compress_batch(ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize,
-                                             maxSymbolValue, tableLog, 1, dws.p, wsBytes, nullptr));
+    HK((hipError_t)huf_compress_impl(streams, ddst.p, dstCapacity, dstCapacity, (size_t*)dres.p, dsrc.p, srcSize, nullptr, srcSize,
+                                     maxSymbolValue, tableLog, 1, dws.p, wsBytes, nullptr));
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r, hipMemcpyDeviceToHost));   // r == 1: the RLE byte sits in dst[0] (:673)
+    return r;
+}
+extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)
+{
+    return huf_compress_host(4, dst, dstCapacity, src, srcSize, maxSymbolValue, tableLog);
+}
+// lib/huf.h:95, :289 (lib/huf_compress.c:727-768 -> HUF_compress_internal :637-724): the workspace is validated as :654-655 validate it
+// (alignment first, then size) and then left alone; the 1X form writes one stream without a jump table (HUF_singleStream, :615-617)
+extern "C" size_t FSEHIP_HUF_compress4X_wksp(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog,
+                                             void* workSpace, size_t wkspSize)
+{
+    if (((size_t)workSpace & 3) != 0) return FSEHIP_ERROR(GENERIC);
+    if (wkspSize < FSEHIP_HUF_WORKSPACE_SIZE) return FSEHIP_ERROR(workSpace_tooSmall);
+    return huf_compress_host(4, dst, dstCapacity, src, srcSize, maxSymbolValue, tableLog);
+}
+extern "C" size_t FSEHIP_HUF_compress1X_wksp(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog,
+                                             void* workSpace, size_t wkspSize)
+{
+    if (((size_t)workSpace & 3) != 0) return FSEHIP_ERROR(GENERIC);
+    if (wkspSize < FSEHIP_HUF_WORKSPACE_SIZE) return FSEHIP_ERROR(workSpace_tooSmall);
+    return huf_compress_host(1, dst, dstCapacity, src, srcSize, maxSymbolValue, tableLog);
+}
+// lib/huf.h:164 (lib/huf_decompress.c:417-438): HUF_readDTableX1_wksp into the caller's DTable -- whose descriptor carries the table-log limit
+// (HUF_CREATE_STATIC_DTABLEX1) and receives {tableType 0, tableLog}, the cells behind it -- then the four streams behind the header.  The
+// workspace is checked as :137 checks it ((16 + 64) words) and then left alone.
+extern "C" size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize,
+                                                     void* workSpace, size_t wkspSize)
+{
+    (void)workSpace;
+    if (wkspSize < 4 * (16 + 64)) return FSEHIP_ERROR(tableLog_tooLarge);
+    const u32 desc = dctx[0];
+    unsigned mtl = desc & 0xFFu;                                   // DTableDesc.maxTableLog: tables up to mtl + 1 fit (:149)
+    if (mtl > FSEHIP_HUF_TABLELOG_MAX - 1) mtl = FSEHIP_HUF_TABLELOG_MAX - 1;      // (HUF_readStats refuses table logs above 12 anyway)
+    const unsigned mtlDev = mtl ? mtl : 1;                          // the batch call reads 0 as "default"; a limit of 0 is enforced below
+    const size_t dtU32 = 1 + ((size_t)1 << mtlDev);
+    const size_t wsB = FSEHIP_HUF_readDTableX1_batch_workspaceSize(1);
+    DevBuf dsrc, ddst, ddt, dws, dres;
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstSize)); HK(ddt.alloc(4 * dtU32)); HK(dws.alloc(wsB)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HUF_readDTableX1_batch((u32*)ddt.p, dtU32, mtlDev, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize, 1, dws.p, wsB, nullptr));
+    size_t hSize = 0;
+    HK(hipMemcpy(&hSize, dres.p, 8, hipMemcpyDeviceToHost));
+    if (FSEHIP_isError(hSize)) return hSize;
+    u32 d0 = 0;
+    HK(hipMemcpy(&d0, ddt.p, 4, hipMemcpyDeviceToHost));
+    const unsigned tl = (d0 >> 16) & 0xFFu;
+    if (tl > (desc & 0xFFu) + 1) return FSEHIP_ERROR(tableLog_tooLarge);
+    HK(hipMemcpy(dctx + 1, (const u32*)ddt.p + 1, tl ? ((size_t)2 << tl) : 2, hipMemcpyDeviceToHost));
+    dctx[0] = (desc & 0xFF0000FFu) | (tl << 16);                    // maxTableLog and the reserved byte stay the caller's (:150-152)
+    const u32 dNew = dctx[0];
+    HK(hipMemcpy(ddt.p, &dNew, 4, hipMemcpyHostToDevice));
+    if (hSize >= cSrcSize) return FSEHIP_ERROR(srcSize_wrong);
+    HK((hipError_t)FSEHIP_HUF_decompress4X1_usingDTable_batch(ddst.p, dstSize, nullptr, dstSize, (size_t*)dres.p, (const u8*)dsrc.p + hSize, cSrcSize - hSize, nullptr, cSrcSize - hSize,
+                                                              (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstSize ? r : dstSize, hipMemcpyDeviceToHost));
     return r;
 }
 extern "C" size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)   // huf_compress.c:795-798

@@ -3,15 +3,20 @@
 //
 // tANS decoding is one loop-carried chain per block (two interleaved states sharing one bit cursor; a simulation of
 // speculative starts shows that this two-state decoder does not re-synchronise within thousands of symbols, so unlike
-// the encoder it cannot be split), hence "one lane per block, as many blocks per CU as LDS holds":
-//   * a workgroup = 1 decoder wave + 4 service waves over G = 15 blocks (tableLog 11); 2 workgroups per CU;
-//   * the decoder lane of a block walks the chain touching registers and LDS only: u16 table cells, a 256-byte ring of
-//     compressed input, a ring of decoded states;
-//   * the service waves own all global-memory traffic of the bulk loop, wave-cooperative and coalesced: they refill the
-//     input rings and turn state-ring records into output bytes (symbol gathers from an L2-resident byte table);
-//   * the two sides talk through per-block control words in LDS (acquire/release, workgroup scope).
-// Throughput = blocks resident per CU (LDS capacity: 30 at tableLog 11) / latency of one iteration of the chain (two
-// dependent LDS lookups and the VALU ops between them; a lone wave also pays ~7 cycles per instruction it issues).
+// the encoder it cannot be split), hence "a lane pair per block, as many blocks per CU as LDS holds":
+//   * ONE workgroup per CU over all 160 KB of LDS: FSE_DEC_WAVES = 2 decoder waves + FSE_SRV_WAVES = 9 service waves (704 threads)
+//     over G = 33 blocks with 4 KiB tables (tableLog <= 11; 18 blocks with the 8 KiB tables of tableLog 12) -- 4944 bytes per block:
+//     the u16 table, a 64-entry ring of decoded states, a 256-byte ring of compressed input, 48 bytes of control words;
+//   * a block is walked by a PAIR of decoder lanes (lane A owns state 1, lane B state 2; wave 0 holds 17 pairs, wave 1 holds 16) that
+//     touch registers and LDS only: one ds_read fetches both states' cells, what the other lane needs moves through DPP;
+//   * the service waves (four blocks each) own all global-memory traffic of the bulk loop, wave-cooperative and coalesced: they
+//     refill the input rings (64-byte chunks requested one ahead) and turn state-ring records into output bytes (symbol gathers
+//     from an L2-resident byte table, 256-byte rows);
+//   * the two sides talk through per-block control words in LDS (acquire/release, workgroup scope); the rounds between two phases
+//     of 16 iterations are wave-uniform (a chain that cannot take a phase decodes on as a "zombie" inside its own LDS slot).
+// Throughput = blocks resident per CU (LDS capacity: 33 at tableLog 11) / latency of one iteration of the chain (two dependent
+// LDS look-ups and the VALU ops between them; a lone wave issues an instruction per ~7-8 cycles whatever its lane count, so the
+// loop is laid out for instruction count: ~33 instructions, ~230 cycles per 4 symbols).  DESIGN.md 4.3 / 4.3a.
 //
 // The kernel reproduces the reference's decoder state -- a 64-bit little-endian window at byte offset `at` plus a
 // consumed-bit count `used` (lib/bitstream.h:91-97) -- exactly, including on truncated / corrupt input:
@@ -332,6 +337,16 @@ DEV void fse_ring_put(u32* rg, int off, u32 w)
 // to ring offset (Stop - 4 - o) mod FSE_IN_RING (Stop = payload size rounded up to 4).  Either way ring byte x <-> payload
 // byte is a bijection on windows of FSE_IN_RING aligned-dword bytes, so the validLo protocol is the same.
 DEV void fse_ring_put_rev(u32* rg, int Sg, int off, u32 w) { fse_ring_put(rg, ((Sg + 3) & ~3) - 4 - off, __brev(w)); }
+// caller tables: the workgroup's slot of the symbol scratch goes back when the LAST of its waves is through with it -- the service waves
+// gather from it during the bulk, the decoder waves' literal tails read it after that (FseCellsRev / FseCellsCompact take their symbols
+// there), so every wave of the workgroup reports here once, after its last access (flagsSh[7] counts them), and the last one releases.
+DEV void fse_scratch_slot_done(const FseDecArgs& a, u32* flagsSh, int lane)
+{
+    if (lane == 0 && atomicAdd(&flagsSh[7], 1u) == FSE_SRV_WAVES + FSE_DEC_WAVES - 1) {
+        const u32 slot = flagsSh[6];
+        __hip_atomic_fetch_and(a.slotBitmap + (slot >> 5), ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 template <bool TIMED, bool CALLER>
 DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev, u32* flagsSh)
 {
@@ -451,11 +466,7 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
         TIMING(const unsigned long long sB = __builtin_readcyclecounter(); sBusy += sB - sA; sA = sB; ++nBusy;);
     }
     TIMING(if (lane == 0 && g0 == 0) { atomicAdd(&g_decTiming[5], sBusy); atomicAdd(&g_decTiming[6], sIdle); });
-    // caller tables: the last service wave to finish hands the workgroup's slot of the symbol scratch back (only service waves read it)
-    if (CALLER && lane == 0 && atomicAdd(&flagsSh[7], 1u) == FSE_SRV_WAVES - 1) {
-        const u32 slot = flagsSh[6];
-        __hip_atomic_fetch_and(a.slotBitmap + (slot >> 5), ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (CALLER) fse_scratch_slot_done(a, flagsSh, lane);
 }
 
 // cell access of the literal path: reference-layout cells in global memory, or LDS cells + global symbol bytes
@@ -1009,11 +1020,9 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     const u32 sOther = dpp_swap(bs.s);               // (all lanes of the wave are still here)
     const unsigned long long tBulk1 = tA;
     (void)tBulk1;
-    if (!owner || half) {
-        // (lane 1 leaves here at once: the wave itself lives until its even lanes are through their tails, so the wave's lifetime is
-        //  taken by lane 0, below, when it has a block; workgroups whose slot 0 is empty are rare and not counted)
-        return;
-    }
+    // (the odd lanes and the pairs without a block have nothing left to do; the wave lives until its even lanes are through their tails.
+    //  No early return: with caller tables the wave reports below, as a whole, when its last tail has read the symbol scratch.)
+    if (owner && !half) {
     op = 4 * (long)iters;
     if (iters) {                                     // back to the reference's (ptr, bitsConsumed, container)
         const u32 B = 8u * (bs.q + 8u) + bs.bq - 8u * inA;      // back to bits of the payload proper
@@ -1037,6 +1046,8 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     a.results[b] = result;
     TIMING(if (lane == 0) { const unsigned long long tE = __builtin_readcyclecounter(); atomicAdd(&g_decTiming[11], tE - tBorn); atomicAdd(&g_decTiming[12], wall_clock64() - wBorn);
                             atomicAdd(&g_decTiming[14], tE - tBulk1); });
+    }
+    if (CALLER) fse_scratch_slot_done(a, flagsSh, lane);        // (all lanes of the wave are here again: its tails are done)
 }
 
 static void fse_decode_geometry(unsigned ldsLog, size_t ldsBytes, unsigned* slotU32, int* G)

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(64) void k_hist(HistArgs a)
     const u8* const p = view_ptr(a.src, b);
     const size_t n = view_size(a.src, b);
     const unsigned limitIn = (a.maxSVs && !a.useUniformIn) ? a.maxSVs[b] : a.uniformMaxSV;
-    const bool checked = limitIn < 255u;                    // lib/hist.c:169
-    const unsigned nOut = checked ? limitIn + 1u : 256u;    // entries the reference writes (hist.c:74,130)
+    const bool checked = limitIn < 255u && !a.trustInput;   // lib/hist.c:169 (HIST_countFast: trustInput, :141-159)
+    const unsigned nOut = limitIn < 255u ? limitIn + 1u : 256u;    // entries the reference writes (hist.c:74,130)
 
     // totals of the four symbols this lane owns: lane, lane+64, lane+128, lane+192
     u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;

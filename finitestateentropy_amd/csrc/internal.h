@@ -8,6 +8,7 @@ struct HistArgs {
     unsigned* maxSVs;            // in/out per block, or nullptr (255 in)
     unsigned uniformMaxSV;       // used when maxSVs == nullptr or useUniformIn
     int useUniformIn;            // 1: limit = uniformMaxSV for every block, maxSVs (if any) is output only
+    int trustInput = 0;          // 1: HIST_countFast (lib/hist.c:141-159): a limit below 255 only bounds the entries written, symbols above it are not an error
     size_t* results;
     BlockView src;
     size_t nBlocks;

@@ -65,6 +65,12 @@ FSEHIP_API const char* FSEHIP_getErrorName(size_t code);    /* FSE_getErrorName 
 #define FSEHIP_FSE_COMPRESSBOUND(size) (FSEHIP_FSE_NCOUNTBOUND + FSEHIP_FSE_BLOCKBOUND(size))
 #define FSEHIP_FSE_CTABLE_SIZE_U32(maxTableLog, maxSymbolValue) (1 + (1 << ((maxTableLog)-1)) + (((maxSymbolValue) + 1) * 2))
 #define FSEHIP_FSE_DTABLE_SIZE_U32(maxTableLog) (1 + (1 << (maxTableLog)))
+#define FSEHIP_FSE_WKSP_SIZE_U32(maxTableLog, maxSymbolValue) (FSEHIP_FSE_CTABLE_SIZE_U32(maxTableLog, maxSymbolValue) + (((maxTableLog) > 12) ? (1 << ((maxTableLog)-2)) : 1024))   /* lib/fse.h:314 */
+#define FSEHIP_HIST_WKSP_SIZE_U32 1024                                             /* lib/hist.h:38-39 */
+#define FSEHIP_HIST_WKSP_SIZE (FSEHIP_HIST_WKSP_SIZE_U32 * sizeof(unsigned))
+#define FSEHIP_HUF_WORKSPACE_SIZE ((6 << 10) + 256)                                /* lib/huf.h:93-94 */
+#define FSEHIP_HUF_WORKSPACE_SIZE_U32 (FSEHIP_HUF_WORKSPACE_SIZE / sizeof(uint32_t))
+#define FSEHIP_HUF_DECOMPRESS_WORKSPACE_SIZE (2 << 10)                             /* lib/huf.h:263 */
 #define FSEHIP_HUF_TABLELOG_MAX 12
 #define FSEHIP_HUF_TABLELOG_DEFAULT 11
 #define FSEHIP_HUF_BLOCKSIZE_MAX (128 * 1024)
@@ -83,6 +89,13 @@ typedef uint32_t FSEHIP_HUF_DTable;   /* lib/huf.h:144 */
 /* lib/hist.h:30  (semantics lib/hist.c:163-180) */
 FSEHIP_API size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize);
 
+/* lib/hist.h:46, :54.  The _wksp forms below are what the reference's own callers go through (SURVEY 8(b) "what calls it": fse_compress.c:652,
+ * huf_compress.c:672, huf_decompress.c:428).  Their workspaces are validated exactly as the reference validates them -- same checks, same order, same
+ * error codes -- and then left alone: every table and counter lives in device memory.  HIST_countFast is the unchecked variant: a limit below
+ * 255 bounds the entries written, larger symbols are counted into the result and *maxSymbolValuePtr but are no error (lib/hist.c:120-131). */
+FSEHIP_API size_t FSEHIP_HIST_count_wksp(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize, void* workSpace, size_t workSpaceSize);
+FSEHIP_API size_t FSEHIP_HIST_countFast(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize);
+
 /* lib/fse.h:174 */
 FSEHIP_API size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const FSEHIP_FSE_CTable* ct);
 /* lib/fse.h:247 */
@@ -91,6 +104,11 @@ FSEHIP_API size_t FSEHIP_FSE_decompress_usingDTable(void* dst, size_t dstCapacit
 FSEHIP_API size_t FSEHIP_FSE_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 FSEHIP_API size_t FSEHIP_FSE_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);
 FSEHIP_API size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize);
+/* lib/fse.h:315 (wkspSize in bytes against FSE_WKSP_SIZE_U32, as lib/fse_compress.c:646 compares them; a table log above 12 codes like 12,
+ * :340) and lib/fse.h:335 (maxLog honoured, limits above FSE_MAX_TABLELOG count as 12; `workSpace`, when given, receives the DTable the
+ * reference would have built there) */
+FSEHIP_API size_t FSEHIP_FSE_compress_wksp(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_FSE_decompress_wksp(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize, FSEHIP_FSE_DTable* workSpace, unsigned maxLog);
 
 /* lib/huf.h:290, :190 */
 FSEHIP_API size_t FSEHIP_HUF_compress1X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable);
@@ -108,6 +126,12 @@ FSEHIP_API size_t FSEHIP_HUF_decompress1X1_usingDTable(void* dst, size_t maxDstS
 FSEHIP_API size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 FSEHIP_API size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);
 FSEHIP_API size_t FSEHIP_HUF_decompress(void* dst, size_t originalSize, const void* cSrc, size_t cSrcSize);
+/* lib/huf.h:95, :289 (workSpace: 4-byte aligned, at least HUF_WORKSPACE_SIZE bytes -- GENERIC / workSpace_tooSmall otherwise, lib/huf_compress.c:654-655;
+ * the 1X form writes a single stream without jump table) and lib/huf.h:164 (dctx: a DTable whose descriptor holds the table-log limit, as
+ * HUF_CREATE_STATIC_DTABLEX1 leaves it; it receives the table read from the block's header, lib/huf_decompress.c:417-431) */
+FSEHIP_API size_t FSEHIP_HUF_compress4X_wksp(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_HUF_compress1X_wksp(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize, void* workSpace, size_t wkspSize);
 
 /* =================================================================================================
  *  Layer 2 -- batched, DEVICE pointers.  Block b lives at base + b*stride.  `d_sizes` may be
@@ -375,6 +399,13 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define HUF_decompress4X1_usingDTable FSEHIP_HUF_decompress4X1_usingDTable
 #define HUF_decompress1X_usingDTable FSEHIP_HUF_decompress1X_usingDTable
 #define HUF_decompress1X1_usingDTable FSEHIP_HUF_decompress1X1_usingDTable
+#define HIST_count_wksp FSEHIP_HIST_count_wksp
+#define HIST_countFast FSEHIP_HIST_countFast
+#define FSE_compress_wksp FSEHIP_FSE_compress_wksp
+#define FSE_decompress_wksp FSEHIP_FSE_decompress_wksp
+#define HUF_compress4X_wksp FSEHIP_HUF_compress4X_wksp
+#define HUF_compress1X_wksp FSEHIP_HUF_compress1X_wksp
+#define HUF_decompress4X1_DCtx_wksp FSEHIP_HUF_decompress4X1_DCtx_wksp
 #endif
 #ifdef FSEHIP_DROPIN_U16_NAMES       /* separate switch: programs/fuzzer.c declares FSE_countU16 with another (stale) prototype */
 #define FSE_countU16 FSEHIP_FSE_countU16

@@ -249,3 +249,39 @@ def test_huf_zero_filled_dtable_is_refused(hip, oracle):
     for fn in (hip.huf_decompress4x1_using_dtable_batch, hip.huf_decompress4x_using_dtable_batch):
         out, res = fn(payload, cres - 27, zero, 32768, max_table_log=12)
         assert (res.cpu().numpy() == -4).all(), res
+
+
+def test_fse_using_dtable_two_streams_and_stragglers(hip, checker):
+    """FSE_decompress_usingDTable over a batch keeps its symbol bytes in a per-workgroup slot of a library scratch (claimed when the workgroup
+    starts, handed back when its LAST wave -- service waves and the decoder waves' literal tails -- is through with it).  Two streams
+    running the call concurrently over ragged batches (32 KB blocks next to 200-byte ones: workgroup durations differ by orders of
+    magnitude, the tails of the short ones run while others claim slots) must not see each other's symbols."""
+    n = 6000
+    rng = np.random.default_rng(3)
+    sizes = np.where(rng.random(n) < 0.5, 32768, rng.integers(200, 2000, n)).astype(np.int64)
+    batches = []
+    for P, seed in ((14, 1), (80, 50001)):
+        src = hip.probagen_batch(P, n, 32768, first_seed=seed)
+        d_sizes = torch.from_numpy(sizes).cuda()
+        ct, hdr, hres = hip.fse_build_ctable_batch(src, table_log=11, sizes=d_sizes)
+        comp, cres = hip.fse_compress_using_ctable_batch(src, ct, max_table_log=11, sizes=d_sizes)
+        dt, dres = hip.fse_build_dtable_batch(hdr, hres, max_log=11)
+        assert (hres > 1).all() and (cres > 1).all()
+        batches.append((src, d_sizes, comp, cres, dt))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    reps = 6
+    # destinations made beforehand: nothing between the launches synchronises (the binding's guard check would)
+    outs = [[(torch.zeros((n, 32768), dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int64, device="cuda")) for _ in range(reps)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(reps):
+        for k, (src, d_sizes, comp, cres, dt) in enumerate(batches):
+            with torch.cuda.stream(streams[k]):
+                hip.fse_decompress_using_dtable_batch(comp, cres, dt, 32768, max_table_log=11, dst=outs[k][rep][0], results=outs[k][rep][1])
+    torch.cuda.synchronize()
+    col = torch.arange(32768, device="cuda").unsqueeze(0)
+    for k, (src, d_sizes, comp, cres, dt) in enumerate(batches):
+        mask = col < d_sizes.unsqueeze(1)
+        for out, res in outs[k]:
+            assert torch.equal(res, d_sizes), "stream %d: regenerated sizes differ" % k
+            assert torch.equal(torch.where(mask, out[:, :32768], torch.zeros_like(src)), torch.where(mask, src, torch.zeros_like(src))), "stream %d: bytes differ" % k

@@ -1,0 +1,161 @@
+"""The `_wksp` entry points the reference's own callers go through (SURVEY 8(b) "what calls it"; lib/fse.h:315,335, lib/huf.h:95,164,289,
+lib/hist.h:46,54) as drop-in names of libfsehip.so: same arguments into FSEHIP_<name> (device) and <name> of the compiled reference,
+same return value, same bytes -- including what the reference makes of a workspace that is too small or misaligned."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SZ, VP, U = C.c_size_t, C.c_void_p, C.c_uint
+
+
+def _p(a):
+    return a.ctypes.data_as(VP)
+
+
+def _both(hip, ref, name, *args):
+    """call FSEHIP_<name> and the reference's <name> with the same arguments (fresh copies of the array arguments for each side)"""
+    out = []
+    for lib, fname in ((hip.lib, "FSEHIP_" + name), (ref.lib, name)):
+        f = getattr(lib, fname)
+        f.restype = SZ
+        f.argtypes = None
+        live = [a.copy() if isinstance(a, np.ndarray) else a for a in args]
+        r = f(*[_p(a) if isinstance(a, np.ndarray) else a for a in live])
+        out.append((int(r), [a for a in live if isinstance(a, np.ndarray)]))
+    return out
+
+
+def _blocks(checker):
+    rng = np.random.default_rng(5)
+    blocks = [checker.probagen_batch(P, 1, n, 7 + i)[0] for i, (P, n) in enumerate(((14, 32768), (80, 32768), (2, 32768), (14, 4097), (50, 1500), (20, 1499), (14, 300), (90, 12)))]
+    blocks.append(np.full(5000, 7, np.uint8))                                   # one repeated byte -> 1
+    blocks.append(rng.integers(0, 256, 20000, dtype=np.uint8))                  # noise -> 0
+    blocks.append(np.zeros(1, np.uint8))
+    blocks.append((rng.integers(0, 2, 3000, dtype=np.uint8) * 131).astype(np.uint8))
+    return blocks
+
+
+def test_hist_wksp_and_fast(hip, ref, checker):
+    ws = np.zeros(1024 + 1, np.uint32)
+    for src in _blocks(checker):
+        for limit in (255, 254, 200, 131, 52, 6):
+            for name, extra in (("HIST_count_wksp", (ws, SZ(4096))), ("HIST_countFast", ())):
+                if name == "HIST_countFast" and src.size < 1500 and int(src.max()) > limit:
+                    continue                        # HIST_count_simple writes beyond count[] there (lib/hist.c:40): nothing to compare with
+                cnt = np.zeros(256 + 8, np.uint32)
+                msv = np.array([limit], np.uint32)
+                (rg, ag), (rr, ar) = _both(hip, ref, name, cnt, msv, src, SZ(src.size), *extra)
+                assert rg == rr, (name, src.size, limit, rg, rr)
+                if rg < (1 << 64) - 9:
+                    assert (ag[0] == ar[0]).all() and ag[1][0] == ar[1][0], (name, src.size, limit)
+    # the workspace checks of lib/hist.c:168-169, in their order
+    src = _blocks(checker)[0]
+    cnt, msv = np.zeros(256, np.uint32), np.array([255], np.uint32)
+    raw = np.zeros(4200, np.uint8)
+    for off, size in ((1, 4096), (0, 4095), (2, 100), (0, 0)):
+        view = raw[off:]
+        res = []
+        for lib, fname in ((hip.lib, "FSEHIP_HIST_count_wksp"), (ref.lib, "HIST_count_wksp")):
+            f = getattr(lib, fname)
+            f.restype = SZ
+            res.append(int(f(_p(cnt), _p(msv), _p(src), SZ(src.size), C.c_void_p(view.ctypes.data), SZ(size))))
+        assert res[0] == res[1] and res[0] > (1 << 64) - 9, (off, size, res)
+
+
+@pytest.mark.parametrize("table_log", [11, 12, 9, 5, 13, 15])
+def test_fse_compress_wksp(hip, ref, checker, table_log):
+    ws = np.zeros(40000, np.uint32)         # FSE_WKSP_SIZE_U32(15, 255) words and more: the reference really uses it
+    for src in _blocks(checker):
+        for msv in (255, 0, 52):
+            cap = src.size + (src.size >> 7) + 600
+            dst = np.zeros(cap + 8, np.uint8)
+            (rg, ag), (rr, ar) = _both(hip, ref, "FSE_compress_wksp", dst, SZ(cap), src, SZ(src.size), U(msv), U(table_log), ws, SZ(4 * ws.size))
+            assert rg == rr, (src.size, msv, table_log, rg, rr)
+            if 1 < rg < (1 << 64) - 9:
+                assert (ag[0][:rg] == ar[0][:rg]).all(), (src.size, msv, table_log)
+    # lib/fse_compress.c:646: wkspSize (bytes) against FSE_WKSP_SIZE_U32 -> tableLog_tooLarge
+    src = _blocks(checker)[0]
+    dst = np.zeros(40000, np.uint8)
+    need = 1 + (1 << (table_log - 1)) + 2 * 256 + ((1 << (table_log - 2)) if table_log > 12 else 1024)
+    for size in (need - 1, need, 0):
+        (rg, _), (rr, _) = _both(hip, ref, "FSE_compress_wksp", dst, SZ(40000), src, SZ(src.size), U(255), U(table_log), ws, SZ(size))
+        assert rg == rr, (table_log, size, rg, rr)
+
+
+def test_fse_decompress_wksp(hip, ref, checker):
+    for src in _blocks(checker):
+        for tl in (11, 12, 9):
+            r, comp = checker.fse_compress2(src, 255, tl)
+            if r <= 1 or r >= (1 << 63):
+                continue
+            comp = np.ascontiguousarray(comp[:r])
+            for max_log in (12, 11, 10, 9, 6, 5):
+                dt = np.zeros(1 + (1 << 12), np.uint32)
+                out = np.zeros(src.size + 8, np.uint8)
+                (rg, ag), (rr, ar) = _both(hip, ref, "FSE_decompress_wksp", out, SZ(src.size), comp, SZ(r), dt, U(max_log))
+                assert rg == rr, (src.size, tl, max_log, rg, rr)
+                if rg < (1 << 64) - 9:
+                    assert (ag[0][:rg] == src[:rg]).all() and (ar[0][:rg] == src[:rg]).all()
+                    h = int(ar[2][0]) & 0xFFFF
+                    assert (ag[2][:1 + (1 << h)] == ar[2][:1 + (1 << h)]).all(), "the DTable left in the workspace differs"
+            # truncated / damaged streams give the reference's verdicts
+            for cut in (r - 1, r // 2, 3, 1):
+                out = np.zeros(src.size + 8, np.uint8)
+                dt = np.zeros(1 + (1 << 12), np.uint32)
+                part = np.ascontiguousarray(comp[:cut])
+                (rg, _), (rr, _) = _both(hip, ref, "FSE_decompress_wksp", out, SZ(src.size), part, SZ(cut), dt, U(12))
+                assert rg == rr, (src.size, tl, cut, rg, rr)
+
+
+@pytest.mark.parametrize("name", ["HUF_compress4X_wksp", "HUF_compress1X_wksp"])
+def test_huf_compress_wksp(hip, ref, checker, name):
+    ws = np.zeros((6 << 10) // 4 + 64 + 1, np.uint32)
+    for src in _blocks(checker):
+        for msv, tl in ((255, 11), (0, 0), (255, 12), (200, 8), (255, 13), (256, 11)):
+            cap = src.size + (src.size >> 8) + 140
+            dst = np.zeros(cap + 8, np.uint8)
+            (rg, ag), (rr, ar) = _both(hip, ref, name, dst, SZ(cap), src, SZ(src.size), U(msv), U(tl), ws, SZ((6 << 10) + 256))
+            assert rg == rr, (name, src.size, msv, tl, rg, rr)
+            if 0 < rg < (1 << 64) - 9:
+                assert (ag[0][:rg] == ar[0][:rg]).all(), (name, src.size, msv, tl)
+    # lib/huf_compress.c:654-655: alignment first, then size
+    src = _blocks(checker)[0]
+    dst = np.zeros(40000, np.uint8)
+    raw = np.zeros(8000, np.uint8)
+    for off, size in ((1, 6400), (0, 6399), (2, 10), (0, 6400)):
+        res = []
+        for lib, fname in ((hip.lib, "FSEHIP_" + name), (ref.lib, name)):
+            f = getattr(lib, fname)
+            f.restype = SZ
+            res.append(int(f(_p(dst), SZ(40000), _p(src), SZ(src.size), U(255), U(11), C.c_void_p(raw[off:].ctypes.data), SZ(size))))
+        assert res[0] == res[1], (name, off, size, res)
+
+
+def test_huf_decompress4x1_dctx_wksp(hip, ref, checker):
+    ws = np.zeros(512, np.uint32)
+    for src in _blocks(checker):
+        for tl in (11, 12, 8):
+            r, comp = checker.huf_compress2(src, 255, tl)
+            if r <= 1 or r >= (1 << 63):
+                continue
+            comp = np.ascontiguousarray(comp[:r])
+            for max_tl in (12, 11, 9, 6):                         # HUF_CREATE_STATIC_DTABLEX1(DTable, max_tl): descriptor = (max_tl - 1) * 0x01000001
+                dctx = np.zeros(1 + (1 << 11), np.uint32)
+                dctx[0] = (max_tl - 1) * 0x01000001
+                out = np.zeros(src.size + 8, np.uint8)
+                (rg, ag), (rr, ar) = _both(hip, ref, "HUF_decompress4X1_DCtx_wksp", dctx, out, SZ(src.size), comp, SZ(r), ws, SZ(2048))
+                assert rg == rr, (src.size, tl, max_tl, rg, rr)
+                if rg < (1 << 64) - 9:
+                    assert (ag[1][:rg] == src[:rg]).all()
+                    htl = (int(ar[0][0]) >> 16) & 0xFF
+                    assert (ag[0][:1 + (1 << htl) // 2] == ar[0][:1 + (1 << htl) // 2]).all(), "the DTable left in dctx differs"
+            for cut, wsz in ((r - 1, 2048), (r // 2, 2048), (2, 2048), (r, 319), (r, 320)):
+                dctx = np.zeros(1 + (1 << 11), np.uint32)
+                dctx[0] = 11 * 0x01000001
+                out = np.zeros(src.size + 8, np.uint8)
+                part = np.ascontiguousarray(comp[:cut])
+                (rg, _), (rr, _) = _both(hip, ref, "HUF_decompress4X1_DCtx_wksp", dctx, out, SZ(src.size), part, SZ(cut), ws, SZ(wsz))
+                assert rg == rr, (src.size, tl, cut, wsz, rg, rr)
