@@ -73,7 +73,8 @@ def parse():
     ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
     ap.add_argument("--parity-blocks", type=int, default=0, help="blocks whose encoder bytes are compared with the CPU reference, untimed (0 = every block of the "
                                                                  "headline and of configs 2-4; the mixed 1M-block configurations use --cfg5-parity-blocks)")
-    ap.add_argument("--cfg5-parity-blocks", type=int, default=65536, help="strided blocks per codec of the config-5 records compared with the CPU reference")
+    ap.add_argument("--cfg5-parity-blocks", type=int, default=0, help="blocks per codec of the config-5 records compared with the CPU reference: 0 = ALL of them "
+                                                                      "(chunked and untimed; the default), N = a strided sample of N")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pinned-host H2D + kernels + D2H figure")
     ap.add_argument("--plain", action="store_true", help="profiler runs (scripts/profile.sh): warm-up + timed steps only -- no event-probe pass, no instrumented "
                                                           "decode pass, no host-inclusive / CPU legs -- so that every kernel is launched exactly warmup + steps times")
@@ -285,11 +286,19 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
             from oracle.oracle import Ref
             if Ref.available():
                 ref = Ref()
-                ch, rh = cdst[:distinct:4].cpu().numpy(), cres[:distinct:4].cpu().numpy()
+                # every DISTINCT block against the reference's bytes (the corpus tiles them); the tiles against the first one on the device
+                ch, rh = cdst[:distinct].cpu().numpy(), cres[:distinct].cpu().numpy()
                 for b in range(len(rh)):
-                    rr, rout = ref.fse_compress_u16(host[4 * b], 0, 0)
-                    assert rr == int(rh[b]) and (rout[:rr] == ch[b][:rr]).all(), "u16 encode differs from the reference (block %d)" % (4 * b)
-                parity += "+reference-bytes-%d-blocks" % len(rh)
+                    rr, rout = ref.fse_compress_u16(host[b], 0, 0)
+                    assert rr == int(rh[b]) and (rout[:rr] == ch[b][:rr]).all(), "u16 encode differs from the reference (block %d)" % b
+                nd = min(distinct, n_blocks)
+                assert torch.equal(cres, cres[:nd].repeat((n_blocks + nd - 1) // nd)[:n_blocks]), "u16 encode: tiled blocks give different sizes"
+                cols = torch.arange(cdst.shape[1], device=dev)[None, :]
+                for lo in range(0, n_blocks, 4096):
+                    hi = min(lo + 4096, n_blocks)
+                    first = cdst[torch.arange(lo, hi, device=dev) % nd]
+                    assert not bool(((cdst[lo:hi] != first) & (cols < cres[lo:hi, None])).any()), "u16 encode: tiled blocks give different bytes"
+                parity += "+reference-bytes-all-%d-distinct-blocks(tiled-to-%d-and-compared-on-device)" % (len(rh), n_blocks)
         except OSError:
             parity += "(checker unavailable)"
     barrier()
@@ -914,11 +923,15 @@ def with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, bar
             packed_out = [torch.empty(total * BLOCK, dtype=torch.uint8, device=dev) for _ in cds5]
             offsets_out = [torch.empty(total + 1, dtype=torch.int64, device=dev) for _ in cds5]
         ptimes, stats, pok = [], None, True
+        # a communicator of its own for the way back: RCCL runs the operations of one communicator on one stream, in order -- with one per
+        # direction the scatter of piece k + 1 and the gather of piece k - 1 are in flight together (created once, collectively)
+        import torch.distributed as dist
+        back_group = dist.new_group() if world > 1 and dist.get_backend() == "nccl" else None
         for p in range(args.comm_passes + 1):
             barrier()
             t0 = time.perf_counter()
             mine, packed_g, stats = shard.sharded_codec_job_pipelined(corpus, total, BLOCK, rank, world, dev, cds5, compact_fn, pieces=args.comm_pieces,
-                                                                      shard_out=shard_out, packed_out=packed_out, offsets_out=offsets_out)
+                                                                      shard_out=shard_out, packed_out=packed_out, offsets_out=offsets_out, gather_group=back_group)
             barrier()
             t = reduce_max([time.perf_counter() - t0])[0]
             if p == 0:                                            # untimed pass: every rank's round trip, and the root decodes what it gathered
@@ -943,8 +956,10 @@ def with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, bar
                 "pieces_per_shard": args.comm_pieces, "roundtrip_ok": bool(pokv),
                 "scatter_bytes": stats["scatter_bytes"], "gather_bytes": stats["gather_bytes"], "payload_bytes": stats["payload_bytes"],
                 "fixed_stride_gather_bytes": (total - n) * sum(cd.cap + 8 for cd in cds5) if rank == 0 else 0,
-                "what": "the same job in %d pieces per shard, transfers posted without waiting (scatter of piece k + 1, codecs of piece k, gather of piece k - 1 "
-                        "overlap); the gather ships the packed records of FSEHIP_compact_batch -- every block at its real size, sizes exchanged first -- "
+                "what": "the same job in %d pieces per shard: scatter of piece k + 1, codecs of piece k and gather of piece k - 1 overlap -- transfers are posted "
+                        "and waited for on two side streams (one per direction, each direction a communicator of its own), the compute stream waits only for the "
+                        "arrival of its next piece and joins the side streams once at the end, the packed sizes travel as host integers over a gloo side "
+                        "group; the gather ships the packed records of FSEHIP_compact_batch -- every block at its real size, sizes exchanged first -- "
                         "plus 8 bytes per record offset; on the untimed pass the root decodes the gathered packed streams where they lie and compares them "
                         "with the corpus" % args.comm_pieces}
         del packed_out, offsets_out

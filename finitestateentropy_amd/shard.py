@@ -8,9 +8,100 @@ Both use fixed-stride slots like the reference bench's output buffers (programs/
 point-to-point transfer per peer so that a root drives its xGMI links concurrently (a star, not a ring).
 
 Everything here is backend-agnostic (`gloo` on CPU tensors in the tests, `nccl`/RCCL on device tensors).
+
+Streams (the pipelined job, RCCL semantics): a transfer posted with `dist.batch_isend_irecv` starts after the work already queued on the
+stream that is CURRENT when it is posted, and `Work.wait()` makes the CURRENT stream wait for it (the host does not block).  The
+pipelined job therefore posts and waits for its transfers on two side streams ("lanes": one per direction) that depend on the compute
+stream only through events -- the compute stream itself waits for exactly one thing per piece, the arrival of that piece's raw blocks --
+and exchanges the packed sizes as HOST integers over a gloo side group, so that nothing between "codecs of piece k queued" and "gather
+of piece k - 1 posted" drains the compute stream.  The few stream / event / process-group calls sit behind the `_`-prefixed functions
+below so that tests/test_shard_streams.py can swap them for recorders and check the order of what is issued without a GPU.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
+
+
+# ---- stream plumbing: no-ops for CPU tensors
+def _is_cuda(device):
+    return torch.device(device).type == "cuda"
+
+
+def _new_stream(device, name):
+    """a side stream (`name` is for the recorders of the tests)"""
+    return torch.cuda.Stream(device) if _is_cuda(device) else None
+
+
+def _on(stream):
+    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+
+def _record_event(device, what):
+    """an event behind everything queued so far on the current stream"""
+    if not _is_cuda(device):
+        return None
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def _stream_wait_event(stream, ev):
+    if stream is not None and ev is not None:
+        stream.wait_event(ev)
+
+
+def _current_wait_event(ev):
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
+def _current_wait_stream(stream):
+    if stream is not None:
+        torch.cuda.current_stream().wait_stream(stream)
+
+
+def _host_wait_event(ev):
+    if ev is not None:
+        ev.synchronize()
+
+
+def _record_stream(t, stream):
+    """a tensor allocated on the compute stream is about to be used on `stream`: tell the caching allocator"""
+    if stream is not None and t is not None and t.is_cuda:
+        t.record_stream(stream)
+
+
+def _batch_p2p(ops, group):
+    """(kind, tensor, peer) triples -> one ncclGroupStart ... ncclGroupEnd of sends / receives; returns the requests"""
+    p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, group) for kind, t, peer in ops]
+    return dist.batch_isend_irecv(p2p) if p2p else []
+
+
+_HOST_GROUPS = {}
+
+
+def host_group(group=None):
+    """the process group the few HOST integers of the pipelined job travel over: `group` itself when it is gloo, else a gloo group over
+    the same ranks, created once (collectively: every rank of `group` gets here at the same point of the job) and kept"""
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = None if group is None else id(group)
+    if key not in _HOST_GROUPS:
+        ranks = None if group is None else dist.get_process_group_ranks(group)
+        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _HOST_GROUPS[key]
+
+
+def host_totals(value, world, hgroup):
+    """every rank's integer `value` on every rank, as python ints, over a host-side (gloo) group: the sizes that have to be known before
+    variable-length transfers can be posted ("size exchange") -- without touching a device stream"""
+    if world == 1:
+        return [int(value)]
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    out = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(out, t, group=hgroup)
+    return [int(x[0]) for x in out]
 
 
 def _staged(group=None):
@@ -19,28 +110,29 @@ def _staged(group=None):
     return dist.get_backend(group) == "gloo"
 
 
+def _stage_ops(ops, group):
+    """device tensors on a gloo group are staged through host memory (tests / two ranks sharing a GPU): returns (ops, landing copies)"""
+    if not _staged(group):
+        return list(ops), []
+    out, landing = [], []
+    for kind, t, peer in ops:
+        if kind == "send":
+            out.append((kind, t.cpu() if t.is_cuda else t, peer))
+        elif t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            landing.append((t, h))
+            out.append((kind, h, peer))
+        else:
+            out.append((kind, t, peer))
+    return out, landing
+
+
 def _grouped(ops, group=None):
     """Issue a list of (kind, tensor, peer) transfers as ONE group and wait for all of them: `dist.batch_isend_irecv` is
     ncclGroupStart ... ncclGroupEnd on RCCL, so a root's transfers to / from its peers are in flight together and its
     xGMI links run concurrently instead of one after the other.  Transfers between one pair of ranks match in list order on both
     sides.  Device tensors on a gloo group are staged through host memory (tests / two ranks sharing a GPU)."""
-    if not ops:
-        return
-    stage = _staged(group)
-    p2p, landing = [], []
-    for kind, t, peer in ops:
-        if kind == "send":
-            p2p.append(dist.P2POp(dist.isend, t.cpu() if (t.is_cuda and stage) else t, peer, group))
-        elif t.is_cuda and stage:
-            h = torch.empty(t.shape, dtype=t.dtype)
-            landing.append((t, h))
-            p2p.append(dist.P2POp(dist.irecv, h, peer, group))
-        else:
-            p2p.append(dist.P2POp(dist.irecv, t, peer, group))
-    for q in dist.batch_isend_irecv(p2p):
-        q.wait()
-    for t, h in landing:
-        t.copy_(h)
+    _finish(_post(ops, group))
 
 
 def shard_range(n_blocks, rank, world):
@@ -102,22 +194,12 @@ def gather_blocks(slots_mine, sizes_mine, n_blocks, rank, world, root=0, group=N
 
 
 def _post(ops, group=None):
-    """like _grouped, but returns at once: (requests, landing copies to make after they complete).  With RCCL a request's wait() makes the
-    current stream wait for the transfer (no host block), so compute queued before the wait overlaps the transfers in flight."""
+    """like _grouped, but returns at once: (requests, landing copies to make after they complete).  With RCCL the transfers start behind
+    what is queued on the CURRENT stream and a request's wait() makes the CURRENT stream wait for the transfer (no host block)."""
     if not ops:
         return [], []
-    stage = _staged(group)
-    p2p, landing = [], []
-    for kind, t, peer in ops:
-        if kind == "send":
-            p2p.append(dist.P2POp(dist.isend, t.cpu() if (t.is_cuda and stage) else t, peer, group))
-        elif t.is_cuda and stage:
-            h = torch.empty(t.shape, dtype=t.dtype)
-            landing.append((t, h))
-            p2p.append(dist.P2POp(dist.irecv, h, peer, group))
-        else:
-            p2p.append(dist.P2POp(dist.irecv, t, peer, group))
-    return dist.batch_isend_irecv(p2p), landing
+    staged, landing = _stage_ops(ops, group)
+    return _batch_p2p(staged, group), landing
 
 
 def _finish(posted):
@@ -128,31 +210,19 @@ def _finish(posted):
         t.copy_(h)
 
 
-def all_totals(value, device, world, group=None):
-    """every rank's int64 `value` on every rank (a list of python ints): the sizes that have to be known before variable-length
-    transfers can be posted ("size exchange: ncclAllGather of one uint64")"""
-    if world == 1:
-        return [int(value)]
-    stage = _staged(group)
-    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if stage else device)
-    out = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    return [int(x.item()) for x in out]
-
-
-def _total_later(offsets):
+def _total_later(offsets, device):
     """the packed size offsets[-1] as a host integer, without draining the stream: a non-blocking copy into pinned memory and an event
     recorded behind it now, the wait when the value is asked for (by then the device is busy with the next piece)"""
-    if not offsets.is_cuda:
-        return lambda: int(offsets[-1].item())
-    host = torch.empty(1, dtype=torch.int64).pin_memory()
-    host.copy_(offsets[-1:], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    if offsets.is_cuda:
+        host = torch.empty(1, dtype=torch.int64).pin_memory()
+        host.copy_(offsets[-1:], non_blocking=True)
+    else:
+        host = offsets[-1:]
+    ev = _record_event(device, "total")
 
     def ready():
-        ev.synchronize()
-        return int(host.item())
+        _host_wait_event(ev)
+        return int(host[0])
     return ready
 
 
@@ -203,40 +273,55 @@ def post_gather_packed(packed_mine, offsets_mine, total_mine, totals, rows, rank
 
 
 def sharded_codec_job_pipelined(corpus_root, n_blocks, block_bytes, rank, world, device, codecs, compact_fn, pieces=4, root=0, group=None,
-                                shard_out=None, packed_out=None, offsets_out=None):
+                                shard_out=None, packed_out=None, offsets_out=None, gather_group=None):
     """BASELINE config 5 with the corpus on one rank, PIPELINED and with variable-length results: every rank's shard is cut into `pieces`
-    contiguous pieces; the root's scatter of piece k + 1, every rank's codecs on piece k and the gather of piece k - 1 overlap (transfers
-    are posted without waiting; with RCCL they run on the communicator's streams beside the compute stream).  What travels back is not
-    fixed-stride slots but the packed records of FSEHIP_compact_batch plus their offsets: `compact_fn(codec_piece, src_piece) ->
-    (packed uint8, offsets int64 (rows + 1))`; before a gather the ranks exchange their packed sizes (one int64 each).
+    contiguous pieces; the root's scatter of piece k + 1, every rank's codecs on piece k and the gather of piece k - 1 overlap.  What
+    travels back is not fixed-stride slots but the packed records of FSEHIP_compact_batch plus their offsets: `compact_fn(codec_piece,
+    src_piece) -> (packed uint8, offsets int64 (rows + 1))`; before a gather the ranks exchange their packed sizes (one integer each).
     `codecs`: objects with .piece(lo, hi) -> an object for rows [lo, hi) of this rank's shard with .src (assignable), .encode(), .decode(),
     .dst, .res, .out, .dres.  Returns (my shard, [(packed, offsets) per codec on the root | (None, None)], stats) where offsets has
     n_blocks + 1 entries (global block order inside every piece round: pieces are gathered rank after rank) and stats counts the bytes
-    the root moved: scatter_bytes, gather_bytes, payload_bytes."""
+    the root moved: scatter_bytes, gather_bytes, payload_bytes.
+
+    Who waits for what (module docstring): three streams per rank -- the caller's COMPUTE stream (codecs, compaction), a SCATTER lane
+    and a GATHER lane.  Transfers are posted and waited for on their lane; the lanes take their dependencies from the compute stream
+    as events (scatter lane: the start of the job; gather lane: "piece k compacted"), the compute stream from the scatter lane ("piece
+    k has landed") and, once at the end, joins both lanes.  The packed sizes travel as host integers over a gloo side group; the host
+    waits only for the event behind piece k - 1's compaction, after piece k's kernels are queued.  `gather_group`: a second process
+    group over the same ranks for the way back -- RCCL serialises the operations of one communicator on one stream, so with a
+    communicator per direction the scatter of piece k + 1 and the gather of piece k - 1 really run side by side (default: `group`)."""
     lo, hi = shard_range(n_blocks, rank, world)
     mine = shard_out if shard_out is not None else torch.empty((hi - lo, block_bytes), dtype=torch.uint8, device=device)
     ranges = [piece_ranges(*shard_range(n_blocks, r, world), pieces) for r in range(world)]      # [rank][piece] -> global rows
     stats = {"scatter_bytes": 0, "gather_bytes": 0, "payload_bytes": 0}
+    ggroup = gather_group if gather_group is not None else group
+    hgroup = host_group(group) if world > 1 else None
+    lane_in, lane_out = _new_stream(device, "scatter"), _new_stream(device, "gather")
+    start = _record_event(device, "start")                            # whatever used these buffers before (an earlier pass) is behind this
+    _stream_wait_event(lane_in, start)
+    _stream_wait_event(lane_out, start)
 
     def post_scatter(k):
-        if world == 1:
-            g0, g1 = ranges[0][k]
-            mine[g0 - lo:g1 - lo].copy_(corpus_root[g0:g1])
-            return [], []
-        ops = []
-        if rank == root:
-            for r in range(world):
-                g0, g1 = ranges[r][k]
-                if r == root:
-                    mine[g0 - lo:g1 - lo].copy_(corpus_root[g0:g1])
-                elif g1 > g0:
-                    ops.append(("send", corpus_root[g0:g1], r))
-                    stats["scatter_bytes"] += (g1 - g0) * block_bytes
-        else:
-            g0, g1 = ranges[rank][k]
-            if g1 > g0:
-                ops.append(("recv", mine[g0 - lo:g1 - lo], root))
-        return _post(ops, group)
+        """piece k of every shard leaves the root, on the scatter lane; returns the event behind its arrival here"""
+        with _on(lane_in):
+            ops = []
+            if world == 1:
+                g0, g1 = ranges[0][k]
+                mine[g0 - lo:g1 - lo].copy_(corpus_root[g0:g1])
+            elif rank == root:
+                for r in range(world):
+                    g0, g1 = ranges[r][k]
+                    if r == root:
+                        mine[g0 - lo:g1 - lo].copy_(corpus_root[g0:g1])
+                    elif g1 > g0:
+                        ops.append(("send", corpus_root[g0:g1], r))
+                        stats["scatter_bytes"] += (g1 - g0) * block_bytes
+            else:
+                g0, g1 = ranges[rank][k]
+                if g1 > g0:
+                    ops.append(("recv", mine[g0 - lo:g1 - lo], root))
+            _finish(_post(ops, group))                                # (RCCL: the LANE waits, not the host)
+            return _record_event(device, "landed %d" % k)
 
     gathered = None
     if rank == root:
@@ -248,36 +333,41 @@ def sharded_codec_job_pipelined(corpus_root, n_blocks, block_bytes, rank, world,
     bases = [0] * len(codecs)                                       # bytes of every codec's packed stream gathered so far
     row_base = 0                                                    # rows of the packed order gathered so far
     order = []                                                      # global block index of every row of the packed order (root)
+    keep = []                                                       # per-piece tensors stay referenced until the lanes are joined
 
-    def gather_piece(k, packs):
-        """exchange sizes, post the variable-length transfers of piece k, finish them"""
+    def gather_piece(k, packs, compacted):
+        """exchange the sizes of piece k (host integers), then post its variable-length transfers, wait for them and rebase the offsets --
+        all on the gather lane, behind the event `compacted`"""
         nonlocal row_base
         rows, r0 = [], row_base
         for r in range(world):
             g0, g1 = ranges[r][k]
             rows.append((r0, r0 + (g1 - g0))); r0 += g1 - g0
-        fixes = []
-        for i, (packed, offsets, tot_ready) in enumerate(packs):
-            total = tot_ready()
-            totals = all_totals(total, device, world, group)
-            pk, of = gathered[i] if rank == root else (None, None)
-            posted, fix = post_gather_packed(packed, offsets, total, totals, rows, rank, world, pk, of, bases[i], root, group)
-            fixes.append((posted, fix, sum(totals)))
-        for i, (posted, fix, tot) in enumerate(fixes):
-            _finish(posted)
-            stats["gather_bytes"] += fix()
-            bases[i] += tot
-            stats["payload_bytes"] += tot
+        sized = []
+        for packed, offsets, tot_ready in packs:
+            total = tot_ready()                                      # host: waits for the event behind piece k's compaction only
+            sized.append((total, host_totals(total, world, hgroup)))
+        with _on(lane_out):
+            _stream_wait_event(lane_out, compacted)
+            for i, ((packed, offsets, _), (total, totals)) in enumerate(zip(packs, sized)):
+                _record_stream(packed, lane_out); _record_stream(offsets, lane_out)
+                pk, of = gathered[i] if rank == root else (None, None)
+                posted, fix = post_gather_packed(packed, offsets, total, totals, rows, rank, world, pk, of, bases[i], root, ggroup)
+                _finish(posted)                                      # (RCCL: the LANE waits, not the host and not the compute stream)
+                stats["gather_bytes"] += fix()
+                tot = sum(totals)
+                bases[i] += tot
+                stats["payload_bytes"] += tot
         if rank == root:
             for r in range(world):
                 order.extend(range(*ranges[r][k]))
         row_base = r0
 
-    posted_in = post_scatter(0)
-    pending = None                                                  # (piece, packs) whose gather has not been posted yet
+    landed = post_scatter(0)
+    pending = None                                                  # (piece, packs, event) whose gather has not been posted yet
     for k in range(pieces):
         nxt = post_scatter(k + 1) if k + 1 < pieces else None
-        _finish(posted_in)
+        _current_wait_event(landed)                                 # the one thing the compute stream waits for: its input
         g0, g1 = ranges[rank][k]
         packs = []
         for cd in codecs:
@@ -285,12 +375,16 @@ def sharded_codec_job_pipelined(corpus_root, n_blocks, block_bytes, rank, world,
             pc.src = mine[g0 - lo:g1 - lo]
             pc.encode(); pc.decode()
             packed, offsets = compact_fn(pc, pc.src)
-            packs.append((packed, offsets, _total_later(offsets)))
+            packs.append((packed, offsets, _total_later(offsets, device)))
+        compacted = _record_event(device, "compacted %d" % k)
+        keep.append(packs)
         if pending is not None:
             gather_piece(*pending)                                  # (its sizes are long known: the device is busy with piece k meanwhile)
-        pending = (k, packs)
-        posted_in = nxt
+        pending = (k, packs, compacted)
+        landed = nxt
     gather_piece(*pending)
+    _current_wait_stream(lane_in)
+    _current_wait_stream(lane_out)                                  # the compute stream joins the lanes once, here
     if rank == root:
         for i in range(len(codecs)):
             gathered[i][1][n_blocks] = bases[i]

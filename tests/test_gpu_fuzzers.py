@@ -35,13 +35,14 @@ def test_reference_huff0_fuzzer_on_device(hip):
     assert "Error" not in out, out[-2000:]
 
 
-@pytest.mark.parametrize("case", [1, 7, 9, 13, 14, 20, 23, 30, 42])
+@pytest.mark.parametrize("case", [1, 2, 3, 7, 8, 9, 13, 14, 20, 23, 30, 33, 42, 46])
 def test_reference_fullbench_on_device(hip, case):
     """programs/fullbench.c (the reference's per-function speed analyzer; `make test` runs `fullbench -i1`, programs/Makefile:135-139) bound
-    to the device like the fuzzers: one timed round of the cases whose function is a hot-path call of libfsehip.so -- 1 HIST_count, 7
-    FSE_compress_usingCTable, 9 FSE_compress, 13 FSE_decompress_usingDTable, 14 FSE_decompress, 20 HUF_compress, 23
-    HUF_compress4x_usingCTable, 30 HUF_decompress, 42 HUF_decompress4X1_usingDTable (programs/fullbench.c:758-771,805-814,851-862,
-    897-905,987-998).  The program prints MB/s and the function's return value; a call that failed shows as an error code there, and the
+    to the device like the fuzzers: one timed round of the cases whose function is a hot-path call of libfsehip.so -- 1 / 2 HIST_count with
+    limits 255 / 254, 3 HIST_countFast(254), 7 FSE_compress_usingCTable, 8 the same into FSE_BLOCKBOUND - 1 bytes (the careful path,
+    programs/fullbench.c:606-610,816-826), 9 FSE_compress, 13 FSE_decompress_usingDTable, 14 FSE_decompress, 20 HUF_compress, 23
+    HUF_compress4x_usingCTable, 30 HUF_decompress, 33 HUF_decompress4X_usingDTable on the reference's double-symbol table (:954-965), 42
+    HUF_decompress4X1_usingDTable, 46 HUF_decompress1X1_usingDTable (:1027-1043) (programs/fullbench.c:758-771,805-826,851-862,897-905,987-998).  The program prints MB/s and the function's return value; a call that failed shows as an error code there, and the
     setup of the decode cases (reference compressor -> device decoder) only works if the formats agree."""
     import re
     out = _run("fullbench-mi355x", "-i1", "-b%d" % case)
@@ -51,5 +52,5 @@ def test_reference_fullbench_on_device(hip, case):
     assert speed > 0
     # the return value the program shows: sizes (HIST_count: the largest count; compressors: compressed size; decompressors: 32768)
     assert 0 < code < (1 << 31) - 16, out[-600:]
-    if case in (13, 14, 30, 42):
+    if case in (13, 14, 30, 33, 42, 46):
         assert code == 32768, out[-600:]
