@@ -54,3 +54,11 @@ def test_reference_fullbench_on_device(hip, case):
     assert 0 < code < (1 << 31) - 16, out[-600:]
     if case in (13, 14, 30, 33, 42, 46):
         assert code == 32768, out[-600:]
+
+
+def test_host_threads_driver_against_reference(hip):
+    """tests/host/san_driver.c on the product library: four host threads through the calls on host pointers (per-thread scratch arenas,
+    FSEHIP_releaseScratch), the _wksp names, then frames over the library's own thread pool -- every result byte for byte against the
+    reference linked beside it.  scripts/sanitize.sh runs the same program on the -fsanitize=address,undefined build of the library."""
+    out = _run("san_driver", "4", "6")
+    assert "san_driver OK" in out, out[-2000:]

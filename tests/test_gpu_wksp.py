@@ -2,6 +2,7 @@
 lib/hist.h:46,54) as drop-in names of libfsehip.so: same arguments into FSEHIP_<name> (device) and <name> of the compiled reference,
 same return value, same bytes -- including what the reference makes of a workspace that is too small or misaligned."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -23,6 +24,8 @@ def _both(hip, ref, name, *args):
         f.restype = SZ
         f.argtypes = None
         live = [a.copy() if isinstance(a, np.ndarray) else a for a in args]
+        if os.environ.get("FSEHIP_TEST_TRACE"):
+            print(fname, [a.shape if isinstance(a, np.ndarray) else a.value for a in live], flush=True)
         r = f(*[_p(a) if isinstance(a, np.ndarray) else a for a in live])
         out.append((int(r), [a for a in live if isinstance(a, np.ndarray)]))
     return out
@@ -65,11 +68,15 @@ def test_hist_wksp_and_fast(hip, ref, checker):
         assert res[0] == res[1] and res[0] > (1 << 64) - 9, (off, size, res)
 
 
-@pytest.mark.parametrize("table_log", [11, 12, 9, 5, 13, 15])
+@pytest.mark.parametrize("table_log", [11, 12, 9, 13, 15])
 def test_fse_compress_wksp(hip, ref, checker, table_log):
+    """(Only calls the reference defines: FSE_compress_wksp carves its CTable out of the workspace at FSE_CTABLE_SIZE_U32(tableLog,
+    maxSymbolValue) of the arguments AS PASSED (lib/fse_compress.c:640-642), so maxSymbolValue 0 ("default") or a tableLog that
+    FSE_optimalTableLog has to raise (below highbit(maxSymbolValue) + 2) make FSE_buildCTable_wksp write into its own scratch -- the
+    reference crashed on exactly that here.  FSE_compress2, which owns a full-size workspace, is where those arguments are compared.)"""
     ws = np.zeros(40000, np.uint32)         # FSE_WKSP_SIZE_U32(15, 255) words and more: the reference really uses it
     for src in _blocks(checker):
-        for msv in (255, 0, 52):
+        for msv in (255, 52):
             cap = src.size + (src.size >> 7) + 600
             dst = np.zeros(cap + 8, np.uint8)
             (rg, ag), (rr, ar) = _both(hip, ref, "FSE_compress_wksp", dst, SZ(cap), src, SZ(src.size), U(msv), U(table_log), ws, SZ(4 * ws.size))
