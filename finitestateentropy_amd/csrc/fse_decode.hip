@@ -211,6 +211,18 @@ DEV u32 ring_dword(u32 P) { u32 r; __asm__("v_bfe_u32 %0, %1, 5, %2" : "=v"(r) :
 // Per 100k Proba14 blocks (decode call = dparse + dbuild + this kernel): compiler's schedule 11.59 ms; cell requested early, cell-only
 // work before the window wait 11.27; with the window requested one iteration ahead 10.72.
 #define SB __builtin_amdgcn_sched_barrier(0)
+// Measurement aid (EXPERIMENTS.md, "what a smaller table cell may cost"): FSE_EXTRA_CHAIN_OPS dependent no-op VALU instructions behind every
+// next-state computation -- the slope ms per instruction on the chain, against which any cell format that saves LDS but adds work
+// between a cell's arrival and the next request has to be weighed.  0 in the product.
+#ifndef FSE_EXTRA_CHAIN_OPS
+#define FSE_EXTRA_CHAIN_OPS 0
+#endif
+DEV u32 fse_chain_pad(u32 s)
+{
+#pragma unroll
+    for (int i = 0; i < FSE_EXTRA_CHAIN_OPS / 2; ++i) __asm__ volatile("v_xor_b32 %0, 1, %0\n\tv_xor_b32 %0, 1, %0" : "+v"(s));
+    return s;
+}
 template <int NITER>
 DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
 {
@@ -232,7 +244,7 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
         __asm__ volatile("" : "+v"(lo), "+v"(hi));
         SB;
         const u32 sStart = s;
-        s = lshl_or(__builtin_amdgcn_ubfe(lo, dpp_swap_and(c, maskB), c), K - c, (c >> cellShift) | tabOff);
+        s = fse_chain_pad(lshl_or(__builtin_amdgcn_ubfe(lo, dpp_swap_and(c, maskB), c), K - c, (c >> cellShift) | tabOff));
         const u32 c2 = lds_cell(s);
         SB;
         const u32 n1 = dpp_swap_add(c, c);
@@ -247,7 +259,7 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
         __asm__ volatile("" : "+v"(lo2), "+v"(rec));
         if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
         SB;
-        s = lshl_or(__builtin_amdgcn_ubfe(lo2, dpp_swap_and(c2, maskB), c2), K - c2, (c2 >> cellShift) | tabOff);
+        s = fse_chain_pad(lshl_or(__builtin_amdgcn_ubfe(lo2, dpp_swap_and(c2, maskB), c2), K - c2, (c2 >> cellShift) | tabOff));
         if (it + 1 < NITER) c = lds_cell(s);
         SB;
         const u32 n2 = dpp_swap_add(c2, c2);
