@@ -22,7 +22,8 @@
 #define CP_THREADS 256
 #define CP_PER_WG 1024
 
-DEV u64 cp_len(size_t r, size_t n) { return is_err(r) ? 0 : r == 0 ? (u64)n : r == 1 ? (n ? 1u : 0u) : (u64)r; }
+// (a result beyond the slot cannot have come from the call that filled these slots: no record, rather than a read behind the slot)
+DEV u64 cp_len(size_t r, size_t n, size_t slotStride) { return is_err(r) ? 0 : r == 0 ? (u64)n : r == 1 ? (n ? 1u : 0u) : r > slotStride ? 0 : (u64)r; }
 
 // inclusive scan over the 256 threads of a workgroup (u64), through LDS
 DEV u64 cp_wg_scan(u64 v, u64* sh, u32 tid)
@@ -38,7 +39,7 @@ DEV u64 cp_wg_scan(u64 v, u64* sh, u32 tid)
     return v + base;
 }
 
-__global__ __launch_bounds__(CP_THREADS) void k_compact_sums(const size_t* results, BlockView src, size_t nBlocks, u64* partials)
+__global__ __launch_bounds__(CP_THREADS) void k_compact_sums(const size_t* results, BlockView src, size_t nBlocks, u64* partials, size_t slotStride)
 {
     __shared__ u64 sh[4];
     const u32 tid = threadIdx.x;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_compact_sums(const size_t* resul
     u64 sum = 0;
     for (u32 k = 0; k < CP_PER_WG / CP_THREADS; ++k) {
         const size_t b = b0 + tid + (size_t)k * CP_THREADS;
-        if (b < nBlocks) sum += cp_len(results[b], view_size(src, b));
+        if (b < nBlocks) sum += cp_len(results[b], view_size(src, b), slotStride);
     }
     const u64 incl = cp_wg_scan(sum, sh, tid);
     if (tid == CP_THREADS - 1) partials[blockIdx.x] = incl;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_compact_scan_groups(u64* partial
     if (tid == 0) partials[nGroups] = carry;
 }
 
-__global__ __launch_bounds__(CP_THREADS) void k_compact_offsets(const size_t* results, BlockView src, size_t nBlocks, const u64* partials, u64* offsets, u32 nGroups)
+__global__ __launch_bounds__(CP_THREADS) void k_compact_offsets(const size_t* results, BlockView src, size_t nBlocks, const u64* partials, u64* offsets, u32 nGroups, size_t slotStride)
 {
     __shared__ u64 sh[4];
     __shared__ u64 carry;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_compact_offsets(const size_t* re
     __syncthreads();
     for (u32 k = 0; k < CP_PER_WG / CP_THREADS; ++k) {
         const size_t b = b0 + tid + (size_t)k * CP_THREADS;
-        const u64 v = b < nBlocks ? cp_len(results[b], view_size(src, b)) : 0;
+        const u64 v = b < nBlocks ? cp_len(results[b], view_size(src, b), slotStride) : 0;
         const u64 incl = cp_wg_scan(v, sh, tid);
         const u64 c = carry;
         if (b < nBlocks) offsets[b] = c + incl - v;
@@ -126,9 +127,9 @@ hipError_t launch_compact(u8* packed, size_t packedCapacity, u64* offsets, const
 {
     const u32 nGroups = (u32)((nBlocks + CP_PER_WG - 1) / CP_PER_WG);
     if (nBlocks == 0) { hipLaunchKernelGGL(k_compact_scan_groups, dim3(1), dim3(CP_THREADS), 0, s, offsets, 0u); return hipGetLastError(); }   // offsets[0] = 0
-    hipLaunchKernelGGL(k_compact_sums, dim3(nGroups), dim3(CP_THREADS), 0, s, results, src, nBlocks, partials);
+    hipLaunchKernelGGL(k_compact_sums, dim3(nGroups), dim3(CP_THREADS), 0, s, results, src, nBlocks, partials, slotStride);
     hipLaunchKernelGGL(k_compact_scan_groups, dim3(1), dim3(CP_THREADS), 0, s, partials, nGroups);
-    hipLaunchKernelGGL(k_compact_offsets, dim3(nGroups), dim3(CP_THREADS), 0, s, results, src, nBlocks, (const u64*)partials, offsets, nGroups);
+    hipLaunchKernelGGL(k_compact_offsets, dim3(nGroups), dim3(CP_THREADS), 0, s, results, src, nBlocks, (const u64*)partials, offsets, nGroups, slotStride);
     hipLaunchKernelGGL(k_compact_copy, dim3((unsigned)nBlocks), dim3(CP_THREADS), 0, s, packed, (u64)packedCapacity, (const u64*)offsets, slots, slotStride, results, src, nBlocks);
     return hipGetLastError();
 }

@@ -1088,7 +1088,7 @@ std::mutex g_symMutex;
 struct SymScratch { u8* base = nullptr; u32* bitmap = nullptr; u32 nSlots = 0; };
 SymScratch g_symScratch[64];
 }
-static hipError_t fse_sym_scratch(FseDecArgs& a)
+static hipError_t fse_sym_scratch(FseDecArgs& a, hipStream_t s)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1096,6 +1096,13 @@ static hipError_t fse_sym_scratch(FseDecArgs& a)
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lock(g_symMutex);
     SymScratch& sc = g_symScratch[dev];
+    if (!sc.base && s) {
+        // the first call on a device allocates (hipMalloc + a synchronous hipMemset): not something a stream capture survives.  A caller who
+        // captures runs one ordinary call first, as for every batched call (include/fsehip.h, "Streams and graphs"), or FSEHIP_prepareDevice().
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return hipErrorStreamCaptureUnsupported;
+        (void)hipGetLastError();
+    }
     if (!sc.base) {
         const u32 nSlots = 2u * (u32)(dev_props().ok ? dev_props().cus : 256);
         const size_t bitmapBytes = ((nSlots + 31u) / 32u * 4u + 255u) & ~(size_t)255;
@@ -1123,7 +1130,7 @@ static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
         if (e == hipSuccess) e = ensure_dyn_lds((const void*)k_fse_decode<true, true, false>, FSE_DEC_LDS);
         if (e == hipSuccess && caller) e = ensure_dyn_lds((const void*)k_fse_decode<true, false, true>, FSE_DEC_LDS);
         if (e == hipSuccess && caller) e = ensure_dyn_lds((const void*)k_fse_decode<false, false, true>, FSE_DEC_LDS);
-        if (e == hipSuccess && caller) e = fse_sym_scratch(a);
+        if (e == hipSuccess && caller) e = fse_sym_scratch(a, s);
         if (e != hipSuccess) return e;
     }
     fse_decode_geometry(a.ldsLog, ldsBytes, &a.slotU32, &a.G);
@@ -1143,6 +1150,15 @@ static hipError_t fse_decode_launch(FseDecArgs a, bool rev, hipStream_t s)
     else if (rev) hipLaunchKernelGGL((k_fse_decode<true, false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     else          hipLaunchKernelGGL((k_fse_decode<false, false, false>), dim3((unsigned)groups), dim3(FSE_DEC_THREADS), ldsBytes, s, a);
     return hipGetLastError();
+}
+
+// What the batched calls otherwise do at their first use on a device, done now: the library's one allocation on these paths (the symbol
+// scratch of FSE_decompress_usingDTable over a batch, 2 x CUs slots of 72 KB) -- for callers who want their first such call inside a
+// stream capture, or no allocation inside a timed region.  Idempotent; the scratch lives until the process ends.
+extern "C" __attribute__((visibility("default"))) int FSEHIP_prepareDevice(void)
+{
+    FseDecArgs a = FseDecArgs();
+    return (int)fse_sym_scratch(a, nullptr);
 }
 
 // enable = 1: zero the counters and send the bit-reversed classes through the TIMED kernel; enable = 0: back to the plain kernel and, if

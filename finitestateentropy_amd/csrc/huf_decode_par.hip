@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
             // ---- pass 2: my symbols again, stored sixteen at a time
             {   u8* p = out + (size_t)q * seg + outBase + (incl - n);
                 u32 left = n, C = S;
+#ifdef HPAR_NO_STORE
+                u32 dummyAcc = 0;
+#endif
                 while (left && ((uintptr_t)p & 3u)) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
                 if (left >= 16) {
                     HparBulk bk; bk.open(arr, C);
@@ -387,13 +390,20 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
                         u32 w[4];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) w[t] = bk.iter(tabOff, mask2);
+#ifdef HPAR_NO_STORE      // measurement aid (EXPERIMENTS.md): pass 2 without its 16-byte stores -- is the scattered store pattern what bounds the kernel?
+                        dummyAcc ^= w[0] ^ w[1] ^ w[2] ^ w[3];
+#else
                         __builtin_memcpy(p, w, 16);
+#endif
                         p += 16; left -= 16;
                     } while (left >= 16);
                     while (left >= 4) { const u32 w = bk.iter(tabOff, mask2); __builtin_memcpy(p, &w, 4); p += 4; left -= 4; }
                     C = bk.cursor();
                 }
                 while (left) { const u32 c = hpar_single(arr, C, tabOff, mask2); *p++ = (u8)(c >> 8); --left; }
+#ifdef HPAR_NO_STORE
+                if (dummyAcc == 0x12345u) *p = 0;
+#endif
             }
             outBase += total;
             Cstart = endC + 32u * mTop;

@@ -138,7 +138,7 @@ FSEHIP_API size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, vo
  *  NULL, in which case every block has `uniformSize` bytes.  `d_results[b]` receives exactly what
  *  the corresponding single-block reference call would return for block b.  `stream` is a
  *  hipStream_t (NULL = default stream).  Return value: 0 (hipSuccess) or a hipError_t.
- *  Launches are asynchronous on `stream`; the library never allocates on these paths.
+ *  Launches are asynchronous on `stream`; the library never allocates on these paths (one exception, made once per device: FSEHIP_prepareDevice below).
  *  Streams and graphs: a call is kernel launches on `stream` and nothing else -- no host synchronisation, no
  *  read-back (what one stage decides for the next travels in device-side lists inside the workspace), no
  *  memset or copy nodes -- so after one ordinary call (which sets the kernels' function attributes) the calls
@@ -273,6 +273,7 @@ FSEHIP_API int FSEHIP_HUF_readDTableX1_batch(FSEHIP_HUF_DTable* d_dtables, size_
  *              its first byte (d_results[b] == 1: :397-400) | nothing (d_results[b] an error code),
  * d_offsets[b] = where record b starts, d_offsets[nBlocks] = the packed size (nBlocks + 1 entries).  A device exclusive scan and one
  * coalesced copy; if the packed size exceeds packedCapacity the records that do not fit are not written and d_offsets[nBlocks] tells.
+ * d_results must be what the call that filled d_slots returned: a value above slotStride (it cannot have come from that call) yields no record.
  * FSEHIP_compact_batch_bound(nBlocks, blockSize) = nBlocks * blockSize always suffices for blocks of at most blockSize bytes.
  * The decoders of a packed batch read the records where they lie and tell the three kinds apart by size, as HUF_decompress itself does
  * (lib/huf_decompress.c:1063-1066): a record as long as the block is the block, a record of one byte that byte repeated, anything else
@@ -377,6 +378,13 @@ FSEHIP_API void FSEHIP_shardRange(size_t nBlocks, int rank, int world, size_t* f
  * FSEHIP_releaseScratch() gives the calling thread's arena back; a thread that exits without calling it leaves its arena to the
  * process teardown. */
 FSEHIP_API int FSEHIP_releaseScratch(void);
+
+/* The one allocation the batched calls make themselves: FSEHIP_FSE_decompress_usingDTable_batch (whose reference signature, lib/fse.h:247, has
+ * no workspace) keeps the symbol bytes of its tables in a per-device scratch of 2 x CUs slots of 72 KB that the library allocates at the first such
+ * call on a device -- a hipMalloc and a synchronous hipMemset, once, kept until the process ends.  FSEHIP_prepareDevice() does that now, on the
+ * current device (idempotent; returns 0 or a hipError_t): call it before a timed region or before capturing such a call into a graph -- a first
+ * call that finds itself inside a stream capture without the scratch returns hipErrorStreamCaptureUnsupported instead of breaking the capture. */
+FSEHIP_API int FSEHIP_prepareDevice(void);
 
 /* build / device info: returns 0 and fills the fields when a gfx950 device is current */
 typedef struct { int deviceOrdinal; int computeUnits; int ldsBytesPerCU; int wavefrontSize; char archName[64]; } FSEHIP_DeviceInfo;

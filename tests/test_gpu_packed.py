@@ -110,3 +110,28 @@ def test_compact_full_size_batch(hip, oracle):
         else:
             out, dres = hip.huf_decompress_packed_batch(packed, offsets, 32768)
         assert bool((dres == 32768).all()) and torch.equal(out, src), codec
+
+
+def test_compact_ignores_results_that_cannot_belong_to_the_slots(hip, oracle):
+    """a results array that does not belong to these slots (a value beyond the slot stride that is no error code) yields no record instead of
+    a read behind the slot; the other records are unaffected"""
+    blocks = mixed_blocks(oracle, 12, 4097, seed=3)
+    src = torch.from_numpy(blocks).cuda()
+    slots, res = hip.fse_compress_batch(src)
+    good_p, good_o = hip.compact_batch(slots, res, src)
+    bad = res.clone()
+    bad[5] = slots.stride(0) + 1
+    bad[9] = 1 << 40
+    p, o = hip.compact_batch(slots, bad, src)
+    oh, gh = o.cpu().numpy(), good_o.cpu().numpy()
+    lens, glens = np.diff(oh), np.diff(gh)
+    assert lens[5] == 0 and lens[9] == 0
+    keep = [b for b in range(12) if b not in (5, 9)]
+    assert (lens[keep] == glens[keep]).all()
+    ph, gph = p.cpu().numpy(), good_p.cpu().numpy()
+    for b in keep:
+        assert (ph[oh[b]:oh[b + 1]] == gph[gh[b]:gh[b + 1]]).all()
+
+
+def test_prepare_device_is_idempotent(hip):
+    assert hip.lib.FSEHIP_prepareDevice() == 0 and hip.lib.FSEHIP_prepareDevice() == 0
