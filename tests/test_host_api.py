@@ -94,11 +94,11 @@ def test_shard_range_c_abi_matches_the_python_one():
 
 def test_c_host_example_with_rccl_compiles():
     """examples/shard_rccl.c -- the scatter / code / gather of config 5 written against the C ABI and RCCL -- must compile against
-    include/fsehip.h and the ROCm headers (it can only RUN where several GPUs are)"""
+    include/fsehip.h and the ROCm headers without a warning (tests/test_gpu_rccl.py RUNS it on the GPU box: one rank exercises every RCCL call)"""
     import shutil, subprocess, tempfile
     if not os.path.exists("/opt/rocm/include/rccl/rccl.h") or shutil.which("gcc") is None:
         pytest.skip("no RCCL headers / gcc here")
     with tempfile.TemporaryDirectory() as d:
         p = subprocess.run(["gcc", "-D__HIP_PLATFORM_AMD__", "-Wall", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-c",
                             os.path.join(ROOT, "examples", "shard_rccl.c"), "-o", os.path.join(d, "x.o")], capture_output=True, text=True)
-        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.returncode == 0 and "warning" not in p.stderr, p.stderr[-2000:]
