@@ -92,4 +92,6 @@ def test_bench_one_gpu_line_has_the_contract_fields():
     assert sec["resident_blocks_per_cu"] >= 16 and 100 < sec["cycles_per_iteration"] < 2000 and 0 < sec["frac"] <= 1.2
     hi = line["host_inclusive"]
     assert hi["roundtrip_ok"] is True and hi["encode_GBps"] > 0 and hi["decode_GBps"] > 0
+    pk = hi["packed"]                              # the same pipeline with packed results: fewer bytes over the link, same bytes back
+    assert pk.get("error") is None and pk["roundtrip_ok"] is True and pk["pcie_bytes"]["encode"] < hi["pcie_bytes"]["encode"]
     assert line["configs"]["cfg5_mixed_1M"]["corpus_blocks"] == 9000 and line["configs"]["cfg5_mixed_1M"]["scaling"] == "strong"
