@@ -676,7 +676,7 @@ HostCallBuf::~HostCallBuf()
 }
 typedef HostCallBuf DevBuf;
 // gives the calling thread's scratch arena back (between calls); the next call on host pointers allocates a new one
-extern "C" int FSEHIP_releaseScratch(void)
+int release_thread_scratch(void)                                  // the calling thread's arena
 {
     Arena& A = t_arena;
     if (A.live) return (int)hipErrorInvalidValue;
@@ -684,6 +684,12 @@ extern "C" int FSEHIP_releaseScratch(void)
     if (A.base) e = hipFree(A.base);                              // whatever device the thread is on now
     A.base = nullptr; A.cap = 0; A.used = 0; A.peak = 0; A.dev = -1;
     return (int)e;
+}
+extern "C" int FSEHIP_releaseScratch(void)
+{
+    const int r = release_thread_scratch();
+    frame_pool_release_scratch();                                 // ... and those of the frame calls' idle helper threads (frame.hip)
+    return r;
 }
 
 // result transport for one block: returns GENERIC when the device path itself fails

@@ -361,16 +361,17 @@ extern "C" size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const v
 namespace {
 
 struct FrameJob {
+    bool releaseOnly = false;                                 // no frames: every helper gives its scratch arena back (FSEHIP_releaseScratch)
     bool compress;
     void* const* dsts; const size_t* caps; const void* const* srcs; const size_t* sizes; size_t* results; size_t n;
     unsigned bsid; int codec; int dev;
     std::atomic<size_t> next{ 0 };
 };
-void frame_worker(FrameJob* j, bool ownStream)
+// `s`: the worker's stream (null: the null stream -- the lone caller, exactly the single-frame call)
+void frame_worker(FrameJob* j, hipStream_t s)
 {
-    hipStream_t s = nullptr;
-    bool ok = hipSetDevice(j->dev) == hipSuccess;
-    if (ok && ownStream && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void)hipGetLastError(); }
+    if (j->releaseOnly) { (void)release_thread_scratch(); return; }
+    const bool ok = hipSetDevice(j->dev) == hipSuccess;
     for (;;) {
         const size_t i = j->next.fetch_add(1);
         if (i >= j->n) break;
@@ -385,8 +386,67 @@ void frame_worker(FrameJob* j, bool ownStream)
         }
         j->results[i] = r;
     }
-    if (s) (void)hipStreamDestroy(s);
 }
+
+// The helpers of the batched frame calls are PERSISTENT (round 5): a worker keeps its thread, its stream and -- the point -- its
+// thread_local scratch arena (capi.hip) from call to call.  Spawned per call, every worker paid a hipMalloc for its arena at its first
+// frame and a hipFree at thread exit, and hipFree synchronises the device under the other workers' streams.
+// One batch call uses the pool at a time; a second caller arriving meanwhile runs on threads of its own (the former behaviour).  The pool
+// object is created on first use and never destroyed: its idle threads sit on a condition variable until the process ends -- no joins in
+// static destructors, nothing to hang on at exit.
+struct FramePool {
+    std::mutex call;                                          // one batch call at a time
+    std::mutex m; std::condition_variable work, done;
+    std::vector<std::thread> threads;
+    FrameJob* job = nullptr; unsigned wanted = 0, active = 0; unsigned long long gen = 0;
+    void loop(unsigned id)
+    {
+        unsigned long long seen = 0;
+        hipStream_t s = nullptr; int sDev = -1;
+        for (;;) {
+            FrameJob* j;
+            {   std::unique_lock<std::mutex> lk(m);
+                work.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (id >= wanted) continue;                      // this call asked for fewer helpers
+                j = job;
+            }
+            if (!j->releaseOnly && sDev != j->dev) {             // first job, or the caller moved to another device: a stream there
+                if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+                if (hipSetDevice(j->dev) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void)hipGetLastError(); }
+                sDev = j->dev;
+            }
+            frame_worker(j, s);
+            {   std::lock_guard<std::mutex> lk(m); if (--active == 0) done.notify_all(); }
+        }
+    }
+    // runs `j` on `helpers` pool threads beside the caller; false: the pool is busy (or cannot grow), nothing was started
+    bool run(FrameJob& j, unsigned helpers)
+    {
+        std::unique_lock<std::mutex> c(call, std::try_to_lock);
+        if (!c.owns_lock()) return false;
+        {   std::lock_guard<std::mutex> lk(m);
+            try { while (!j.releaseOnly && threads.size() < helpers) { const unsigned id = (unsigned)threads.size(); threads.emplace_back([this, id] { loop(id); }); } }
+            catch (...) { /* fewer helpers than asked for */ }
+            if (threads.empty()) return false;
+            helpers = helpers < threads.size() ? helpers : (unsigned)threads.size();
+            job = &j; wanted = helpers; active = helpers; ++gen;
+        }
+        work.notify_all();
+        if (!j.releaseOnly) {
+            hipStream_t mine = nullptr;                         // the caller works too, on a stream of its own beside the helpers'
+            if (hipStreamCreateWithFlags(&mine, hipStreamNonBlocking) != hipSuccess) { mine = nullptr; (void)hipGetLastError(); }
+            frame_worker(&j, mine);
+            if (mine) (void)hipStreamDestroy(mine);
+        }
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return active == 0; });
+        job = nullptr;
+        return true;
+    }
+};
+FramePool& frame_pool() { static FramePool* const p = new FramePool; return *p; }      // (never destroyed: see above)
+
 size_t run_frames(FrameJob& j, unsigned nThreads)
 {
     if (!j.n) return 0;
@@ -399,13 +459,32 @@ size_t run_frames(FrameJob& j, unsigned nThreads)
     if (!want) { want = std::thread::hardware_concurrency() / 2; if (want > 4) want = 4; }
     if (want < 1) want = 1;
     if ((size_t)want > j.n) want = (unsigned)j.n;
+    if (want > 64) want = 64;
+    if (want == 1) { frame_worker(&j, nullptr); return 0; }    // alone: on the null stream, exactly the single-frame call
+    if (frame_pool().run(j, want - 1)) return 0;
+    // the pool is serving another caller: threads of this call's own
     std::vector<std::thread> pool;
-    try { for (unsigned t = 1; t < want; ++t) pool.emplace_back(frame_worker, &j, true); } catch (...) { /* fewer workers than asked for */ }
-    frame_worker(&j, !pool.empty());                        // the caller works too (alone: on the null stream, exactly the single-frame call)
+    auto helper = [&j] {
+        hipStream_t s = nullptr;
+        if (hipSetDevice(j.dev) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void)hipGetLastError(); }
+        frame_worker(&j, s);
+        if (s) (void)hipStreamDestroy(s);
+    };
+    try { for (unsigned t = 1; t < want; ++t) pool.emplace_back(helper); } catch (...) { /* fewer workers than asked for */ }
+    helper();
     for (auto& t : pool) t.join();
     return 0;
 }
 }   // namespace
+
+// FSEHIP_releaseScratch: the idle helpers of the pool give their arenas back too (a pool that serves a call right now is left alone)
+void frame_pool_release_scratch(void)
+{
+    FramePool& p = frame_pool();
+    FrameJob j; j.releaseOnly = true; j.compress = false; j.dsts = nullptr; j.caps = nullptr; j.srcs = nullptr; j.sizes = nullptr; j.results = nullptr;
+    j.n = 0; j.bsid = 0; j.codec = 0; j.dev = 0;
+    (void)p.run(j, 64);
+}
 
 extern "C" size_t FSEHIP_frame_compress_batch(void* const* dsts, const size_t* dstCapacities, const void* const* srcs, const size_t* srcSizes,
                                               size_t* results, size_t nFrames, unsigned blockSizeId, int codec, unsigned nThreads)

@@ -279,3 +279,5 @@ private:
 struct DevProps { int cus; int ldsPerCU; bool ok; };
 const DevProps& dev_props();
 hipError_t ensure_dyn_lds(const void* kernel, int bytes);
+int release_thread_scratch(void);          // capi.hip: gives the calling thread's host-call arena back
+void frame_pool_release_scratch(void);      // frame.hip: the same for the idle helper threads of the batched frame calls

@@ -86,7 +86,7 @@ def host_group(group=None):
     the same ranks, created once (collectively: every rank of `group` gets here at the same point of the job) and kept"""
     if dist.get_backend(group) == "gloo":
         return group
-    key = None if group is None else id(group)
+    key = id(group if group is not None else dist.group.WORLD)      # (a default group re-created later in the process gets a side group of its own)
     if key not in _HOST_GROUPS:
         ranks = None if group is None else dist.get_process_group_ranks(group)
         _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")

@@ -316,7 +316,9 @@ FSEHIP_API size_t FSEHIP_frame_decompress(void* dst, size_t dstCapacity, const v
  * is coded from srcs[i] / srcSizes[i] into dsts[i] / dstCapacities[i] exactly as the single-frame call would code it -- same bytes,
  * same result, in results[i] -- by a pool of nThreads host threads (0: half the host's hardware threads, at most 4; never more than
  * nFrames), each with a device stream and a scratch arena of its own: one frame is bound by one host thread's XXH32 and its copies,
- * many frames are not.  All pointers are HOST pointers.  Returns 0, or an error code when the call itself cannot run (null arrays,
+ * many frames are not.  The helper threads are persistent: created at the first such call, they keep their streams and arenas between calls
+ * (no hipMalloc / hipFree per call) and sit idle on a condition variable otherwise; FSEHIP_releaseScratch() makes the idle ones give their arenas
+ * back.  One batch call uses them at a time -- a second caller arriving meanwhile runs on threads of its own.  All pointers are HOST pointers.  Returns 0, or an error code when the call itself cannot run (null arrays,
  * no device); a frame's own failure is in its results entry only. */
 FSEHIP_API size_t FSEHIP_frame_compress_batch(void* const* dsts, const size_t* dstCapacities, const void* const* srcs, const size_t* srcSizes,
                                               size_t* results, size_t nFrames, unsigned blockSizeId, int codec, unsigned nThreads);
@@ -375,8 +377,8 @@ FSEHIP_API void FSEHIP_shardRange(size_t nBlocks, int rank, int world, size_t* f
 
 /* The calls on HOST pointers (layer 1, the frames) take their device scratch from an arena the calling thread keeps between calls
  * (grow-only, at most 1 GiB; larger buffers are allocated and freed per call): no hipMalloc / hipFree on the repeated-call path.
- * FSEHIP_releaseScratch() gives the calling thread's arena back; a thread that exits without calling it leaves its arena to the
- * process teardown. */
+ * FSEHIP_releaseScratch() gives the calling thread's arena back (and those of the batched frame calls' idle helper threads); a thread that
+ * exits without calling it leaves its arena to the process teardown. */
 FSEHIP_API int FSEHIP_releaseScratch(void);
 
 /* The one allocation the batched calls make themselves: FSEHIP_FSE_decompress_usingDTable_batch (whose reference signature, lib/fse.h:247, has
