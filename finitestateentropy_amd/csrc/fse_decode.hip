@@ -223,12 +223,31 @@ DEV u32 fse_chain_pad(u32 s)
     for (int i = 0; i < FSE_EXTRA_CHAIN_OPS / 2; ++i) __asm__ volatile("v_xor_b32 %0, 1, %0\n\tv_xor_b32 %0, 1, %0" : "+v"(s));
     return s;
 }
+// Measurement aid (EXPERIMENTS.md, "the state ring in global memory"): FSE_PROBE_GSTORE 1 = the decoder lanes ALSO store every record pair to
+// global memory (one global_store_dwordx2 per lane and two iterations, SGPR base + VGPR offset), 2 = INSTEAD of the LDS ring (results wrong:
+// timing only) -- what would a state ring outside LDS (36 instead of 33 blocks per CU) cost the decoder wave's instruction stream?
+#ifndef FSE_PROBE_GSTORE
+#define FSE_PROBE_GSTORE 0
+#endif
+#if FSE_PROBE_GSTORE
+__device__ u8 g_probeRing[512u * 64u * 2u * 4096u];                 // 512 workgroup slots x 64 lanes x 2 decoder waves x 4 KiB
+DEV void fse_probe_gstore(u32 off, u32 a, u32 b)
+{
+    typedef u32 v2 __attribute__((ext_vector_type(2)));
+    __attribute__((address_space(1))) u8* const base = (__attribute__((address_space(1))) u8*)g_probeRing;
+    *(__attribute__((address_space(1))) v2*)(base + off) = (v2){ a, b };
+}
+#endif
 template <int NITER>
 DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
 {
     u32 s = sMine, P = Pref;
     u32 prev = 0;
     __asm__ volatile("" : "+v"(myIn));
+#if FSE_PROBE_GSTORE
+    // (a 4 KiB stretch per lane, the position inside it following the LDS ring's: 512 bytes of it are ever touched)
+    const u32 probeOff = (((blockIdx.x & 511u) * 128u + (threadIdx.x & 127u)) << 12) + ((u32)(uintptr_t)ringMine & 0x1F8u);
+#endif
     u32 c = lds_cell(s);
     u32 Pw = P;
     lds_u32_ptr wp = (lds_u32_ptr)(uintptr_t)(myIn + (ring_dword(P) << 2));
@@ -257,7 +276,13 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
         u32 lo2 = __builtin_amdgcn_alignbit(hi, lo, n1);
         u32 rec = __builtin_amdgcn_perm(s, sStart, 0x05040100u);
         __asm__ volatile("" : "+v"(lo2), "+v"(rec));
+#if FSE_PROBE_GSTORE == 2
+        if (it & 1) fse_probe_gstore(probeOff + 8u * (u32)(it & ~1), prev, rec); else prev = rec;
+#elif FSE_PROBE_GSTORE == 1
+        if (it & 1) { ringMine[it & ~1] = make_uint2(prev, rec); fse_probe_gstore(probeOff + 8u * (u32)(it & ~1), prev, rec); } else prev = rec;
+#else
         if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
+#endif
         SB;
         s = fse_chain_pad(lshl_or(__builtin_amdgcn_ubfe(lo2, dpp_swap_and(c2, maskB), c2), K - c2, (c2 >> cellShift) | tabOff));
         if (it + 1 < NITER) c = lds_cell(s);
