@@ -29,12 +29,23 @@ def test_c_host_with_rccl_runs_one_rank(hip, n_blocks):
     assert "through ncclSend / ncclRecv" in out
 
 
+@pytest.mark.parametrize("n_blocks,pieces", [(4096, 4), (1001, 7), (5, 2)])
+def test_c_host_pipelined_protocol_runs_one_rank(hip, n_blocks, pieces):
+    """the PIPELINED protocol of DESIGN.md section 5 in C (three streams, a communicator per direction, the compute stream waiting only for its
+    next piece, the host only for the event behind the previous piece's compaction): shards in `pieces` pieces, the packed stream gathered piece
+    after piece and decoded against the corpus in arrival order"""
+    p = subprocess.run([_exe(), str(n_blocks), str(pieces)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "shard_rccl OK: %d blocks" % n_blocks in out and "shard_rccl pipelined OK: %d pieces" % pieces in out, out[-2000:]
+
+
 def test_c_host_with_rccl_two_ranks_on_one_gpu(hip, tmp_path):
     """two processes sharing the box's one GPU (rank % deviceCount): a real two-rank communicator -- rank 0 sends, rank 1 receives, codes
     and sends back.  RCCL may refuse two ranks on one device; that refusal (not a wrong result) skips the test."""
     idfile = str(tmp_path / "nccl_id")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
-    procs = [subprocess.Popen([_exe(), "2001", str(r), "2", idfile], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    procs = [subprocess.Popen([_exe(), "2001", str(r), "2", idfile, "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
     outs = []
     for p in procs:
         try:
