@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--max-log", type=int, default=12, help="FSE decode limit: 12 = FSE_decompress (lib/fse_decompress.c:279-283)")
     ap.add_argument("--no-configs", action="store_true", help="headline only (skip configs 3/4/5 and the tableLog-12 variants)")
     ap.add_argument("--configs", default="", help="comma-separated subset of the `configs` keys to run (default: all)")
+    ap.add_argument("--ut-keys", default="", help="comma-separated subset of the using_tables records (fse_p14, fse_p80, huf_p14; default: all) -- scripts/profile.sh "
+                                                  "collects their counters one record per run")
     ap.add_argument("--config-steps", type=int, default=0, help="steps of the `configs` entries (0 = the headline's --steps / --warmup)")
     ap.add_argument("--cfg5-blocks", type=int, default=125000, help="blocks per GPU of the weak-scaling config-5 record (1M / 8)")
     ap.add_argument("--cfg5-total", type=int, default=1000000, help="blocks of the fixed config-5 corpus (strong scaling; BASELINE configs[4])")
@@ -330,7 +332,7 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
                         "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
 
 
-def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warmup, barrier, reduce_max, world, rank):
+def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warmup, barrier, reduce_max, world, rank, key=""):
     """The functions north_star names, in the form it names them (lib/fse.h:174,247, lib/huf.h:190,275; what programs/fullbench.c:805-814,
     851-862,897-905,987-998 time separately): tables built ONCE on the device (FSEHIP_*_build*Table_batch: the library's own prepare
     kernels behind calls of their own), then `steps` timed passes of *_compress_usingCTable_batch + *_decompress_usingDTable_batch over
@@ -419,6 +421,17 @@ def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warm
             roofs[direction] = {"bound": "hbm", "kernel": k, "achieved": round(alg * nb / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(alg * nb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms_per_pass": round(kms, 3),
                                 "algorithmic_bytes_per_block": round(alg, 1), "traffic": None}
+            # the builder's counters of THIS call form (scripts/profile.sh runs every using-table record by itself; the caller-table FSE decoder is
+            # an instantiation of its own, `k_fse_decode<true, false, true>`, and is told apart by its full name): a cross-reference like the headline's
+            tp = os.path.join(ROOT, "profiles", "traffic_%s_ut_%s.json" % (k, key))
+            if os.path.exists(tp):
+                try:
+                    trec = json.load(open(tp))
+                    roofs[direction]["traffic"] = round(trec["hbm_bytes_per_block"] * nb)
+                    roofs[direction]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this record alone (%s blocks per launch there), "
+                                                         "HBM bytes per block scaled to this run -- recorded by the builder, not counters of this run" % (os.path.basename(tp), trec.get("blocks")))
+                except Exception:
+                    pass
     rec["roofline"] = roofs
     del ct, hdr, dt
     return rec
@@ -869,9 +882,12 @@ def main():
             case("huf_tl12", 2, ("huf",), nb, rank * nb, table_log=12, desc="Proba02 (256 symbols), Huff0 with tableLog 12 (HUF_TABLELOG_MAX)")
         if want("using_tables"):
             ut = {}
+            ut_keys = set(k for k in args.ut_keys.split(",") if k)
             for key, codec_name, proba in (("fse_p14", "fse", 14), ("fse_p80", "fse", 80), ("huf_p14", "huf", 14)):
+                if ut_keys and key not in ut_keys:
+                    continue
                 s_ut = gen(proba, nb, rank * nb)
-                ut[key] = using_tables_case(hip, codec_name, proba, s_ut, pools, args.table_log, cs, cw, barrier, reduce_max, world, rank)
+                ut[key] = using_tables_case(hip, codec_name, proba, s_ut, pools, args.table_log, cs, cw, barrier, reduce_max, world, rank, key)
             ut["note"] = ("the north-star-named calls on caller-built tables in the reference's layouts; FSE decode converts the tables to its bit-reversed "
                           "cells while staging them and runs the same fast loop as the one-shot path (compare kernel_ms_per_step.k_fse_decode with the "
                           "headline's and cfg3's)")

@@ -34,7 +34,48 @@ def agg(path, counter=None):
     return out
 
 
+def ut_summary(run_prefix, tag, nblocks):
+    """python scripts/pmc_summary.py --ut gpurun_out/<run> <tag> <blocks>: the using-table records (scripts/profile.sh: one record per run, in
+    <run>_ut_<key>/pmc_fetch|pmc_write).  Kernels are told apart by their FULL names -- the caller-table FSE decoder is `k_fse_decode<true, false,
+    true>`, the one-shot decoder of the same run's headline `<true, false, false>` -- and a kernel's bytes are divided by its launches that carried
+    blocks (3 per record: warm-up + 2 steps; the encoder is launched by the headline of the run as well: 6)."""
+    lines = ["# %s: HBM traffic of the using-table calls (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one record per run)" % tag, "",
+             "| record | kernel | launches counted | fetch KiB (raw) | write KiB | HBM bytes / block (FETCH x2) |", "|---|---|---|---|---|---|"]
+    want = {"fse_p14": (("k_fse_decode", "<true, false, true>", 3), ("k_fse_encode_wave", "", 6)),
+            "fse_p80": (("k_fse_decode", "<true, false, true>", 3), ("k_fse_encode_wave", "", 6)),
+            "huf_p14": (("k_huf_decode", "k_huf_decode", 3), ("k_huf_encode", "", 3))}
+    for key, kernels in want.items():
+        run = "%s_ut_%s" % (run_prefix, key)
+        sums = {}
+        for sub in ("pmc_fetch", "pmc_write"):
+            path = os.path.join(run, sub, "bench_counter_collection.csv")
+            if not os.path.exists(path):
+                continue
+            for r in csv.DictReader(open(path)):
+                name = r["Kernel_Name"]
+                for k, must, passes in kernels:
+                    base = name.split("(")[0].replace("void ", "")
+                    if k == "k_huf_decode":
+                        ok = base.startswith("k_huf_decode")            # the stream-parallel launches and the serial one: the whole a5 step
+                    else:
+                        ok = base.split("<")[0] == k and must in name
+                    if ok:
+                        sums.setdefault(k, {"pmc_fetch": 0.0, "pmc_write": 0.0})[sub] += float(r["Counter_Value"])
+        for k, must, passes in kernels:
+            if k not in sums:
+                continue
+            f, w = sums[k]["pmc_fetch"], sums[k]["pmc_write"]
+            per_block = (f * 1024 * 2.0 + w * 1024) / (nblocks * passes)
+            lines.append("| %s | %s%s | %d | %.0f | %.0f | %.0f |" % (key, k, must if must.startswith("<") else "", passes, f, w, per_block))
+            json.dump({"kernel": k, "record": key, "hbm_bytes_per_block": round(per_block, 1), "fetch_correction": 2.0, "fetch_KiB_raw_total": f, "write_KiB_total": w,
+                       "blocks": nblocks, "passes": passes, "source": tag}, open("profiles/traffic_%s_ut_%s.json" % (k, key), "w"))
+    open("profiles/%s_pmc.md" % tag, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 def main():
+    if sys.argv[1] == "--ut":
+        return ut_summary(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     run, tag, nblocks = sys.argv[1], sys.argv[2], int(sys.argv[3])
     suffix = sys.argv[4] if len(sys.argv) > 4 else ""             # traffic_<kernel><suffix>.json: records of a configuration other than the headline's
     os.makedirs("profiles", exist_ok=True)

@@ -56,4 +56,14 @@ for extra in fse_u16 using_tables; do
     mkdir -p $O
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --codec fse --configs $extra --plain --steps 5 --warmup 2 > $O/trace.log 2>&1
 done
+# the using-table calls, one record per run (the headline of the same run uses the record's distribution, so that kernels both of them launch see one kind
+# of data); python scripts/pmc_summary.py --ut gpurun_out/<run> <tag> 20000 turns them into profiles/traffic_<kernel>_ut_<key>.json
+for rec in fse_p14:fse:14 fse_p80:fse:80 huf_p14:fse:14; do
+    key=${rec%%:*}; rest=${rec#*:}; codec=${rest%%:*}; proba=${rest#*:}
+    O=$R/gpurun_out/${RUN}_ut_$key
+    mkdir -p $O
+    B="python $R/bench.py --codec $codec --proba $proba --configs using_tables --ut-keys $key --plain"
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B $P > $O/fetch.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
+done
 find $R/gpurun_out/${RUN}_fse $R/gpurun_out/${RUN}_huf $R/gpurun_out/${RUN}_p80 -name "*.csv" | head -60
