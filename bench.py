@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--u16-blocks", type=int, default=25000, help="blocks per GPU of the 16-bit-symbol configuration")
     ap.add_argument("--parity-blocks", type=int, default=0, help="blocks whose encoder bytes are compared with the CPU reference, untimed (0 = every block of the "
                                                                  "headline and of configs 2-4; the mixed 1M-block configurations use --cfg5-parity-blocks)")
+    ap.add_argument("--comm-timeout", type=int, default=240, help="seconds the with-comm leg of config 5 (N > 1) may take before the line is printed without it")
     ap.add_argument("--cfg5-parity-blocks", type=int, default=0, help="blocks per codec of the config-5 records compared with the CPU reference: 0 = ALL of them "
                                                                       "(chunked and untimed; the default), N = a strided sample of N")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pinned-host H2D + kernels + D2H figure")
@@ -858,6 +859,7 @@ def main():
     del codecs
 
     configs = {}
+    comm_leg = None
     if not args.no_configs:
 
         def case(key, proba, names, n, first_block, table_log=args.table_log, max_log=args.max_log, desc="", total=None, n_check=None, traffic_tag=None):
@@ -912,15 +914,39 @@ def main():
             if corpus_note:
                 rec5["corpus_note"] = corpus_note
             if world > 1:
-                try:
-                    rec5["with_comm"] = with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, barrier, reduce_max, sharing)
-                except Exception as e:   # the communication leg is a report beside the compute-only record, never a reason to lose the line
-                    rec5["with_comm"] = {"value": None, "error": repr(e)}
+                comm_leg = (total, cds5)              # runs LAST, under a watchdog (below): a transfer that never completes must not cost the line
             del s5, cds5
         if want("fse_u16") and hasattr(hip, "fse_compress_u16_batch"):
             configs["fse_u16"] = u16_case(hip, dev, args.u16_blocks, cs, barrier, reduce_max, world, rank)
 
+    # ---- the communication leg of config 5 (N > 1), after everything else has been measured and the line is ready: the scatter / gather over
+    #      RCCL is the one part of this program no box of ours has ever run across GPUs.  A watchdog on every rank bounds it: if the leg has
+    #      not finished after --comm-timeout seconds, rank 0 prints the line with an error record in its place and every rank leaves through
+    #      os._exit (a hung collective cannot be cancelled from Python); the NCCL watchdog of the process group (8 minutes) comes later.
+    def comm_leg_guarded(emit_without):
+        import threading
+        done = threading.Event()
+
+        def give_up():
+            if done.is_set():
+                return
+            if rank == 0:
+                emit_without("the communication leg did not finish within %d s (a transfer or a collective never completed); every other figure of this line was measured before it" % args.comm_timeout)
+            os._exit(0)
+        timer = threading.Timer(float(args.comm_timeout), give_up)
+        timer.daemon = True
+        timer.start()
+        total5, cds = comm_leg
+        try:
+            rec = with_comm_case(args, hip, shard, dev, rank, world, total5, cds, srcpool, barrier, reduce_max, sharing)
+        except Exception as e:       # the communication leg is a report beside the compute-only record, never a reason to lose the line
+            rec = {"value": None, "error": repr(e)}
+        done.set(); timer.cancel()
+        return rec
+
     if rank != 0:
+        if comm_leg is not None:
+            comm_leg_guarded(None)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -952,6 +978,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, cpu_sample, head_names[0])
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
             line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": host_threads(), "kind": "unavailable", "sample": repr(e)}
+    if comm_leg is not None:
+        def emit_without(why):
+            configs["cfg5_mixed_1M"]["with_comm"] = {"value": None, "error": why}
+            print(json.dumps(line)); sys.stdout.flush()
+        configs["cfg5_mixed_1M"]["with_comm"] = comm_leg_guarded(emit_without)
     print(json.dumps(line))
     sys.stdout.flush()
     if dist is not None:

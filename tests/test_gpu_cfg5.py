@@ -80,6 +80,19 @@ def test_bench_two_ranks_start_from_gpus_flag():
     assert pp["gather_bytes"] - 8 * 2 * (n_peer + pp["pieces_per_shard"]) > 0 and pp["gather_bytes"] < 0.7 * pp["fixed_stride_gather_bytes"]
 
 
+def test_bench_two_ranks_comm_watchdog_keeps_the_line():
+    """the with-comm leg runs last, under a watchdog: when it does not finish in time (here: at once) rank 0 still prints the line --
+    every other figure in place, an error record where the leg's would be -- and every rank leaves"""
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "2048", "--cfg5-total", "6001",
+                       "--configs", "cfg5_mixed_1M", "--no-cpu-baseline", "--no-host-inclusive", "--comm-passes", "2", "--parity-blocks", "256",
+                       "--comm-timeout", "0"],
+                      env={"FSEHIP_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    strong = line["configs"]["cfg5_mixed_1M"]
+    assert strong["value"] > 0 and strong["corpus_blocks"] == 6001
+    assert strong["with_comm"]["value"] is None and "did not finish within 0 s" in strong["with_comm"]["error"]
+
+
 def test_bench_one_gpu_line_has_the_contract_fields():
     line = _run_bench(["--steps", "2", "--warmup", "1", "--blocks", "8192", "--configs", "cfg5_mixed_1M", "--cfg5-total", "9000",
                        "--no-cpu-baseline", "--parity-blocks", "256"])
