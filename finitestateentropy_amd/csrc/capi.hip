@@ -733,6 +733,24 @@ extern "C" size_t FSEHIP_HIST_countFast(unsigned* count, unsigned* maxSymbolValu
 {
     return hist_count_host(count, maxSymbolValuePtr, src, srcSize, 1);
 }
+// lib/hist.h:62 (lib/hist.c:141-150): below 1500 bytes the reference takes HIST_count_simple and never looks at the workspace; from there on
+// the workspace is checked like HIST_count_wksp's
+extern "C" size_t FSEHIP_HIST_countFast_wksp(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize, void* workSpace, size_t workSpaceSize)
+{
+    if (srcSize >= 1500) {
+        if ((size_t)workSpace & 3) return FSEHIP_ERROR(GENERIC);
+        if (workSpaceSize < FSEHIP_HIST_WKSP_SIZE) return FSEHIP_ERROR(workSpace_tooSmall);
+    }
+    return hist_count_host(count, maxSymbolValuePtr, src, srcSize, 1);
+}
+// lib/hist.h:74 (lib/hist.c:29-54): the unchecked loop; returns the largest count as `unsigned`.  A symbol above the limit makes the reference write
+// beyond count[]; here it is counted into the result and *maxSymbolValuePtr like HIST_countFast does (defined behaviour at every size).  A device
+// failure reads as 0 (the function has no error channel).
+extern "C" unsigned FSEHIP_HIST_count_simple(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize)
+{
+    const size_t r = hist_count_host(count, maxSymbolValuePtr, src, srcSize, 1);
+    return FSEHIP_isError(r) ? 0u : (unsigned)r;
+}
 
 extern "C" size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const FSEHIP_FSE_CTable* ct)
 {

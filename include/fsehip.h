@@ -95,6 +95,9 @@ FSEHIP_API size_t FSEHIP_HIST_count(unsigned* count, unsigned* maxSymbolValuePtr
  * 255 bounds the entries written, larger symbols are counted into the result and *maxSymbolValuePtr but are no error (lib/hist.c:120-131). */
 FSEHIP_API size_t FSEHIP_HIST_count_wksp(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize, void* workSpace, size_t workSpaceSize);
 FSEHIP_API size_t FSEHIP_HIST_countFast(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize);
+/* lib/hist.h:62 (below 1500 bytes the workspace is not looked at, lib/hist.c:141-150) and :74 (returns the largest count as `unsigned`) */
+FSEHIP_API size_t FSEHIP_HIST_countFast_wksp(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize, void* workSpace, size_t workSpaceSize);
+FSEHIP_API unsigned FSEHIP_HIST_count_simple(unsigned* count, unsigned* maxSymbolValuePtr, const void* src, size_t srcSize);
 
 /* lib/fse.h:174 */
 FSEHIP_API size_t FSEHIP_FSE_compress_usingCTable(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const FSEHIP_FSE_CTable* ct);
@@ -411,6 +414,8 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define HUF_decompress1X1_usingDTable FSEHIP_HUF_decompress1X1_usingDTable
 #define HIST_count_wksp FSEHIP_HIST_count_wksp
 #define HIST_countFast FSEHIP_HIST_countFast
+#define HIST_countFast_wksp FSEHIP_HIST_countFast_wksp
+#define HIST_count_simple FSEHIP_HIST_count_simple
 #define FSE_compress_wksp FSEHIP_FSE_compress_wksp
 #define FSE_decompress_wksp FSEHIP_FSE_decompress_wksp
 #define HUF_compress4X_wksp FSEHIP_HUF_compress4X_wksp

@@ -45,12 +45,14 @@ def test_hist_wksp_and_fast(hip, ref, checker):
     ws = np.zeros(1024 + 1, np.uint32)
     for src in _blocks(checker):
         for limit in (255, 254, 200, 131, 52, 6):
-            for name, extra in (("HIST_count_wksp", (ws, SZ(4096))), ("HIST_countFast", ())):
-                if name == "HIST_countFast" and src.size < 1500 and int(src.max()) > limit:
+            for name, extra in (("HIST_count_wksp", (ws, SZ(4096))), ("HIST_countFast", ()), ("HIST_countFast_wksp", (ws, SZ(4096))), ("HIST_count_simple", ())):
+                if name != "HIST_count_wksp" and (src.size < 1500 or name == "HIST_count_simple") and int(src.max()) > limit:
                     continue                        # HIST_count_simple writes beyond count[] there (lib/hist.c:40): nothing to compare with
                 cnt = np.zeros(256 + 8, np.uint32)
                 msv = np.array([limit], np.uint32)
                 (rg, ag), (rr, ar) = _both(hip, ref, name, cnt, msv, src, SZ(src.size), *extra)
+                if name == "HIST_count_simple":          # returns `unsigned`: the upper half of the register is not part of the result
+                    rg, rr = rg & 0xFFFFFFFF, rr & 0xFFFFFFFF
                 assert rg == rr, (name, src.size, limit, rg, rr)
                 if rg < (1 << 64) - 9:
                     assert (ag[0] == ar[0]).all() and ag[1][0] == ar[1][0], (name, src.size, limit)
@@ -58,14 +60,24 @@ def test_hist_wksp_and_fast(hip, ref, checker):
     src = _blocks(checker)[0]
     cnt, msv = np.zeros(256, np.uint32), np.array([255], np.uint32)
     raw = np.zeros(4200, np.uint8)
-    for off, size in ((1, 4096), (0, 4095), (2, 100), (0, 0)):
-        view = raw[off:]
-        res = []
-        for lib, fname in ((hip.lib, "FSEHIP_HIST_count_wksp"), (ref.lib, "HIST_count_wksp")):
-            f = getattr(lib, fname)
-            f.restype = SZ
-            res.append(int(f(_p(cnt), _p(msv), _p(src), SZ(src.size), C.c_void_p(view.ctypes.data), SZ(size))))
-        assert res[0] == res[1] and res[0] > (1 << 64) - 9, (off, size, res)
+    for base_name in ("HIST_count_wksp", "HIST_countFast_wksp"):
+        for off, size in ((1, 4096), (0, 4095), (2, 100), (0, 0)):
+            view = raw[off:]
+            res = []
+            for lib, fname in ((hip.lib, "FSEHIP_" + base_name), (ref.lib, base_name)):
+                f = getattr(lib, fname)
+                f.restype = SZ
+                res.append(int(f(_p(cnt), _p(msv), _p(src), SZ(src.size), C.c_void_p(view.ctypes.data), SZ(size))))
+            assert res[0] == res[1] and res[0] > (1 << 64) - 9, (base_name, off, size, res)
+    # below 1500 bytes HIST_countFast_wksp does not look at its workspace (lib/hist.c:145-146)
+    small = _blocks(checker)[6]
+    res = []
+    for lib, fname in ((hip.lib, "FSEHIP_HIST_countFast_wksp"), (ref.lib, "HIST_countFast_wksp")):
+        f = getattr(lib, fname)
+        f.restype = SZ
+        m2 = np.array([255], np.uint32)
+        res.append(int(f(_p(cnt), _p(m2), _p(small), SZ(small.size), C.c_void_p(raw[1:].ctypes.data), SZ(0))))
+    assert res[0] == res[1] and res[0] < (1 << 64) - 9, res
 
 
 @pytest.mark.parametrize("table_log", [11, 12, 9, 13, 15])

@@ -40,7 +40,7 @@ def test_dropin_names_cover_the_reference_prototypes():
                  "HUF_compress", "HUF_compress2", "HUF_decompress", "HUF_compress1X_usingCTable", "HUF_compress4X_usingCTable",
                  "HUF_decompress4X_usingDTable", "HUF_decompress4X1_usingDTable",
                  # the _wksp forms the reference's own callers go through (lib/fse.h:315,335, lib/huf.h:95,164,289, lib/hist.h:46,54)
-                 "HIST_count_wksp", "HIST_countFast", "FSE_compress_wksp", "FSE_decompress_wksp", "HUF_compress4X_wksp", "HUF_compress1X_wksp",
+                 "HIST_count_wksp", "HIST_countFast", "HIST_countFast_wksp", "HIST_count_simple", "FSE_compress_wksp", "FSE_decompress_wksp", "HUF_compress4X_wksp", "HUF_compress1X_wksp",
                  "HUF_decompress4X1_DCtx_wksp"):
         assert re.search(r"#define %s FSEHIP_%s\b" % (name, name), header), name
 
