@@ -701,10 +701,19 @@ static size_t hist_count_host(unsigned* count, unsigned* maxSymbolValuePtr, cons
     HK(dsrc.alloc(srcSize)); HK(dcnt.alloc(1024)); HK(dmsv.alloc(4)); HK(dres.alloc(8));
     HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
     HK(hipMemcpy(dmsv.p, maxSymbolValuePtr, 4, hipMemcpyHostToDevice));
-    HistArgs a;
-    a.counts = (unsigned*)dcnt.p; a.maxSVs = (unsigned*)dmsv.p; a.uniformMaxSV = 255; a.useUniformIn = 0; a.trustInput = trustInput;
-    a.results = (size_t*)dres.p; a.src = mkview(dsrc.p, srcSize, nullptr, srcSize); a.nBlocks = 1;
-    HK(launch_hist(a, nullptr));
+    if (srcSize >= HIST_LARGE_MIN) {                        // a whole buffer: pieces counted as a batch and folded (hist.hip)
+        const size_t nPart = (srcSize + HIST_PIECE - 1) / HIST_PIECE;
+        DevBuf dpart, dpr;
+        HK(dpart.alloc(nPart * 1024)); HK(dpr.alloc(nPart * 8));
+        HK(launch_hist_large((const u8*)dsrc.p, srcSize, *maxSymbolValuePtr, trustInput, (unsigned*)dpart.p, (unsigned*)dcnt.p, (unsigned*)dmsv.p,
+                             (size_t*)dres.p, (size_t*)dpr.p, nullptr));
+        HK(hipDeviceSynchronize());
+    } else {
+        HistArgs a;
+        a.counts = (unsigned*)dcnt.p; a.maxSVs = (unsigned*)dmsv.p; a.uniformMaxSV = 255; a.useUniformIn = 0; a.trustInput = trustInput;
+        a.results = (size_t*)dres.p; a.src = mkview(dsrc.p, srcSize, nullptr, srcSize); a.nBlocks = 1;
+        HK(launch_hist(a, nullptr));
+    }
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (FSEHIP_isError(r)) return r;

@@ -14,6 +14,11 @@ struct HistArgs {
     size_t nBlocks;
 };
 hipError_t launch_hist(const HistArgs& a, hipStream_t s);
+// one input of n >= HIST_PIECE bytes cut into HIST_PIECE-byte pieces: d_part holds ceil(n / HIST_PIECE) x 256 words, d_scratchResults as many size_t
+#define HIST_PIECE ((size_t)65536)
+#define HIST_LARGE_MIN ((size_t)262144)
+hipError_t launch_hist_large(const u8* d_src, size_t n, unsigned limitIn, int trustInput, unsigned* d_part, unsigned* d_count, unsigned* d_maxSV,
+                             size_t* d_result, size_t* d_scratchResults, hipStream_t s);
 // n 32-bit words at p set to zero by a kernel of ours (p 4-byte aligned).  Used instead of hipMemsetAsync for the few counter words
 // the pipelines clear per call: captured into a HIP graph, the runtime's small-memset node faulted on later replays (ROCm 7.2, after
 // other work had been synchronised on the stream in between) -- a plain kernel node does not.

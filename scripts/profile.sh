@@ -12,7 +12,7 @@
 R=$(pwd)
 RUN=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
-for codec in fse huf; do
+for codec in ${PROFILE_CODECS:-fse huf}; do
     O=$R/gpurun_out/${RUN}_$codec
     mkdir -p $O
     B="python $R/bench.py --codec $codec --no-configs --plain"
@@ -26,6 +26,7 @@ for codec in fse huf; do
     timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq2 -o bench -- $B $P > $O/sq2.log 2>&1
     tail -1 $O/trace.log | cut -c1-300
 done
+[ -n "$PROFILE_CODECS" ] && exit 0      # PROFILE_CODECS=fse scripts/profile.sh <run>: only the codec passes above (a kernel of theirs changed)
 # BASELINE config 3 (Proba80, FSE): kernel trace + HBM traffic passes;  16-bit symbols and the using-table calls: kernel traces (their
 # kernels run beside the headline's in one bench run; the rows are told apart by kernel name / call count)
 O=$R/gpurun_out/${RUN}_p80

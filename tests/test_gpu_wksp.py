@@ -41,6 +41,33 @@ def _blocks(checker):
     return blocks
 
 
+def test_hist_whole_buffer(hip, ref, checker):
+    """HIST_count / HIST_countFast of ONE large input (lib/hist.c:163-180): from 256 KiB the device cuts it into 64 KiB pieces counted as a
+    batch and folded (hist.hip k_hist_fold) -- sizes either side of the switch, ragged tails, a limit that is too small, a symbol that
+    only the last byte holds."""
+    rng = np.random.default_rng(11)
+    ws = np.zeros(1024, np.uint32)
+    for n, P in ((262143, 14), (262144, 80), (262145, 2), (1 << 20, 14), ((1 << 20) + 17, 50), (5 * 65536 + 65535, 20), (3000001, 80)):
+        src = np.concatenate([checker.probagen_batch(P, 1, min(n - k, 1 << 20), 3 + k)[0] for k in range(0, n, 1 << 20)])
+        assert src.size == n
+        variants = [src]
+        last = src.copy(); last[-1] = 255                   # the largest present symbol sits in the tail piece only
+        variants.append(last)
+        for v in variants:
+            for limit in (255, 254, int(v.max()), int(v.max()) - 1, 30):
+                for name, extra in (("HIST_count", ()), ("HIST_count_wksp", (ws, SZ(4096))), ("HIST_countFast", ())):
+                    cnt = np.full(256 + 8, 0xABCDEF, np.uint32)
+                    msv = np.array([limit], np.uint32)
+                    (rg, ag), (rr, ar) = _both(hip, ref, name, cnt, msv, v, SZ(v.size), *extra)
+                    assert rg == rr, (name, n, limit, rg, rr)
+                    if rg < (1 << 64) - 200:
+                        assert (ag[0] == ar[0]).all() and ag[1][0] == ar[1][0], (name, n, limit)
+    noise = rng.integers(0, 256, 700000, dtype=np.uint8)
+    cnt, msv = np.zeros(256, np.uint32), np.array([255], np.uint32)
+    (rg, ag), (rr, ar) = _both(hip, ref, "HIST_count", cnt, msv, noise, SZ(noise.size))
+    assert rg == rr and (ag[0] == ar[0]).all() and int(ag[0].sum()) == noise.size
+
+
 def test_hist_wksp_and_fast(hip, ref, checker):
     ws = np.zeros(1024 + 1, np.uint32)
     for src in _blocks(checker):
