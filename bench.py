@@ -330,7 +330,7 @@ def u16_case(hip, dev, n_blocks, steps, barrier, reduce_max, world, rank):
             "encode_GBps": round(total / enc / 1e9, 2), "decode_GBps": round(total / dec / 1e9, 2),
             "compressed_bytes_per_block": round(float(cres.sum().item()) / n_blocks, 1), "parity": parity,
             "workload": "16-bit symbols (lib/fseU16.c): %d x 16384 symbols per GPU, 287-symbol alphabet (fuzzerU16's generator, p = 0.08), "
-                        "FSE_compressU16 + FSE_decompressU16, default table log 12; one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
+                        "FSE_compressU16 + FSE_decompressU16 at the default limits (FSE_optimalTableLog gives these blocks table log 11: default 12, capped by highbit(16383) - 2); one tANS state per block: the encoder splits the chain across a wave, the decoder runs one lane per block" % n_blocks}
 
 
 def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warmup, barrier, reduce_max, world, rank, key=""):

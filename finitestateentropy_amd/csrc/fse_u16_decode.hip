@@ -15,19 +15,20 @@
 #include "internal.h"
 #include "bitreader.h"
 
-#define U16D_LOG 12u                 // largest table log of this kernel: cells = newState (12 bits) | nbBits << 12
+#define U16D_LOG 12u                 // largest table log of this kernel: cells = newState (12 bits) | nbBits << 12; the kernel is instantiated for
+                                     // table slots of 4 KiB (table logs up to 11: 33 blocks per CU) and of 8 KiB (table log 12: 18 blocks per CU)
                                      // (measured: cells carrying 15 - nbBits, so that the bits are (t >> 17) >> field without the subtraction on the
                                      //  chain, run 2.4 % SLOWER -- 145.6 vs 149.0 GB/s -- the 64-bit shifts feeding it cost more than the subtraction)
-#define U16D_TAB (2u << U16D_LOG)    // LDS bytes per table slot
+#define U16D_TAB(LOG) (2u << (LOG))   // LDS bytes per table slot
 #define U16D_RING 64u                // state ring: one entry (4 cell indices, 8 bytes) per iteration
 #define U16D_IN_RING 256u
 #define U16D_IN_MIRROR 16u
 #define U16D_IN_CHUNK 64u
 #define U16D_PHASE 16                // iterations per phase (<= 6 bytes each)
 #define U16D_SRV_G 4
-#define U16D_SRV_WAVES 5
-#define U16D_MAXG (U16D_SRV_G * U16D_SRV_WAVES)
-#define U16D_THREADS (64 * (1 + U16D_SRV_WAVES))
+#define U16D_SRV_WAVES(LOG) ((LOG) >= 12u ? 5 : 9)
+#define U16D_MAXG(LOG) (U16D_SRV_G * U16D_SRV_WAVES(LOG))
+#define U16D_THREADS(LOG) (64 * (1 + U16D_SRV_WAVES(LOG)))
 #define U16D_LDS (160 * 1024)
 #define U16D_FLUSH_MIN 32u
 #ifndef U16D_UNROLL
@@ -94,6 +95,7 @@ DEV void u16d_ring_put(u32* rg, int off, u32 w)
 }
 
 // service wave: lane l (< 4) keeps the books of block g0 + l; the 16-lane group k moves the input chunk of block g0 + k
+template <u32 LOG>
 DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, int g0)
 {
     const int myG = g0 + (lane < U16D_SRV_G ? lane : 0);
@@ -157,9 +159,9 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
             if ((u32)lane < cnt) {
                 const u32 ri = (fp_g + (u32)lane) & (U16D_RING - 1);
                 const uint2 rec = *(const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + 8u * ri);
-                // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 13)
-                yq[l][0] = tg[__builtin_amdgcn_ubfe(rec.x, 1u, U16D_LOG)]; yq[l][1] = tg[__builtin_amdgcn_ubfe(rec.x, 17u, U16D_LOG)];
-                yq[l][2] = tg[__builtin_amdgcn_ubfe(rec.y, 1u, U16D_LOG)]; yq[l][3] = tg[__builtin_amdgcn_ubfe(rec.y, 17u, U16D_LOG)];
+                // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1 + LOG)
+                yq[l][0] = tg[__builtin_amdgcn_ubfe(rec.x, 1u, LOG)]; yq[l][1] = tg[__builtin_amdgcn_ubfe(rec.x, 17u, LOG)];
+                yq[l][2] = tg[__builtin_amdgcn_ubfe(rec.y, 1u, LOG)]; yq[l][3] = tg[__builtin_amdgcn_ubfe(rec.y, 17u, LOG)];
             }
         }
         if (fillK) u16d_ring_put(rgK, fillOff, pend);
@@ -179,35 +181,42 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
     }
 }
 
-// LDS: G tables of 8 KiB on table-size aligned addresses | U16Ctl[G] | per block: state ring (64 x 8 B), input ring (256 + 16 B)
-__global__ __launch_bounds__(U16D_THREADS) void k_u16_decode_lds(U16DArgs a, int G, u32 slotBytes)
+// the blocks of an instance: marked by k_u16_dprep (state 1) and of its table-log class
+template <u32 LOG> DEV bool u16d_mine(const U16Meta& m) { return m.state == 1 && (LOG >= 12u ? m.tableLog >= 12u : m.tableLog < 12u); }
+
+// LDS: G table slots (4 or 8 KiB) on table-size aligned addresses | U16Ctl[G] | per block: state ring (64 x 8 B), input ring (256 + 16 B).
+// A workgroup takes G consecutive blocks of the batch and decodes those of its class; the other instance's launch takes the rest (a batch
+// of one class -- blocks of one size and kind, as a caller of FSE_decompressU16 cuts them -- fills every slot of one of the two).
+template <u32 LOG>
+__global__ __launch_bounds__(U16D_THREADS(LOG)) void k_u16_decode_lds(U16DArgs a, int G, u32 slotBytes)
 {
+    constexpr u32 TAB = U16D_TAB(LOG), THREADS = U16D_THREADS(LOG);
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t first = (size_t)blockIdx.x * G;
     u8* const lds8 = (u8*)lds;
-    U16Ctl* const ctlAll = (U16Ctl*)(lds8 + (size_t)G * U16D_TAB);
+    U16Ctl* const ctlAll = (U16Ctl*)(lds8 + (size_t)G * TAB);
     u8* const ldsb = (u8*)ctlAll + (size_t)G * sizeof(U16Ctl);
     const size_t nTab = a.nBlocks - first < (size_t)G ? a.nBlocks - first : (size_t)G;
 
     // ---- stage the chain cells of every block this kernel decodes (LDS-DMA: 1 KiB per wave instruction)
-    for (u32 p = (u32)wave; p < (u32)nTab * (U16D_TAB >> 10); p += U16D_THREADS / 64) {
-        const u32 g = p >> 3, k = p & 7u;
-        if (a.meta[first + g].state != 1) continue;                      // uniform per wave
+    for (u32 p = (u32)wave; p < (u32)nTab * (TAB >> 10); p += THREADS / 64) {
+        const u32 g = p / (TAB >> 10), k = p % (TAB >> 10);
+        if (!u16d_mine<LOG>(a.meta[first + g])) continue;                 // uniform per wave
         const u8* const src = (const u8*)(a.cells + ((first + g) << FSEHIP_FSEU16_MAX_TABLELOG)) + 1024u * k + 16u * (u32)lane;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds8 + (size_t)g * U16D_TAB + 1024u * k), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds8 + (size_t)g * TAB + 1024u * k), 16, 0, 0);
     }
 
     // ---- per-block set-up by the decoder wave: lane g walks block first + g
     const int gsl = lane;
     const bool inRange = wave == 0 && gsl < G && first + (size_t)gsl < a.nBlocks;
     const size_t b = inRange ? first + (size_t)gsl : 0;
-    bool owner = inRange && a.meta[b].state == 1;
+    bool owner = inRange && u16d_mine<LOG>(a.meta[b]);
     const u32 tl = owner ? a.meta[b].tableLog : 0u;
     const u32 ldsBase = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)lds8;
-    if (ldsBase & (U16D_TAB - 1)) __builtin_trap();                      // the records carry 16 address bits: slots are table-size aligned
-    const u32 tabOff = ldsBase + (u32)(gsl < G ? gsl : 0) * U16D_TAB;
+    if (ldsBase & (TAB - 1)) __builtin_trap();                           // the records carry 16 address bits: slots are table-size aligned
+    const u32 tabOff = ldsBase + (u32)(gsl < G ? gsl : 0) * TAB;
     const u16* const A = (const u16*)(lds8 + (tabOff - ldsBase));
     const u16* const syms = (const u16*)(a.cells + (b << FSEHIP_FSEU16_MAX_TABLELOG)) + ((size_t)1 << FSEHIP_FSEU16_MAX_TABLELOG);
     const u8* in = nullptr; size_t S = 0; u16* out = nullptr;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(U16D_THREADS) void k_u16_decode_lds(U16DArgs a, int
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);                                  // vmcnt(0): the LDS-DMA pieces have landed
     __syncthreads();
-    if (wave >= 1) { u16d_service(ldsb, ctlAll, slotBytes, G, lane, (wave - 1) * U16D_SRV_G); return; }
+    if (wave >= 1) { u16d_service<LOG>(ldsb, ctlAll, slotBytes, G, lane, (wave - 1) * U16D_SRV_G); return; }
 
     __builtin_amdgcn_s_setprio(3);
     uint2* const myRing = (uint2*)(ldsb + (size_t)(gsl < G ? gsl : 0) * slotBytes);
@@ -312,14 +321,21 @@ __global__ __launch_bounds__(U16D_THREADS) void k_u16_decode_lds(U16DArgs a, int
     a.results[b] = result;
 }
 
+template <u32 LOG>
+static hipError_t u16d_launch(const U16DArgs& a, hipStream_t s)
+{
+    const hipError_t e = ensure_dyn_lds((const void*)k_u16_decode_lds<LOG>, U16D_LDS);
+    if (e != hipSuccess) return e;
+    const u32 slotBytes = U16D_RING * 8 + U16D_IN_RING + U16D_IN_MIRROR;
+    int G = (int)((U16D_LDS - 16) / (U16D_TAB(LOG) + slotBytes + sizeof(U16Ctl)));
+    if (G > U16D_MAXG(LOG)) G = U16D_MAXG(LOG);
+    hipLaunchKernelGGL(k_u16_decode_lds<LOG>, dim3((unsigned)((a.nBlocks + G - 1) / G)), dim3(U16D_THREADS(LOG)), U16D_LDS, s, a, G, slotBytes);
+    return hipGetLastError();
+}
 hipError_t launch_u16_decode_lds(const U16DArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    const hipError_t e = ensure_dyn_lds((const void*)k_u16_decode_lds, U16D_LDS);
+    const hipError_t e = u16d_launch<11>(a, s);                           // table logs up to 11: 4 KiB slots
     if (e != hipSuccess) return e;
-    const u32 slotBytes = U16D_RING * 8 + U16D_IN_RING + U16D_IN_MIRROR;
-    int G = (int)((U16D_LDS - 16) / (U16D_TAB + slotBytes + sizeof(U16Ctl)));
-    if (G > U16D_MAXG) G = U16D_MAXG;
-    hipLaunchKernelGGL(k_u16_decode_lds, dim3((unsigned)((a.nBlocks + G - 1) / G)), dim3(U16D_THREADS), U16D_LDS, s, a, G, slotBytes);
-    return hipGetLastError();
+    return u16d_launch<12>(a, s);                                         // table log 12: 8 KiB slots
 }

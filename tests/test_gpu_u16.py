@@ -333,3 +333,37 @@ def test_reference_u16_fuzzer_on_device(hip):
     p = subprocess.run([exe, "-s1", "-i150"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "Error" not in out, out[-2000:]
+
+
+def test_u16_decode_mixed_table_log_classes(hip, ref):
+    """One FSE_decompressU16 batch whose blocks alternate between the decoder's table-log classes (csrc/fse_u16_decode.hip: 4 KiB slots for
+    table logs up to 11, 8 KiB slots for 12): every workgroup of every launch finds blocks of the other
+    classes in its range and must leave them alone.  Results and symbols against the compiled reference, block by block."""
+    rng = np.random.default_rng(23)
+    n, nb = 20000, 150
+    logs = (12, 9, 11, 13, 12, 10, 12, 11, 0)
+    host = np.stack([u16_block(rng, n, KINDS[b % len(KINDS)]) for b in range(nb)])
+    dev = torch.from_numpy(host.view(np.int16)).cuda()
+    rows, sizes = [None] * nb, [0] * nb
+    for tl in sorted(set(logs)):
+        idx = [b for b in range(nb) if logs[b % len(logs)] == tl]
+        cd, cr = hip.fse_compress_u16_batch(dev[idx].contiguous(), table_log=tl)
+        torch.cuda.synchronize()
+        cdh, crh = cd.cpu().numpy(), cr.cpu().numpy()
+        for k, b in enumerate(idx):
+            rows[b], sizes[b] = cdh[k], int(crh[k])
+    keep = [b for b in range(nb) if sizes[b] > 1]                       # (0 / 1: not compressible / one repeated symbol -- no stream to decode)
+    assert len(keep) > 100
+    seen = set()
+    for b in keep:
+        seen.add(int(rows[b][0]) & 15)                                  # the header's first four bits: table log - 5
+    assert {4, 5, 6, 7} <= seen, seen                                   # table logs 9 ... 12 are all present (13 asked for: capped at 12 for 20000 symbols)
+    cdst = torch.from_numpy(np.stack([rows[b] for b in keep])).cuda()
+    cres = torch.tensor([sizes[b] for b in keep], dtype=torch.int64, device="cuda")
+    out, dres = hip.fse_decompress_u16_batch(cdst, cres, n)
+    torch.cuda.synchronize()
+    out_h, dres_h = out.cpu().numpy().view(np.uint16), dres.cpu().numpy()
+    for k, b in enumerate(keep):
+        rr, rout = ref.fse_decompress_u16(rows[b][:sizes[b]], n)
+        assert int(dres_h[k]) == s64(rr) == n, (b, dres_h[k], rr)
+        assert (out_h[k, :n] == rout[:n]).all() and (out_h[k, :n] == host[b]).all(), b
