@@ -35,7 +35,7 @@
 // ---- LDS of the builders (one wave per block) ------------------------------------------------------------------------------
 // TLMAX = the largest table log the instance builds: the cell -> symbol map is most of the footprint, and the footprint is what bounds
 // the builders (latency-bound, one wave per block: waves per CU).  The compress side never goes beyond 12 (k_u16_cprep), a stream may
-// carry 13: k_u16_dprep<12> leaves such blocks (meta.state 4) to a second launch of the 13-bit instance -- 12.5 KB -> 12 waves per CU
+// carry 13: k_u16_dprep<12> leaves such blocks (still marked U16_PARSED) to a second launch of the 13-bit instance -- 12.5 KB -> 12 waves per CU
 // instead of 7 for everything the reference's compressor writes.
 template <u32 TLMAX>
 struct U16Lds {
@@ -154,13 +154,53 @@ __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
     for (u32 s = lane; s < U16_SYMS; s += 64) { L.cnt[s] = 0; L.nrm[s] = 0; }
     if (lane < 8) L.scal[lane] = 0;
     __syncthreads();
-    bool over = false;
-    for (size_t i = lane; i < n; i += 64) { const u32 s = src[i]; if (s > maxSV) over = true; else atomicAdd(&L.cnt[s], 1u); }
+    // Four columns per symbol (col4[symbol][lane & 3], in the cell -> symbol map's space, which is idle until the spread): the lanes of one LDS
+    // pass that hold the same symbol spread over four words, and the source arrives in 16-byte loads, one 4 KiB group ahead of the updates
+    // (hist.hip's scheme).  Round 4 counted with one 2-byte load per lane and step into a single column: 1.12 ms per 25k blocks of 32 KB,
+    // more than the wave encoder behind it.
+    static_assert(sizeof(L.symTab) >= U16_SYMS * 4 * sizeof(u32), "the count columns live in the cell -> symbol map");
+    u32* const col4 = (u32*)L.symTab;
+    for (u32 i = lane; i < U16_SYMS; i += 64) ((uint4*)col4)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (__any(over)) { if (lane == 0) { a.results[b] = FERR(maxSymbolValue_tooSmall); if (a.meta) a.meta[b] = m; } return; }
+    u32 over = 0;
+    {   const u32 col = lane & 3u;
+        auto add = [&](u32 sy) { over |= sy > maxSV ? 1u : 0u; atomicAdd(&col4[((sy < U16_SYMS ? sy : U16_SYMS - 1u) << 2) | col], 1u); };   // (a symbol beyond the limit is an error: what it counts into is never read)
+        auto add8 = [&](const uint4& v) { add(v.x & 0xFFFFu); add(v.x >> 16); add(v.y & 0xFFFFu); add(v.y >> 16); add(v.z & 0xFFFFu); add(v.z >> 16); add(v.w & 0xFFFFu); add(v.w >> 16); };
+        size_t head = (size_t)(((0 - (uintptr_t)src) & 15u) >> 1);           // symbols in front of the first 16-byte boundary
+        if (head > n) head = n;
+        if (lane < head) add(src[lane]);
+        const uint4* const v = (const uint4*)(src + head);
+        const size_t nvec = (n - head) >> 3;
+        size_t i = lane;
+        if (i + 192 < nvec) {
+            uint4 x0 = v[i], x1 = v[i + 64], x2 = v[i + 128], x3 = v[i + 192];
+            for (;;) {
+                const size_t j = i + 256;
+                const bool more = j + 192 < nvec;
+                uint4 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
+                if (more) { y0 = v[j]; y1 = v[j + 64]; y2 = v[j + 128]; y3 = v[j + 192]; }
+                __asm__ volatile("" ::: "memory");                          // keep the next group's loads above this group's LDS updates
+                add8(x0); add8(x1); add8(x2); add8(x3);
+                i = j;
+                if (!more) break;
+                x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            }
+        }
+        for (; i < nvec; i += 64) { const uint4 x = v[i]; add8(x); }
+        const size_t done = head + (nvec << 3);
+        if (lane < n - done) add(src[done + lane]);
+    }
+    __syncthreads();
+    if (__any(over != 0)) { if (lane == 0) { a.results[b] = FERR(maxSymbolValue_tooSmall); if (a.meta) a.meta[b] = m; } return; }
     u32 c[U16_SPL], top = 0, big = 0;
 #pragma unroll
-    for (int i = 0; i < U16_SPL; ++i) { const u32 s = U16_SPL * lane + i; c[i] = L.cnt[s]; if (c[i]) top = s; big = c[i] > big ? c[i] : big; }
+    for (int i = 0; i < U16_SPL; ++i) {
+        const u32 s = U16_SPL * lane + i;
+        const uint4 q = ((const uint4*)col4)[s];
+        c[i] = q.x + q.y + q.z + q.w; L.cnt[s] = c[i];
+        if (c[i]) top = s; big = c[i] > big ? c[i] : big;
+    }
+    __syncthreads();                                                         // (col4 is read: the map's space may be written again)
     top = wg_max<64>(top); big = wg_max<64>(big);
     if (n == 0) top = 0;
     if (countOnly) {
@@ -438,33 +478,56 @@ __global__ void k_u16_encode(U16CArgs a)
 }
 
 // ---- decompress side ------------------------------------------------------------------------------------------------------------
+// The NCount header is a serial variable-length code (ncount_reader.h): one LANE per block reads it -- 64 headers per wave -- into a row of
+// LDS, and the rows leave as coalesced 640-byte pieces into the head of the block's table slot, where the builder picks them up.  (Until round
+// 5 lane 0 of the builder's wave read the header while 63 lanes waited: 0.22 of the 0.49 ms k_u16_dprep took per 25k blocks.)
+#define U16_PARSED 5u
+#define U16_NRM_ROW (U16_SYMS + 2)                  // s16 per LDS row: 161 dwords, odd, so the 64 lanes' rows start on different banks
+__global__ __launch_bounds__(64) void k_u16_dparse(U16DArgs a)
+{
+    __shared__ s16 rows[64 * U16_NRM_ROW];
+    const u32 lane = threadIdx.x;
+    const size_t b0 = (size_t)blockIdx.x * 64, b = b0 + lane;
+    for (u32 i = lane; i < 64 * U16_NRM_ROW / 2; i += 64) ((u32*)rows)[i] = 0;
+    __syncthreads();
+    if (b < a.nBlocks) {                                                     // fseU16.c:316-325
+        const u8* const in = a.csrc + b * a.cStride;
+        const size_t cSize = a.cSizes ? a.cSizes[b] : a.uniformCSize;
+        U16Meta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
+        size_t r = 0; u32 maxSV = U16_MAXSV, tl = 0;
+        if (cSize < 2) r = FERR(srcSize_wrong);
+        else {
+            r = ncount_read<1>(rows + lane * U16_NRM_ROW, &maxSV, &tl, in, cSize);
+            if (!is_err(r) && tl > U16_MAXTL) r = FERR(tableLog_tooLarge);   // FSE_buildDTable's check (fse_decompress.c:83)
+            if (!is_err(r) && r >= cSize) r = FERR(srcSize_wrong);           // nothing behind the header (undefined in the reference)
+        }
+        if (is_err(r)) a.results[b] = r;
+        else { m.state = U16_PARSED; m.hdrSize = (u32)r; m.tableLog = tl; m.maxSV = maxSV; }
+        a.meta[b] = m;
+    }
+    __syncthreads();
+    const size_t nRows = a.nBlocks - b0 < 64 ? a.nBlocks - b0 : 64;
+    for (size_t k = 0; k < nRows; ++k) {                                     // (rows of headers that failed are written too: nobody reads them)
+        u32* const out = a.cells + ((b0 + k) << U16_MAXTL);
+        const u32* const row = (const u32*)(rows + k * U16_NRM_ROW);
+        for (u32 i = lane; i < U16_SYMS / 2; i += 64) out[i] = row[i];
+    }
+}
+
 template <u32 TLMAX>
 __global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
 {
     __shared__ U16Lds<TLMAX> L;
     const u32 lane = threadIdx.x;
     const size_t b = blockIdx.x;
-    if (TLMAX > 12 && a.meta[b].state != 4) return;                          // (second launch: only what the 12-bit instance left)
-    const u8* const in = a.csrc + b * a.cStride;
-    const size_t cSize = a.cSizes ? a.cSizes[b] : a.uniformCSize;
-    U16Meta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0;
-    for (u32 s = lane; s < U16_SYMS; s += 64) L.nrm[s] = 0;
-    __syncthreads();
-    if (lane == 0) {                                                         // fseU16.c:316-325
-        size_t r = 0; u32 maxSV = U16_MAXSV, tl = 0;
-        if (cSize < 2) r = FERR(srcSize_wrong);
-        else {
-            r = ncount_read<1>(L.nrm, &maxSV, &tl, in, cSize);
-            if (!is_err(r) && tl > U16_MAXTL) r = FERR(tableLog_tooLarge);   // FSE_buildDTable's check (fse_decompress.c:83)
-            if (!is_err(r) && r >= cSize) r = FERR(srcSize_wrong);           // nothing behind the header (undefined in the reference)
-        }
-        L.scal[0] = (u32)r; L.scal[1] = (u32)(r >> 32); L.scal[2] = maxSV; L.scal[3] = tl;
+    U16Meta m = a.meta[b];
+    if (m.state != U16_PARSED || m.tableLog > TLMAX) return;                 // uniform: nothing to build, or the wide instance's block (second launch)
+    {   const u32* const nrmIn = a.cells + (b << U16_MAXTL);                 // the counters k_u16_dparse left (zero beyond the header's last symbol)
+        for (u32 i = lane; i < U16_SYMS / 2; i += 64) ((u32*)L.nrm)[i] = nrmIn[i];
     }
-    __syncthreads();
-    const size_t r = ((size_t)L.scal[1] << 32) | L.scal[0];
-    if (is_err(r)) { if (lane == 0) { a.results[b] = r; a.meta[b] = m; } return; }
-    const u32 maxSV = L.scal[2], tl = L.scal[3], ts = 1u << tl;
-    if (tl > TLMAX) { m.state = 4; if (lane == 0) a.meta[b] = m; return; }    // uniform: the wide instance's block
+    __syncthreads();                                                         // (every lane has read the slot's head: the tables may overwrite it)
+    const size_t r = m.hdrSize;
+    const u32 maxSV = m.maxSV, tl = m.tableLog, ts = 1u << tl;
     // Two table formats in the block's 32 KiB slot.  Table logs up to 12 (all the reference's compressor writes): the CHAIN cells
     // newState | nbBits << 12 as 16-bit words (the image k_u16_decode_lds keeps in LDS) followed, 16 KiB further on, by the 16-bit symbol
     // of every cell (gathered by its service waves) -- state 1.  Table log 13 needs 17 bits per chain cell: one 32-bit word per cell
@@ -533,7 +596,9 @@ hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s)
 hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_u16_dprep<12>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_u16_dparse, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_u16_dprep<11>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);         // 8.6 KB of LDS: 18 waves per CU (the builders are latency-bound)
+    hipLaunchKernelGGL(k_u16_dprep<12>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);         // 12.7 KB: 12 waves; returns at once for what is built
     hipLaunchKernelGGL(k_u16_dprep<U16_MAXTL>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);   // table log 13 (returns at once otherwise)
     const hipError_t e = launch_u16_decode_lds(a, s);                     // table logs up to 12: chain cells in LDS
     if (e != hipSuccess) return e;

@@ -286,9 +286,10 @@ def test_decompress_u16_table_log_13(hip, ref):
     assert done >= 8
 
 
-def test_u16_batch_ragged(hip, ref):
+@pytest.mark.parametrize("width", [9000, 9003, 2501])        # row strides of 18000 (16-byte aligned rows), 18006 and 5002 bytes (rows on every 2-byte phase of a 16-byte line)
+def test_u16_batch_ragged(hip, ref, width):
     rng = np.random.default_rng(7)
-    nb, width = 97, 9000
+    nb = 97
     sizes = rng.integers(0, width + 1, nb)
     sizes[:6] = (0, 1, 2, width, width, 3)
     host = np.zeros((nb, width), np.uint16)
