@@ -529,11 +529,11 @@ __global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
     const size_t r = m.hdrSize;
     const u32 maxSV = m.maxSV, tl = m.tableLog, ts = 1u << tl;
     // Two table formats in the block's 32 KiB slot.  Table logs up to 12 (all the reference's compressor writes): the CHAIN cells
-    // newState | nbBits << 12 as 16-bit words (the image k_u16_decode_lds keeps in LDS) followed, 16 KiB further on, by the 16-bit symbol
-    // of every cell (gathered by its service waves) -- state 1.  Table log 13 needs 17 bits per chain cell: one 32-bit word per cell
+    // newState | nbBits << 12 as 16-bit words (the image k_u16_decode_lds keeps in LDS) followed, 16 KiB further on, by the 9-bit symbols
+    // of the cells, packed (gathered by its service waves) -- state 1.  Table log 13 needs 17 bits per chain cell: one 32-bit word per cell
     // for the lane-per-block kernel -- state 3.
     u32* const cells = a.cells + (b << U16_MAXTL);
-    u16* const cells16 = (u16*)cells; u16* const syms16 = cells16 + ((size_t)1 << U16_MAXTL);
+    u16* const cells16 = (u16*)cells; u32* const syms9 = (u32*)(cells16 + ((size_t)1 << U16_MAXTL));
     const bool wide = tl > 12;
     u16_spread_rank(L, maxSV, tl, lane, [&](u32 u, u32 s, u32 rk) {       // FSE_buildDTable (fse_decompress.c:116-123)
         const int v = L.nrm[s];
@@ -541,8 +541,24 @@ __global__ __launch_bounds__(64) void k_u16_dprep(U16DArgs a)
         const u32 nb = tl - hibit32(next);
         const u32 ns = ((next << nb) - ts) & 0xFFFFu;
         if (wide) cells[u] = ns | (nb << 16) | (s << 20);
-        else { cells16[u] = (u16)(ns | (nb << 12)); syms16[u] = (u16)s; }      // (fse_u16_decode.hip: U16D_LOG)
+        else cells16[u] = (u16)(ns | (nb << 12));                              // (fse_u16_decode.hip: U16D_LOG)
     });
+    // The symbols of the cells, for the decoder's service waves to gather: 9 bits each, packed (cell u at bit 9u: 2.3 KB at table log 11).  As
+    // 16-bit words (4 KB) the tables of the 33 blocks a CU decodes at once did not fit the 4 MB of L2 an XCD's 32 CUs share: 294 KB per block
+    // were fetched from beyond it (round 5 counters), 40 KB now.  A lane packs 32 cells into nine words.
+    if (!wide) {
+        __syncthreads();
+        for (u32 j = lane; j < (ts >> 5); j += 64) {                         // (table log 12: two rounds)
+            const u16* const sy = L.symTab + 32u * j;
+            u32* const out = syms9 + 9u * j;
+            unsigned long long acc = 0; u32 nacc = 0, w = 0;
+#pragma unroll
+            for (u32 i = 0; i < 32; ++i) {
+                acc |= (unsigned long long)sy[i] << nacc; nacc += 9;
+                if (nacc >= 32) { out[w++] = (u32)acc; acc >>= 32; nacc -= 32; }
+            }
+        }
+    }
     m.state = wide ? 3u : 1u; m.hdrSize = (u32)r; m.tableLog = tl; m.maxSV = maxSV;
     if (lane == 0) a.meta[b] = m;
 }

@@ -4,7 +4,7 @@
 // parallelism is blocks: as many chains per CU as LDS holds tables.  What the chain needs per cell is nbBits and newState -- 16 bits
 // for table logs up to 12 -- so a table is 8 KiB of LDS and one 160 KB workgroup per CU carries 18 blocks; the 9-bit symbols are not
 // on the chain: like k_fse_decode, the decoder lane only appends the states it decoded FROM to a ring in LDS and service waves turn
-// them into symbols (gathered from the block's 16-bit symbol table in global memory, L2-resident) and store them as coalesced rows.
+// them into symbols (gathered from the block's packed 9-bit symbol table in global memory, L2-resident) and store them as coalesced rows.
 //   workgroup = 1 decoder wave (lane g walks block g: registers + LDS only) + 5 service waves (4 blocks each: input-ring refills of
 //   64 bytes, state-ring records -> 8 output bytes each), talking through per-block control words in LDS.
 // The bulk loop takes iterations of 4 symbols; the reference reloads its reader in front of EVERY symbol (fseU16.c:289), and a reload
@@ -87,6 +87,13 @@ DEV void u16d_phase(u32& sRef, u32& qRef, u32& bqRef, u32 tabOff, u32 myIn, uint
     sRef = s; qRef = q; bqRef = bq;
 }
 
+// symbol of a cell: 9 bits at bit 9 * state of the packed table k_u16_dprep leaves behind the chain cells (an unaligned 2-byte load)
+typedef u16 __attribute__((aligned(1))) u16d_u16u;
+DEV u32 u16d_sym_g(const __attribute__((address_space(1))) u8* base, u32 state)
+{
+    const u32 bit = state * 9u;
+    return ((u32)*(const __attribute__((address_space(1))) u16d_u16u*)(base + (bit >> 3)) >> (bit & 7u)) & 0x1FFu;
+}
 DEV void u16d_ring_put(u32* rg, int off, u32 w)
 {
     const u32 j = (u32)off & (U16D_IN_RING - 1);
@@ -111,7 +118,7 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
     const int SgK = __shfl(S32, grp, WAVE);
     // (global-address-space pointers: a flat_* access would count on lgkmcnt too and every LDS wait of this wave would wait for the
     //  symbol gathers in flight -- fse_decode.hip)
-    typedef const __attribute__((address_space(1))) u8* g_u8; typedef const __attribute__((address_space(1))) u16* g_u16;
+    typedef const __attribute__((address_space(1))) u8* g_u8;
     typedef u32 __attribute__((aligned(1))) u32_u; typedef unsigned long long __attribute__((aligned(1))) u64_u;
     const g_u8 igK = (g_u8)(uintptr_t)__shfl(inBits, grp, WAVE);
     u32* const rgK = (u32*)(ldsb + (size_t)(g0 + grp) * slotBytes + U16D_RING * 8);
@@ -155,13 +162,13 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
         for (int l = 0; l < U16D_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
-            const g_u16 tg = (g_u16)(uintptr_t)__shfl(symBits, l, WAVE);
+            const g_u8 tg = (g_u8)(uintptr_t)__shfl(symBits, l, WAVE);
             if ((u32)lane < cnt) {
                 const u32 ri = (fp_g + (u32)lane) & (U16D_RING - 1);
                 const uint2 rec = *(const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + 8u * ri);
                 // a record holds the low 16 bits of 4 cell addresses; the tables are table-size aligned: state = address bits [1, 1 + LOG)
-                yq[l][0] = tg[__builtin_amdgcn_ubfe(rec.x, 1u, LOG)]; yq[l][1] = tg[__builtin_amdgcn_ubfe(rec.x, 17u, LOG)];
-                yq[l][2] = tg[__builtin_amdgcn_ubfe(rec.y, 1u, LOG)]; yq[l][3] = tg[__builtin_amdgcn_ubfe(rec.y, 17u, LOG)];
+                yq[l][0] = u16d_sym_g(tg, __builtin_amdgcn_ubfe(rec.x, 1u, LOG)); yq[l][1] = u16d_sym_g(tg, __builtin_amdgcn_ubfe(rec.x, 17u, LOG));
+                yq[l][2] = u16d_sym_g(tg, __builtin_amdgcn_ubfe(rec.y, 1u, LOG)); yq[l][3] = u16d_sym_g(tg, __builtin_amdgcn_ubfe(rec.y, 17u, LOG));
             }
         }
         if (fillK) u16d_ring_put(rgK, fillOff, pend);
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(U16D_THREADS(LOG)) void k_u16_decode_lds(U16DArgs a
     if (ldsBase & (TAB - 1)) __builtin_trap();                           // the records carry 16 address bits: slots are table-size aligned
     const u32 tabOff = ldsBase + (u32)(gsl < G ? gsl : 0) * TAB;
     const u16* const A = (const u16*)(lds8 + (tabOff - ldsBase));
-    const u16* const syms = (const u16*)(a.cells + (b << FSEHIP_FSEU16_MAX_TABLELOG)) + ((size_t)1 << FSEHIP_FSEU16_MAX_TABLELOG);
+    const u8* const syms = (const u8*)((const u16*)(a.cells + (b << FSEHIP_FSEU16_MAX_TABLELOG)) + ((size_t)1 << FSEHIP_FSEU16_MAX_TABLELOG));   // 9-bit symbols, packed
     const u8* in = nullptr; size_t S = 0; u16* out = nullptr;
     const size_t cap = a.dstCapacity;
     BitReader r; r.base = nullptr; r.size = 0; r.at = 0; r.win = 0; r.used = 0;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(U16D_THREADS(LOG)) void k_u16_decode_lds(U16DArgs a
     // ---- literal: fseU16.c:288-298 on the LDS cells and the symbol table in global memory
     auto step = [&]() {
         const u32 c = A[state];
-        const u16 sym = syms[state];
+        const u16 sym = (u16)u16d_sym_g((const __attribute__((address_space(1))) u8*)(uintptr_t)syms, state);
         const u32 low = r.read(c >> 12);
         state = (c & 0xFFFu) + low;
         return sym;

@@ -12,7 +12,7 @@
 R=$(pwd)
 RUN=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
-for codec in ${PROFILE_CODECS:-fse huf}; do
+for codec in $([ -n "$PROFILE_U16_ONLY" ] || echo ${PROFILE_CODECS:-fse huf}); do
     O=$R/gpurun_out/${RUN}_$codec
     mkdir -p $O
     B="python $R/bench.py --codec $codec --no-configs --plain"
@@ -27,6 +27,7 @@ for codec in ${PROFILE_CODECS:-fse huf}; do
     tail -1 $O/trace.log | cut -c1-300
 done
 [ -n "$PROFILE_CODECS" ] && exit 0      # PROFILE_CODECS=fse scripts/profile.sh <run>: only the codec passes above (a kernel of theirs changed)
+if [ -z "$PROFILE_U16_ONLY" ]; then     # PROFILE_U16_ONLY=1 PROFILE_CODECS= scripts/profile.sh <run>: only the 16-bit coder's passes
 # BASELINE config 3 (Proba80, FSE): kernel trace + HBM traffic passes;  16-bit symbols and the using-table calls: kernel traces (their
 # kernels run beside the headline's in one bench run; the rows are told apart by kernel name / call count)
 O=$R/gpurun_out/${RUN}_p80
@@ -45,6 +46,7 @@ B="python $R/bench.py --codec both --workload mixed --no-configs --plain"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B $P > $O/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $B --steps 5 --warmup 2 > $O/trace.log 2>&1
+fi
 # the 16-bit-symbol coder: its kernels (k_u16_*) beside the headline's in one run
 O=$R/gpurun_out/${RUN}_u16pmc
 mkdir -p $O
@@ -52,13 +54,14 @@ B="python $R/bench.py --codec fse --configs fse_u16 --u16-blocks 20000 --plain"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B $P > $O/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B $P > $O/write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $B --steps 5 --warmup 2 > $O/trace.log 2>&1
-for extra in fse_u16 using_tables; do
+for extra in fse_u16 ${PROFILE_U16_ONLY:+} $([ -z "$PROFILE_U16_ONLY" ] && echo using_tables); do
     O=$R/gpurun_out/${RUN}_$extra
     mkdir -p $O
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --codec fse --configs $extra --plain --steps 5 --warmup 2 > $O/trace.log 2>&1
 done
 # the using-table calls, one record per run (the headline of the same run uses the record's distribution, so that kernels both of them launch see one kind
 # of data); python scripts/pmc_summary.py --ut gpurun_out/<run> <tag> 20000 turns them into profiles/traffic_<kernel>_ut_<key>.json
+[ -n "$PROFILE_U16_ONLY" ] && exit 0
 for rec in fse_p14:fse:14 fse_p80:fse:80 huf_p14:fse:14; do
     key=${rec%%:*}; rest=${rec#*:}; codec=${rest%%:*}; proba=${rest#*:}
     O=$R/gpurun_out/${RUN}_ut_$key
