@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
         const size_t b = first + g;
         if (b >= a.nBlocks) break;
         if (a.meta && fse_enc_skip(a.meta[b].state, a.onlyState)) continue;
+        if (a.sizeSplit && view_size(a.src, b) >= FSE_ENC_WAVE_MIN) continue;    // the wave kernel's block
         const u32* t = a.ctables + b * a.ctStrideU32;
         const u32 h = t[0];
         // symbols are bytes: entries above 255 of a table with a larger maxSymbolValue (FSE_buildCTable_raw with nbBits > 8,
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
     if (b >= a.nBlocks) return;
     u32 hdr = 0;
     if (a.meta) { if (fse_enc_skip(a.meta[b].state, a.onlyState)) return; hdr = a.meta[b].hdrSize; }
+    if (a.sizeSplit && view_size(a.src, b) >= FSE_ENC_WAVE_MIN) return;
 
     const u32 h0 = a.ctables[b * a.ctStrideU32];
     const u32 tl = h0 & 0xFFFFu;

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
     const size_t n64 = on ? view_size(a.src, b) : 0;
     u8* const dst = a.dst + (on ? b : 0) * a.dstStride + hdr;
     const size_t cap = a.dstCapacity - hdr;
+    if (on && a.sizeSplit && n64 < FSE_ENC_WAVE_MIN) on = false;              // the lane-per-block kernel's block (internal.h)
     if (on && n64 >= ((size_t)1 << 31)) { if (hl == 0) a.results[b] = FERR(srcSize_wrong); on = false; }
     const u32 n = (u32)n64;
     if (on && (n <= 2 || cap <= 8)) { if (hl == 0) a.results[b] = 0; on = false; }    // fse_compress.c:566-568

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a, u32 capTs)
     // lane-per-block kernel.  (The wave kernel re-checks exactly and hands further blocks over at run time.)
     int top1 = nn[0] > nn[1] ? nn[0] : nn[1]; top1 = nn[2] > top1 ? nn[2] : top1; top1 = nn[3] > top1 ? nn[3] : top1;
     top1 = wave_max_i32(top1);
-    m.state = ((u32)top1 * 64u > (63u << tl)) ? FSE_ENC_LANE : FSE_ENC_PAR;
+    m.state = ((u32)top1 * 64u > (63u << tl) || n < FSE_ENC_WAVE_MIN) ? FSE_ENC_LANE : FSE_ENC_PAR;     // (short blocks: 64 lanes do not pay, internal.h)
     {   // pace bin for the encoder's block order (internal.h): tableSize / symbols in use = the merging time of two encoder states
         u32 present = (nn[0] != 0) + (nn[1] != 0) + (nn[2] != 0) + (nn[3] != 0);
         present = wg_sum<64>(present);

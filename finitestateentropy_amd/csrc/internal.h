@@ -60,6 +60,7 @@ struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per b
     unsigned slotU32;            // LDS words per table slot
     size_t nBlocks;
     unsigned onlyState;          // with meta: 0 = every prepared block, else only blocks whose meta.state equals it
+    unsigned sizeSplit;          // without meta, ragged batch: 1 = the wave kernel takes the blocks of FSE_ENC_WAVE_MIN bytes and more, the lane kernel the others
     u32* list; u32* count;       // wave kernel, one-shot path: FSE_EBINS lists of the FSE_ENC_PAR blocks by pace (nBlocks entries apart) and their
 };                               // lengths (device memory, filled by launch_fse_encode_auto), or nullptr: blocks in order
 // A wave of the encoder carries two blocks and lasts as long as the slower one; how long a block takes follows its table (few symbols:
@@ -67,19 +68,29 @@ struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per b
 enum { FSE_EBINS = 4 };
 // meta.state on the compress side: 0 = finished by the prepare kernel, FSE_ENC_PAR / FSE_ENC_LANE = table ready, preferred kernel
 enum { FSE_ENC_PAR = 1, FSE_ENC_LANE = 2 };
+#define FSE_ENC_WAVE_MIN 2048u   // bytes: below this a block's 32 lanes of the wave kernel do not pay; k_fse_cprep marks such blocks FSE_ENC_LANE
 __host__ __device__ inline bool fse_enc_skip(unsigned state, unsigned onlyState) { return state == 0 || (onlyState != 0 && state != onlyState); }
 hipError_t launch_fse_encode(FseEncArgs a, hipStream_t s);
 size_t fse_encode_blocks_per_round(unsigned maxTableLog);
 hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s);
 hipError_t launch_fse_enc_lists(const FseEncArgs& a, hipStream_t s);     // fills a.list / a.count from meta (state == FSE_ENC_PAR, pace)  // block-parallel variant (one wave per block, streaming I/O)
-// picks the wave-per-block kernel for uniformly sized blocks of >= 2 KiB, the lane-per-block kernel otherwise (both exact)
-// With prepare-kernel metadata the choice is per block (k_fse_cprep marks extremely skewed tables FSE_ENC_LANE, the wave
-// kernel hands over blocks it cannot write word-wise): both kernels are launched and each one skips the other's blocks.
+// The wave-per-block kernel takes the blocks of FSE_ENC_WAVE_MIN bytes and more, the lane-per-block kernel the others (both exact).  A batch
+// of uniformly sized blocks needs one launch; otherwise the choice is per block and both kernels are launched, each skipping the other's
+// blocks: with prepare-kernel metadata by meta.state (k_fse_cprep marks short blocks and extremely skewed tables FSE_ENC_LANE, the wave
+// kernel hands over blocks it cannot write word-wise), without it (caller tables, ragged batch) by the block's size.  (Until round 5 a
+// ragged batch went to the lane-per-block kernel whole: 75 instead of 600 GB/s for blocks of 20-64 KB.)
 inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
 {
-    a.onlyState = 0;
-    if (a.src.sizes || a.src.uniform < 2048 || a.dstCapacity > 0x7FFFFFF0u) return launch_fse_encode(a, s);
-    if (!a.meta) { a.list = nullptr; a.count = nullptr; return launch_fse_encode_wave(a, s); }
+    a.onlyState = 0; a.sizeSplit = 0;
+    const bool ragged = a.src.sizes || a.src.offsets;
+    if (a.dstCapacity > 0x7FFFFFF0u || (!ragged && a.src.uniform < FSE_ENC_WAVE_MIN)) return launch_fse_encode(a, s);
+    if (!a.meta) {
+        a.list = nullptr; a.count = nullptr;
+        if (!ragged) return launch_fse_encode_wave(a, s);
+        a.sizeSplit = 1;
+        const hipError_t e = launch_fse_encode_wave(a, s);
+        return e != hipSuccess ? e : launch_fse_encode(a, s);
+    }
     a.onlyState = FSE_ENC_PAR;
     hipError_t e = a.list ? launch_fse_enc_lists(a, s) : hipSuccess;
     if (e == hipSuccess) e = launch_fse_encode_wave(a, s);
