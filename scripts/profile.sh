@@ -12,6 +12,7 @@
 R=$(pwd)
 RUN=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
+P="--steps 2 --warmup 1 --blocks 20000"       # the counter passes: 3 launches of every kernel over 20000 blocks
 for codec in $([ -n "$PROFILE_U16_ONLY" ] || echo ${PROFILE_CODECS:-fse huf}); do
     O=$R/gpurun_out/${RUN}_$codec
     mkdir -p $O
