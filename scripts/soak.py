@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from finitestateentropy_amd.api import FseHip
-from oracle.oracle import Checker as Oracle
+from oracle.oracle import Checker as Oracle, Ref
 from test_gpu_fse import _random_blocks, s64, is_error
 
 FseHip.guard = 64 + 3 * (int(sys.argv[2]) % 2 if len(sys.argv) > 2 else 0)      # guard gaps behind every destination (tests/conftest.py), odd on odd first seeds
 hip = FseHip()
 oracle = Oracle()
+ref16 = Ref() if Ref.available() else None       # the 16-bit coder is checked against the compiled reference only
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time()
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -118,5 +119,54 @@ while time.time() - t0 < budget:
     packed, offsets = hip.compact_batch(slots_p, res_p, src)
     out_p, dres_p = hip.fse_decompress_packed_batch(packed, offsets, size, size)
     assert bool((dres_p == size).all()) and torch.equal(out_p, src), ("packed", seed, size)
+    # ragged batch: per-block sizes either side of the encoders' switch (csrc/internal.h launch_fse_encode_auto)
+    rs = rng.integers(0, size + 1, len(blocks)); rs[::3] = rng.integers(0, min(size, 2300) + 1, len(rs[::3])); rs[:3] = (min(size, 2047), min(size, 2048), size)
+    d_rs = torch.from_numpy(rs.astype(np.int64)).cuda()
+    rdst, rres = hip.fse_compress_batch(src, table_log=tl, sizes=d_rs)
+    rdst, rres = rdst.cpu().numpy(), rres.cpu().numpy()
+    for b in range(len(blocks)):
+        r, o = oracle.fse_compress2(blocks[b][:rs[b]], 255, tl)
+        assert rres[b] == s64(r), ("fse ragged size", seed, size, tl, b, rs[b], rres[b], r)
+        if not is_error(r) and r > 1:
+            assert (rdst[b][:r] == o[:r]).all(), ("fse ragged bytes", seed, size, tl, b, rs[b])
+    # 16-bit symbols (lib/fseU16.c): a batch of one size, every kind of content, a table log per iteration; streams back through the decoder,
+    # intact and damaged
+    if seed % 2 == 0 and ref16 is not None:
+        from test_gpu_u16 import u16_block, KINDS, MAXSV
+        nsym = int(rng.choice([int(rng.integers(1, 3000)), int(rng.integers(3000, 41000)), 16384, 2048, 2047]))
+        utl = int(rng.choice([0, 0, 5, 9, 11, 12, 13]))
+        kinds = KINDS + ("rle",)
+        hb = np.stack([u16_block(rng, nsym, kinds[b % len(kinds)]) for b in range(28)])
+        dev = torch.from_numpy(hb.view(np.int16)).cuda()
+        cd, cr = hip.fse_compress_u16_batch(dev, table_log=utl, sizes=nsym)
+        torch.cuda.synchronize()
+        cdh, crh = cd.cpu().numpy(), cr.cpu().numpy()
+        keep = []
+        for b in range(28):
+            rr, ro = ref16.fse_compress_u16(hb[b][:nsym], 0, utl, cap=cd.shape[1])
+            assert int(crh[b]) == s64(rr), ("u16 size", seed, nsym, utl, b, crh[b], rr)
+            if not is_error(rr) and rr > 1:
+                assert (cdh[b, :rr] == ro[:rr]).all(), ("u16 bytes", seed, nsym, utl, b)
+                keep.append(b)
+        if keep:
+            streams = cdh[keep].copy(); ssz = crh[keep].astype(np.int64).copy()
+            for i in range(0, len(keep), 3):                              # every third stream damaged -- behind its header: the reference
+                hdr = ref16.fse_read_ncount(streams[i][:ssz[i]], MAXSV)[0]  # is undefined (null dereference, tests/test_gpu_u16.py) for some damaged headers
+                if is_error(hdr) or hdr + 1 >= ssz[i]:
+                    continue
+                kind = int(rng.integers(0, 3))
+                if kind == 0: ssz[i] = int(rng.integers(hdr + 1, ssz[i]))
+                elif kind == 1: streams[i, int(rng.integers(hdr, ssz[i]))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                else: streams[i, ssz[i] - 1] = 0
+            for cap in sorted({nsym, max(nsym - 1, 1), nsym + 5}):
+                uo, ur = hip.fse_decompress_u16_batch(torch.from_numpy(streams).cuda(), torch.from_numpy(ssz).cuda(), cap)
+                torch.cuda.synchronize()
+                uoh, urh = uo.cpu().numpy().view(np.uint16), ur.cpu().numpy()
+                for i in range(len(keep)):
+                    rr, ro = ref16.fse_decompress_u16(streams[i][:ssz[i]], cap)
+                    assert int(urh[i]) == s64(rr), ("u16 dsize", seed, nsym, utl, cap, i, urh[i], rr)
+                    if not is_error(rr):
+                        assert (uoh[i, :rr] == ro[:rr]).all(), ("u16 dbytes", seed, nsym, utl, cap, i)
+        nblocks += 28
     nblocks += len(blocks)
 print("soak ok: seeds %d..%d, %d blocks, %.0f s" % (seed0 + 1, seed, nblocks, time.time() - t0))
