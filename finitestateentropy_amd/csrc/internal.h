@@ -260,12 +260,14 @@ struct U16CArgs {
 struct U16DArgs {
     u16* dst; size_t dstStrideBytes; size_t dstCapacity;                     // capacity in symbols
     const u8* csrc; size_t cStride; const size_t* cSizes; size_t uniformCSize;
-    u32* cells; U16Meta* meta;                                               // per block: 32 KiB of table in one of two formats (k_u16_dprep)
+    u32* cells; U16Meta* meta;                                               // per block a 32 KiB slot: first the normalised counters k_u16_dparse read from the header
+                                                                             // (640 bytes), then, over them, the table k_u16_dprep builds -- 16-bit chain cells + the packed
+                                                                             // 9-bit symbols 16 KiB further on (table logs up to 12), or 32-bit cells (table log 13)
     size_t* results; size_t nBlocks;
 };
 hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s);
 hipError_t launch_u16_decompress(const U16DArgs& a, hipStream_t s);
-hipError_t launch_u16_decode_lds(const U16DArgs& a, hipStream_t s);   // fse_u16_decode.hip: blocks k_u16_dprep marked state 1 (table log <= 12)
+hipError_t launch_u16_decode_lds(const U16DArgs& a, hipStream_t s);   // fse_u16_decode.hip: blocks k_u16_dprep marked state 1 (table log <= 12), one launch per slot class (<= 11 / 12)
 
 // ---- workload generator -----------------------------------------------------------------------------
 hipError_t launch_probagen(u8* dst, size_t dstStride, size_t blockSize, size_t nBlocks, const u8* d_table, u32 firstSeed, u32 seedStep, hipStream_t s);
