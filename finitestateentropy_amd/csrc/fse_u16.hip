@@ -128,11 +128,17 @@ DEV void u16_spread_rank(U16Lds<TLMAX>& L, u32 maxSV, u32 tl, u32 lane, Emit&& e
 }
 
 // ---- compress side: FSE_compressU16 up to the table (fseU16.c:203-249) -------------------------------------------------------
+// Two instances, launched one after the other: <11, false> for every block -- 8.6 KB of LDS, 18 waves per CU (the table build is latency-bound;
+// blocks of up to 16,384 symbols get table log 11 or less from FSE_optimalTableLog) -- which leaves a block whose table log comes out as 12
+// marked U16_WIDE, and <12, true>, which takes only those (12.7 KB, 12 waves per CU).
+#define U16_WIDE 6u
+template <u32 TLMAX, bool SECOND>
 __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
 {
-    __shared__ U16Lds<FSE_MAX_TL> L;                                        // (the compressor's table log is clamped to the byte coder's limit, see below)
+    __shared__ __attribute__((aligned(16))) U16Lds<TLMAX> L;                // (the compressor's table log is clamped to the byte coder's limit, see below)
     const u32 lane = threadIdx.x;
     const size_t b = blockIdx.x;
+    if (SECOND && a.meta[b].state != U16_WIDE) return;                       // uniform
     const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
     const size_t n = a.srcSizes ? a.srcSizes[b] : a.uniformSrcSize;
     const bool countOnly = a.countsOut != nullptr;
@@ -151,15 +157,12 @@ __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
     if (done) { if (lane == 0) { a.results[b] = result; if (a.meta) a.meta[b] = m; } return; }   // uniform
 
     // ---- FSE_countU16 (:121-146)
-    for (u32 s = lane; s < U16_SYMS; s += 64) { L.cnt[s] = 0; L.nrm[s] = 0; }
-    if (lane < 8) L.scal[lane] = 0;
-    __syncthreads();
-    // Four columns per symbol (col4[symbol][lane & 3], in the cell -> symbol map's space, which is idle until the spread): the lanes of one LDS
+    // Four columns per symbol (col4[symbol][lane & 3], over the head of L, all of which is idle until the counts are known): the lanes of one LDS
     // pass that hold the same symbol spread over four words, and the source arrives in 16-byte loads, one 4 KiB group ahead of the updates
     // (hist.hip's scheme).  Round 4 counted with one 2-byte load per lane and step into a single column: 1.12 ms per 25k blocks of 32 KB,
     // more than the wave encoder behind it.
-    static_assert(sizeof(L.symTab) >= U16_SYMS * 4 * sizeof(u32), "the count columns live in the cell -> symbol map");
-    u32* const col4 = (u32*)L.symTab;
+    static_assert(sizeof(L) >= U16_SYMS * 4 * sizeof(u32), "the count columns live in the builder's LDS");
+    u32* const col4 = (u32*)&L;
     for (u32 i = lane; i < U16_SYMS; i += 64) ((uint4*)col4)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     u32 over = 0;
@@ -197,10 +200,15 @@ __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
     for (int i = 0; i < U16_SPL; ++i) {
         const u32 s = U16_SPL * lane + i;
         const uint4 q = ((const uint4*)col4)[s];
-        c[i] = q.x + q.y + q.z + q.w; L.cnt[s] = c[i];
+        c[i] = q.x + q.y + q.z + q.w;
         if (c[i]) top = s; big = c[i] > big ? c[i] : big;
     }
-    __syncthreads();                                                         // (col4 is read: the map's space may be written again)
+    __syncthreads();                                                         // (col4 is read: L becomes the builder's)
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) L.cnt[U16_SPL * lane + i] = c[i];
+    for (u32 s = lane; s < U16_SYMS; s += 64) L.nrm[s] = 0;
+    if (lane < 8) L.scal[lane] = 0;
+    __syncthreads();
     top = wg_max<64>(top); big = wg_max<64>(big);
     if (n == 0) top = 0;
     if (countOnly) {
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
     // templates only): the calls at :231-240 reach the byte coder's objects, whose table-log limit is 12 -- a request of 13 passes
     // the check at :222 and is then clamped to 12.  (The decoder side does accept 13: FSE_buildDTableU16 is a template instance.)
     const u32 tl = wg_optimal_tablelog(tlReq, n, maxSV, 2, U16_DEFTL, FSE_MAX_TL);
+    if (tl > TLMAX) { m.state = U16_WIDE; if (lane == 0) a.meta[b] = m; return; }   // uniform: the second launch's block
     int nn[U16_SPL];
     size_t e = wg_normalize<64, U16_SPL, FSE_MAX_TL>(nn, c, (u64)n, maxSV, tl, lane);
     if (is_err(e)) { if (lane == 0) { a.results[b] = e; a.meta[b] = m; } return; }
@@ -602,8 +611,9 @@ __global__ void k_u16_decode(U16DArgs a)
 hipError_t launch_u16_compress(const U16CArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_u16_cprep, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((k_u16_cprep<11, false>), dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
     if (!a.countsOut) {
+        hipLaunchKernelGGL((k_u16_cprep<FSE_MAX_TL, true>), dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);   // table log 12 (returns at once otherwise)
         hipLaunchKernelGGL(k_u16_encode_wave, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_u16_encode, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
     }
