@@ -680,8 +680,8 @@ def secondary_roofline(hip, cd, dev_info):
 
 
 
-def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None):
-    hot = [k for k in HOT[codec_name] if k in per]
+def roofline(per, codec_name, mean_csize, nb, steps, traffic_tag=None, kernels=None):
+    hot = [k for k in (kernels or HOT[codec_name]) if k in per]
     if not hot:                                                   # --plain: no event probe ran
         return {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     dom = max(hot, key=lambda k: per[k][0])
@@ -780,6 +780,13 @@ def main():
     def reduce_max(values):
         return shard.max_over_ranks(values, dev, world)
 
+    # N > 1: the line says which transport carried the job and how many ranks answered on it (an all-reduce of ones over the default group)
+    rccl = None
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        rccl = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones.item())}
+
     wanted = set(k for k in args.configs.split(",") if k)
 
     def want(key):
@@ -838,6 +845,8 @@ def main():
     elapsed = vals[0]
     dom_codec = max(head_names, key=lambda n: max(r["per"].get(k, (0, 0))[0] for k in HOT[n]))
     head_roof = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, args.steps, traffic_tag="")
+    enc_roof = roofline(r["per"], dom_codec, r["csize"][dom_codec], nb, args.steps, traffic_tag="",
+                        kernels=[k for k in HOT[dom_codec] if "encode" in k])
     head_roof["measured_over"] = ("%d steps repeated with the event probe on, directly after the timed region (%.3f ms per step with the probe, %.3f without)"
                                   % (args.steps, r["probe_elapsed"] / args.steps * 1e3, r["elapsed"] / args.steps * 1e3))
     if rank == 0 and dom_codec == "fse" and not PLAIN:
@@ -930,6 +939,7 @@ def main():
         def give_up():
             if done.is_set():
                 return
+            sys.stderr.write("bench.py rank %d: the communication leg did not finish within %d s -- leaving\n" % (rank, args.comm_timeout)); sys.stderr.flush()
             if rank == 0:
                 emit_without("the communication leg did not finish within %d s (a transfer or a collective never completed); every other figure of this line was measured before it" % args.comm_timeout)
             os._exit(0)
@@ -963,9 +973,11 @@ def main():
                    "blocks_per_gpu": nb, "block_bytes": BLOCK, "codec": args.codec, "parity": head.get("parity"),
                    "compressed_bytes_per_block": head["%s_compressed_bytes_per_block" % head_names[0]]},
         "encode_GBps": head["%s_encode_GBps" % head_names[0]], "decode_GBps": head["%s_decode_GBps" % head_names[0]],
-        "roofline": head_roof,
+        "roofline": head_roof, "roofline_encode": enc_roof,
         "kernel_ms_per_step": head["kernel_ms_per_step"],
     }
+    if rccl is not None:
+        line["rccl"] = rccl
     if len(head_names) > 1:
         for n in head_names[1:]:
             line["%s_encode_GBps" % n] = head["%s_encode_GBps" % n]; line["%s_decode_GBps" % n] = head["%s_decode_GBps" % n]
@@ -978,13 +990,31 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, cpu_sample, head_names[0])
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
             line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": host_threads(), "kind": "unavailable", "sample": repr(e)}
+    def emit():
+        """detail file first, then the one short line (the last thing on stdout)"""
+        extra = {}
+        if rccl is not None:
+            extra["rccl"] = rccl
+            rec5 = configs.get("cfg5_mixed_1M")
+            if rec5:
+                extra["compute_only"] = {"value": rec5["value"], "ms_per_step": rec5["ms_per_step"]}
+                wc = rec5.get("with_comm")
+                if wc:
+                    pp = wc.get("pipelined_packed") or {}
+                    links = wc.get("root_link_GBps") or {}
+                    extra["with_comm"] = {"serial_ms": wc.get("ms"), "pipelined_ms": pp.get("ms"), "scatter_GBps": links.get("scatter"),
+                                          "gather_GBps": links.get("gather"), "roundtrip_ok": wc.get("roundtrip_ok")}
+                    if wc.get("error"):
+                        extra["with_comm"]["error"] = wc["error"][:160]
+        print(compact_line(line, extra, write_detail(line)))
+        sys.stdout.flush()
+
     if comm_leg is not None:
         def emit_without(why):
             configs["cfg5_mixed_1M"]["with_comm"] = {"value": None, "error": why}
-            print(json.dumps(line)); sys.stdout.flush()
+            emit()
         configs["cfg5_mixed_1M"]["with_comm"] = comm_leg_guarded(emit_without)
-    print(json.dumps(line))
-    sys.stdout.flush()
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -1103,6 +1133,61 @@ def with_comm_case(args, hip, shard, dev, rank, world, total, cds5, srcpool, bar
     rec["pipelined_packed"] = pipe
     del corpus, gather_out
     return rec
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_block", "avg_launch_ms")
+LINE_LIMIT = 4096          # the driver reads the LAST stdout line out of an 8 KB tail; round 5's 21 KB line was lost that way
+
+
+def compact_line(full, extra=None, detail_path=None):
+    """The ONE line rank 0 prints: the contract fields, one roofline per direction, the CPU baseline and a {value, ms_per_step, frac}
+    triple per BASELINE configuration (protocol: one short result line per run, programs/bench.c:458-468).  Everything else -- the
+    secondary roofline, host-inclusive figures, using-table calls, tableLog-12 and 16-bit records, notes -- is in the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full[k] for k in keep}
+    cfg = full["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "blocks_per_gpu", "block_bytes", "codec", "parity") if k in cfg}
+    line["encode_GBps"], line["decode_GBps"] = full["encode_GBps"], full["decode_GBps"]
+    line["roofline"] = {k: full["roofline"].get(k) for k in ROOF_KEYS}
+    if full.get("roofline_encode"):
+        line["roofline_encode"] = {k: full["roofline_encode"].get(k) for k in ROOF_KEYS}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "encode_MiBps", "decode_MiBps", "single_thread_value") if k in cb}
+    cfgs = {}
+    for key, rec in (full.get("configs") or {}).items():
+        if not key.startswith("cfg") or not isinstance(rec, dict) or "value" not in rec:
+            continue
+        roof = rec.get("roofline") or {}
+        cfgs[key] = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "frac": roof.get("frac"), "kernel": roof.get("kernel"),
+                     "parity_blocks_checked": rec.get("parity_blocks_checked")}
+    if cfgs:
+        line["configs"] = cfgs
+    for k, v in (extra or {}).items():
+        line[k] = v
+    line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:        # never lose the line to its own size: drop the optional parts, longest first
+        for k in ("configs", "roofline_encode", "with_comm", "compute_only"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+def write_detail(full):
+    """bench_detail.json beside bench.py (and under gpurun_out/ when that directory exists, so that a gpurun call brings it back)"""
+    path = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if d != ROOT and not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                json.dump(full, f, indent=1)
+            path = path or os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT)
+        except OSError:
+            pass
+    return path
 
 
 if __name__ == "__main__":

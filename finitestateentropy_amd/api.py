@@ -286,6 +286,37 @@ class FseHip:
                                                      C.c_uint(max_log), SZ(n), _ptr(ws), SZ(ws.numel()), _stream()), "FSE_buildDTable_batch")
         return dt, res
 
+    # ------------------------------------------------------------------ table glue, step by step (lib/fse.h:137-156, 222-229)
+    def fse_normalize_count_batch(self, counts, totals, max_symbol_values, table_log):
+        """FSE_normalizeCount per row of `counts` (n, 256) int32: (norms (n, 256) int16, results = tableLog or error)"""
+        n = counts.shape[0]
+        norms = torch.zeros((n, 256), dtype=torch.int16, device=counts.device)
+        res = torch.zeros(n, dtype=torch.int64, device=counts.device)
+        _check(self.lib.FSEHIP_FSE_normalizeCount_batch(_ptr(norms), SZ(256), C.c_uint(table_log), _ptr(counts), SZ(counts.stride(0)), _ptr(totals),
+                                                        _ptr(max_symbol_values), SZ(n), _ptr(res), _stream()), "FSE_normalizeCount_batch")
+        return norms, res
+
+    def fse_write_ncount_batch(self, norms, max_symbol_values, table_log, capacity=512, stride=None):
+        """FSE_writeNCount per row of `norms` (n, 256) int16: (headers (n, stride) uint8 pre-filled with 0xA5, results = header bytes or error)"""
+        n = norms.shape[0]
+        hdr = torch.full((n, stride or max(capacity, 1)), 0xA5, dtype=torch.uint8, device=norms.device)
+        res = torch.zeros(n, dtype=torch.int64, device=norms.device)
+        _check(self.lib.FSEHIP_FSE_writeNCount_batch(_ptr(hdr), SZ(hdr.stride(0)), SZ(capacity), _ptr(norms), SZ(norms.stride(0)), _ptr(max_symbol_values),
+                                                     C.c_uint(table_log), SZ(n), _ptr(res), _stream()), "FSE_writeNCount_batch")
+        return hdr, res
+
+    def fse_read_ncount_batch(self, headers, header_sizes, max_symbol_values):
+        """FSE_readNCount per row: (norms (n, 256) int16, maxSymbolValues out, tableLogs, results = bytes read or error)"""
+        n = _blocks(headers, "headers").shape[0]
+        norms = torch.zeros((n, 256), dtype=torch.int16, device=headers.device)
+        msv = max_symbol_values.clone()
+        tls = torch.zeros(n, dtype=torch.int32, device=headers.device)
+        res = torch.zeros(n, dtype=torch.int64, device=headers.device)
+        ps, uni, keep = _sizes_arg(header_sizes, headers)
+        _check(self.lib.FSEHIP_FSE_readNCount_batch(_ptr(norms), SZ(256), _ptr(msv), _ptr(tls), _ptr(headers), SZ(headers.stride(0)), ps, uni, SZ(n), _ptr(res),
+                                                    _stream()), "FSE_readNCount_batch")
+        return norms, msv, tls, res
+
     # ------------------------------------------------------------------ packed (variable-length) batches
     def compact_batch(self, slots, results, src, sizes=None, packed=None, offsets=None):
         """FSEHIP_compact_batch: (packed uint8 (capacity,), offsets int64 (n + 1,)); offsets[n] = the packed size"""

@@ -516,6 +516,32 @@ extern "C" int FSEHIP_FSE_buildCTable_batch(FSEHIP_FSE_CTable* d_ctables, size_t
     return 0;
 }
 
+// ---- the glue steps as calls of their own (fsehip.h "Table glue, step by step")
+extern "C" int FSEHIP_FSE_normalizeCount_batch(short* d_norms, size_t normStride, unsigned tableLog, const unsigned* d_counts, size_t countStride,
+                                               const size_t* d_totals, const unsigned* d_maxSymbolValues, size_t nBlocks, size_t* d_results, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    if (!d_norms || !d_counts || !d_totals || !d_maxSymbolValues || !d_results || normStride < 256 || countStride < 256) return (int)hipErrorInvalidValue;
+    return (int)launch_fse_glue_normalize((s16*)d_norms, normStride, tableLog, d_counts, countStride, d_totals, d_maxSymbolValues, d_results, nBlocks, (hipStream_t)stream);
+}
+extern "C" int FSEHIP_FSE_writeNCount_batch(void* d_headers, size_t headerStride, size_t headerCapacity, const short* d_norms, size_t normStride,
+                                            const unsigned* d_maxSymbolValues, unsigned tableLog, size_t nBlocks, size_t* d_results, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    if (!d_headers || !d_norms || !d_maxSymbolValues || !d_results || normStride < 256 || headerCapacity > headerStride) return (int)hipErrorInvalidValue;
+    return (int)launch_fse_glue_write_ncount((u8*)d_headers, headerStride, headerCapacity, (const s16*)d_norms, normStride, d_maxSymbolValues, tableLog, d_results, nBlocks,
+                                             (hipStream_t)stream);
+}
+extern "C" int FSEHIP_FSE_readNCount_batch(short* d_norms, size_t normStride, unsigned* d_maxSymbolValues, unsigned* d_tableLogs,
+                                           const void* d_headers, size_t headerStride, const size_t* d_headerSizes, size_t uniformHeaderSize,
+                                           size_t nBlocks, size_t* d_results, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    if (!d_norms || !d_maxSymbolValues || !d_tableLogs || !d_headers || !d_results) return (int)hipErrorInvalidValue;
+    return (int)launch_fse_glue_read_ncount((s16*)d_norms, normStride, d_maxSymbolValues, d_tableLogs, mkview(d_headers, headerStride, d_headerSizes, uniformHeaderSize),
+                                            d_results, nBlocks, (hipStream_t)stream);
+}
+
 extern "C" size_t FSEHIP_FSE_buildDTable_batch_workspaceSize(size_t nBlocks, unsigned maxLog) { return FSEHIP_FSE_decompress_batch_workspaceSize(nBlocks, maxLog); }
 extern "C" int FSEHIP_FSE_buildDTable_batch(FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, size_t* d_results,
                                             const void* d_headers, size_t headerStride, const size_t* d_headerSizes, size_t uniformHeaderSize,

@@ -242,6 +242,93 @@ hipError_t launch_fse_export_dtables(const FseDPrepArgs& a, u32* dtables, size_t
 #ifdef FSE_WB_TIMING
 extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_wbTiming(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wbTiming), sizeof(g_wbTiming)); }
 #endif
+// ---------------------------------------------------------------------------------------------------
+//  The glue steps as calls of their own (fsehip.h "Table glue, step by step"): the SAME wave routines k_fse_cprep / k_fse_dparse run
+//  (wg_normalize<64>, wg_write_ncount<64>, ncount_read), on caller-supplied counters / headers, so that the reference's own unit vectors for
+//  FSE_normalizeCount / FSE_writeNCount / FSE_readNCount (programs/fuzzer.c:325-417) can be put to the device exactly as written.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fse_glue_normalize(s16* norms, size_t normStride, u32 tlReq, const u32* counts, size_t countStride,
+                                                          const size_t* totals, const u32* maxSVs, size_t* results)
+{
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const u32 maxSV = maxSVs[b] > 255u ? 255u : maxSVs[b];
+    const u32* const cb = counts + b * countStride;
+    u32 c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = 4 * lane + i <= maxSV ? cb[4 * lane + i] : 0u;
+    int nn[4] = { 0, 0, 0, 0 };
+    const u32 tl = tlReq ? tlReq : FSE_DEF_TL;                                 // lib/fse_compress.c:434
+    const u64 total = (u64)totals[b];
+    size_t r = total ? wg_normalize<64>(nn, c, total, maxSV, tl, lane) : FERR(GENERIC);
+    if (!is_err(r)) r = tl;
+    s16* const nb = norms + b * normStride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (4 * lane + i <= maxSV && !is_err(r)) nb[4 * lane + i] = (s16)nn[i];
+    if (lane == 0) results[b] = r;
+}
+
+__global__ __launch_bounds__(64) void k_fse_glue_write_ncount(u8* headers, size_t headerStride, size_t headerCapacity, const s16* norms, size_t normStride,
+                                                             const u32* maxSVs, u32 tl, size_t* results)
+{
+    __shared__ u32 img[136];
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const u32 maxSV = maxSVs[b];
+    size_t r;
+    if (tl > FSE_MAX_TL) r = FERR(tableLog_tooLarge);                            // lib/fse_compress.c:281-282
+    else if (tl < FSE_MIN_TL || maxSV > 255u) r = FERR(GENERIC);
+    else {
+        const s16* const nb = norms + b * normStride;
+        int nn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nn[i] = 4 * lane + i <= maxSV ? (int)nb[4 * lane + i] : 0;
+        for (u32 i = lane; i < 136; i += 64) img[i] = 0;
+        __syncthreads();
+        r = wg_write_ncount<64>(img, headerCapacity, nn, maxSV, tl, lane);
+        __syncthreads();
+        if (!is_err(r)) {
+            u8* const dst = headers + b * headerStride;
+            const u8* const hb = (const u8*)img;
+            for (u32 i = lane; i < (u32)r; i += 64) dst[i] = hb[i];
+        }
+    }
+    if (lane == 0) results[b] = r;
+}
+
+__global__ __launch_bounds__(64) void k_fse_glue_read_ncount(s16* norms, size_t normStride, u32* maxSVs, u32* tableLogs, BlockView headers, size_t nBlocks, size_t* results)
+{
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= nBlocks) return;
+    u32 maxSV = maxSVs[b], tl = 0;
+    size_t r;
+    if ((size_t)maxSV >= normStride) r = FERR(maxSymbolValue_tooLarge);       // (the reference trusts its caller's array; a batch call can check)
+    else r = ncount_read<1>(norms + b * normStride, &maxSV, &tl, view_ptr(headers, b), view_size(headers, b));
+    if (!is_err(r)) { maxSVs[b] = maxSV; tableLogs[b] = tl; }
+    results[b] = r;
+}
+
+hipError_t launch_fse_glue_normalize(s16* norms, size_t normStride, u32 tl, const u32* counts, size_t countStride, const size_t* totals, const u32* maxSVs,
+                                     size_t* results, size_t nBlocks, hipStream_t s)
+{
+    if (nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fse_glue_normalize, dim3((unsigned)nBlocks), dim3(64), 0, s, norms, normStride, tl, counts, countStride, totals, maxSVs, results);
+    return hipGetLastError();
+}
+hipError_t launch_fse_glue_write_ncount(u8* headers, size_t headerStride, size_t headerCapacity, const s16* norms, size_t normStride, const u32* maxSVs, u32 tl,
+                                        size_t* results, size_t nBlocks, hipStream_t s)
+{
+    if (nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fse_glue_write_ncount, dim3((unsigned)nBlocks), dim3(64), 0, s, headers, headerStride, headerCapacity, norms, normStride, maxSVs, tl, results);
+    return hipGetLastError();
+}
+hipError_t launch_fse_glue_read_ncount(s16* norms, size_t normStride, u32* maxSVs, u32* tableLogs, const BlockView& headers, size_t* results, size_t nBlocks, hipStream_t s)
+{
+    if (nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fse_glue_read_ncount, dim3((unsigned)((nBlocks + 63) / 64)), dim3(64), 0, s, norms, normStride, maxSVs, tableLogs, headers, nBlocks, results);
+    return hipGetLastError();
+}
+
 hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;

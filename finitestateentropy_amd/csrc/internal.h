@@ -48,6 +48,12 @@ struct FseCPrepArgs {            // glue g1-g4 (compress side): lib/fse_compress
     size_t nBlocks;
 };
 hipError_t launch_fse_cprep(const FseCPrepArgs& a, hipStream_t s);
+// the glue steps as calls of their own (fse_tables.hip): FSE_normalizeCount / FSE_writeNCount / FSE_readNCount on caller-supplied counters and headers
+hipError_t launch_fse_glue_normalize(s16* norms, size_t normStride, u32 tl, const u32* counts, size_t countStride, const size_t* totals, const u32* maxSVs,
+                                     size_t* results, size_t nBlocks, hipStream_t s);
+hipError_t launch_fse_glue_write_ncount(u8* headers, size_t headerStride, size_t headerCapacity, const s16* norms, size_t normStride, const u32* maxSVs, u32 tl,
+                                        size_t* results, size_t nBlocks, hipStream_t s);
+hipError_t launch_fse_glue_read_ncount(s16* norms, size_t normStride, u32* maxSVs, u32* tableLogs, const BlockView& headers, size_t* results, size_t nBlocks, hipStream_t s);
 
 struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per block
     u8* dst; size_t dstStride; size_t dstCapacity;

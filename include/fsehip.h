@@ -269,6 +269,24 @@ FSEHIP_API int FSEHIP_HUF_readDTableX1_batch(FSEHIP_HUF_DTable* d_dtables, size_
                                              const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize,
                                              size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
 
+/* ---- Table glue, step by step: the reference's public FSE_normalizeCount (lib/fse.h:137-144, lib/fse_compress.c:431-494), FSE_writeNCount
+ * (lib/fse.h:150-156, lib/fse_compress.c:275-298) and FSE_readNCount (lib/fse.h:222-229, lib/entropy_common.c:41-144) as batch calls on counters /
+ * headers the CALLER supplies -- the same device routines FSE_buildCTable_batch / FSE_buildDTable_batch run between the histogram and the tables,
+ * reachable one step at a time (a caller with its own statistics; the reference's unit vectors, programs/fuzzer.c:325-417).
+ *   normalizeCount : d_counts + b*countStride holds count[0 .. maxSymbolValues[b]] (countStride, normStride >= 256 elements), d_totals[b] their sum;
+ *                    d_norms + b*normStride receives normalizedCounter[0 .. maxSymbolValues[b]]; d_results[b] = tableLog used (0 = default 11) or error.
+ *   writeNCount    : d_headers + b*headerStride receives at most headerCapacity bytes; d_results[b] = header size, or dstSize_tooSmall / GENERIC as
+ *                    the reference (no byte is written for a failed block).
+ *   readNCount     : d_maxSymbolValues[b] in = the alphabet limit (< normStride), out = last symbol described; d_tableLogs[b] out;
+ *                    d_results[b] = bytes read or error (maxSymbolValue_tooSmall, tableLog_tooLarge, corruption_detected). */
+FSEHIP_API int FSEHIP_FSE_normalizeCount_batch(short* d_norms, size_t normStride, unsigned tableLog, const unsigned* d_counts, size_t countStride,
+                                               const size_t* d_totals, const unsigned* d_maxSymbolValues, size_t nBlocks, size_t* d_results, void* stream);
+FSEHIP_API int FSEHIP_FSE_writeNCount_batch(void* d_headers, size_t headerStride, size_t headerCapacity, const short* d_norms, size_t normStride,
+                                            const unsigned* d_maxSymbolValues, unsigned tableLog, size_t nBlocks, size_t* d_results, void* stream);
+FSEHIP_API int FSEHIP_FSE_readNCount_batch(short* d_norms, size_t normStride, unsigned* d_maxSymbolValues, unsigned* d_tableLogs,
+                                           const void* d_headers, size_t headerStride, const size_t* d_headerSizes, size_t uniformHeaderSize,
+                                           size_t nBlocks, size_t* d_results, void* stream);
+
 /* ---- Packed (variable-length) batches.  The batched compressors write fixed-stride slots like the reference bench's buffers
  * (programs/bench.c:514-516); what the reference's container stores (programs/fileio.c:343-400) and what is worth moving between GPUs
  * or to the host is every block at its real size.  FSEHIP_compact_batch turns slots + results into records back to back:

@@ -13,10 +13,44 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
 
 
+# The modules that PIN the restatement (oracle/fse_oracle.c against the compiled reference, the golden vectors and the reference tool): they need
+# no GPU and run in the CPU suite; on a box with a GPU they additionally carry the `gpu` marker, so that the driver's `pytest -m gpu` run holds
+# the whole parity chain (restatement -> compiled reference -> golden vectors, kernels -> compiled reference) and deselects none of it.
+PIN_MODULES = ("test_oracle_vs_ref", "test_oracle_golden", "test_u16_golden", "test_frame_oracle")
+
+
+def _gpu_box():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    if not _gpu_box():
+        return
+    for item in items:
+        if item.module.__name__.split(".")[-1] in PIN_MODULES and item.get_closest_marker("gpu") is None:
+            item.add_marker(pytest.mark.gpu)
+
+
 @pytest.fixture(scope="session")
-def oracle():
+def restatement():
+    """oracle/fse_oracle.c alone (the CPU restatement): what the pin modules put against the compiled reference and the golden vectors"""
     from oracle.oracle import Oracle
     return Oracle()
+
+
+@pytest.fixture(scope="session")
+def oracle(request):
+    """What the kernels are compared with.  One hop wherever possible: the COMPILED REFERENCE (oracle/_ref/libfse_ref.so, which travels to the
+    GPU box) behind the restatement's interface -- `Checker` routes every codec entry point to it and keeps the restatement only for what the
+    reference library does not have (the probagen generator, the .fse frame, the checksums).  Without oracle/_ref it is the restatement.
+    (The pin modules override this fixture with `restatement`: there the restatement is the thing under test.)"""
+    from oracle.oracle import Checker
+    return Checker()
 
 
 @pytest.fixture(scope="session")

@@ -13,6 +13,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CLI = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "fse_cli")
 
 
+@pytest.fixture(scope="module")
+def oracle(restatement):
+    """here the restatement itself is under test (conftest.py: every other module's `oracle` is the compiled reference where present)"""
+    return restatement
+
+
 def _inputs(oracle):
     rng = np.random.default_rng(5)
     yield "empty", np.zeros(0, np.uint8)

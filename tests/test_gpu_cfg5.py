@@ -53,17 +53,31 @@ def _run_bench(extra, env=None, timeout=900):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    # the driver parses the LAST stdout line out of an 8 KB tail (round 5's 21 KB line was lost): it must stay short and be the last one
+    assert p.stdout.rstrip("\n").splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 4096, len(lines[0])
+    short = json.loads(lines[0])
+    with open(os.path.join(ROOT, short["detail"])) as f:
+        detail = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype"):
+        assert short[k] == detail[k], k
+    return short, detail
 
 
 def test_bench_two_ranks_start_from_gpus_flag():
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself, reports n_gpus == 2, codes the fixed corpus of
     config 5 as two shards (strong scaling) and round-trips the with-comm variant (scatter, both codecs, gather)."""
-    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "4096", "--cfg5-blocks", "3000", "--cfg5-total", "8001",
+    short, line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "4096", "--cfg5-blocks", "3000", "--cfg5-total", "8001",
                        "--configs", "cfg5_mixed_shard,cfg5_mixed_1M", "--no-cpu-baseline", "--no-host-inclusive", "--comm-passes", "2",
                        "--parity-blocks", "512"],
                       env={"FSEHIP_BENCH_BACKEND": "gloo"})
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    # the N > 1 line describes itself: transport, ranks that answered, config 5 compute-only and with the scatter / gather
+    assert short["rccl"] == {"backend": "gloo", "world": 2, "ranks_seen": 2}
+    assert short["compute_only"] == {"value": line["configs"]["cfg5_mixed_1M"]["value"], "ms_per_step": line["configs"]["cfg5_mixed_1M"]["ms_per_step"]}
+    swc = short["with_comm"]
+    assert swc["roundtrip_ok"] is True and swc["serial_ms"] > 0 and swc["pipelined_ms"] > 0 and swc["scatter_GBps"] > 0 and swc["gather_GBps"] > 0
+    assert set(short["configs"]) == {"cfg5_mixed_shard", "cfg5_mixed_1M"} and short["configs"]["cfg5_mixed_1M"]["value"] == short["compute_only"]["value"]
     weak, strong = line["configs"]["cfg5_mixed_shard"], line["configs"]["cfg5_mixed_1M"]
     assert weak["scaling"] == "weak" and weak["blocks_per_gpu"] == 3000
     assert strong["scaling"] == "strong" and strong["corpus_blocks"] == 8001 and strong["blocks_per_gpu"] == 4001
@@ -83,7 +97,7 @@ def test_bench_two_ranks_start_from_gpus_flag():
 def test_bench_two_ranks_comm_watchdog_keeps_the_line():
     """the with-comm leg runs last, under a watchdog: when it does not finish in time (here: at once) rank 0 still prints the line --
     every other figure in place, an error record where the leg's would be -- and every rank leaves"""
-    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "2048", "--cfg5-total", "6001",
+    short, line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "2048", "--cfg5-total", "6001",
                        "--configs", "cfg5_mixed_1M", "--no-cpu-baseline", "--no-host-inclusive", "--comm-passes", "2", "--parity-blocks", "256",
                        "--comm-timeout", "0"],
                       env={"FSEHIP_BENCH_BACKEND": "gloo"})
@@ -91,11 +105,25 @@ def test_bench_two_ranks_comm_watchdog_keeps_the_line():
     strong = line["configs"]["cfg5_mixed_1M"]
     assert strong["value"] > 0 and strong["corpus_blocks"] == 6001
     assert strong["with_comm"]["value"] is None and "did not finish within 0 s" in strong["with_comm"]["error"]
+    assert short["with_comm"]["serial_ms"] is None and "did not finish" in short["with_comm"]["error"] and short["compute_only"]["value"] == strong["value"]
 
 
 def test_bench_one_gpu_line_has_the_contract_fields():
-    line = _run_bench(["--steps", "2", "--warmup", "1", "--blocks", "8192", "--configs", "cfg5_mixed_1M", "--cfg5-total", "9000",
-                       "--no-cpu-baseline", "--parity-blocks", "256"])
+    short, line = _run_bench(["--steps", "2", "--warmup", "1", "--blocks", "8192", "--configs", "cfg5_mixed_1M", "--cfg5-total", "9000",
+                              "--cpu-sample-blocks", "1024", "--cpu-seconds", "0.2", "--parity-blocks", "256"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "roofline_encode", "cpu_baseline", "configs", "detail"):
+        assert k in short, k
+    for roof, side in ((short["roofline"], "decode"), (short["roofline_encode"], "encode")):
+        assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and side in roof["kernel"]
+        assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4 and roof["avg_launch_ms"] > 0
+        assert 32768 < roof["algorithmic_bytes_per_block"] < 2 * 32768
+    cb = short["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and "blocks" in cb["sample"]
+    assert short["config"]["blocks_per_gpu"] == 8192 and "workload" in short["config"] and "model" not in short["config"]
+    c5 = short["configs"]["cfg5_mixed_1M"]
+    assert c5["value"] == line["configs"]["cfg5_mixed_1M"]["value"] and 0 < c5["frac"] < 1
+    assert "rccl" not in short
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["dtype"] == "u8"

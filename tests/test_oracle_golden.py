@@ -1,6 +1,7 @@
 """The CPU restatement (oracle/fse_oracle.c) against (a) SURVEY.md Appendix B known answers and
 (b) the fixtures produced by the compiled reference (tests/golden/make_golden.py).  Runs anywhere."""
 import numpy as np
+import pytest
 
 from oracle.oracle import is_error
 
@@ -16,6 +17,12 @@ APPENDIX_B = {
     (2, 2): ("ddb9ec0bd3f76cf2", 255, 675, 28996, "cbff575b6c218da5", 28969, "69b24dffeb0b0015"),
     (2, 3): ("34a194ca9e6ac46f", 255, 654, 29003, "dd8592541084be06", 28963, "4d84693753e11fc8"),
 }
+
+
+@pytest.fixture(scope="module")
+def oracle(restatement):
+    """here the restatement itself is under test (conftest.py: every other module's `oracle` is the compiled reference where present)"""
+    return restatement
 
 
 def hx(v):

@@ -10,6 +10,12 @@ SIZES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 31, 100, 255, 256, 1
 PROBAS = (0, 1, 2, 14, 15, 20, 50, 80, 90, 99, 100)
 
 
+@pytest.fixture(scope="module")
+def oracle(restatement):
+    """here the restatement itself is under test (conftest.py: every other module's `oracle` is the compiled reference where present)"""
+    return restatement
+
+
 def block(oracle, P, n, seed):
     if n == 0:
         return np.zeros(0, np.uint8)
