@@ -563,8 +563,7 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
     hipError_t e = hipSuccess;
     if (!a.meta) {
         a.classLo = 0;
-        e = launch_huf_decode_par(a, HPAR_DATA_TINY, nullptr, nullptr, s);
-        a.classLo = HPAR_DATA_TINY;
+        if (HPAR_USE_TINY) { e = launch_huf_decode_par(a, HPAR_DATA_TINY, nullptr, nullptr, s); a.classLo = HPAR_DATA_TINY; }
         if (e == hipSuccess) e = launch_huf_decode_par(a, HPAR_DATA_SMALL, nullptr, nullptr, s);
         a.classLo = HPAR_DATA_SMALL;
         if (e == hipSuccess) e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
@@ -597,6 +596,7 @@ hipError_t launch_huf_decode_classes(HufDecArgs a, u32* lists, u32* counts, hipS
         const int kind = c >> 1, ser = 2 * HUF_DKIND_SERIAL + (c & 1);
         a.list = lists + (size_t)c * a.nBlocks; a.count = counts + c;
         a.ldsLog = (c & 1) ? FSEHIP_HUF_TABLELOG_MAX : HD_SLOT_LOG;
+        if (kind == HUF_DKIND_PAR_TINY && !HPAR_USE_TINY) continue;           // (nothing is filed there)
         if (kind == HUF_DKIND_SERIAL) e = huf_decode_launch(a, s);
         else e = launch_huf_decode_par(a, kind == HUF_DKIND_PAR_TINY ? HPAR_DATA_TINY : kind == HUF_DKIND_PAR_SMALL ? HPAR_DATA_SMALL : HPAR_DATA_LARGE, lists + (size_t)ser * a.nBlocks, counts + ser, s);
     }

@@ -60,65 +60,242 @@ DEV u32 hpar_single(u32 arr, u32& C, u32 tabOff, u32 mask2)
     return c;
 }
 
-// four symbols per iteration, the loop of hd_bulk_phase (huf_decode.hip) on the flat consumption-order array
+// Four symbols per iteration on the flat consumption-order array.  The kernel is bound by instruction issue (EXPERIMENTS.md section 3, round 6), so the
+// loop is laid out for instruction count: the cursor is ONE number, QA = (consumed bits - 1) + 8 * (LDS byte address of the array) -- the
+// bit address of the bit below the next unread one -- and every iteration reads its three window dwords afresh at (QA >> 3) & ~3 (two
+// address instructions, two LDS reads, two v_alignbit) instead of sliding a register window by selects (round 5: fourteen instructions).
+// Per symbol: v_and (cell address), ds_read_u16, v_alignbit + v_lshrrev (drop the code's bits), v_perm (collect the byte).
 struct HparBulk {
-    u32 arr, q4, bq, w0, w1, w2, lo;
-    DEV void open(u32 a, u32 C)
-    {
-        arr = a;
-        const u32 Q = C - 1u;
-        q4 = (Q >> 5) << 2; bq = Q & 31u;
-        const hpar_lds_u32 wp = (hpar_lds_u32)(uintptr_t)(arr + q4);
-        w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
-        lo = __builtin_amdgcn_alignbit(w1, w0, bq);
-    }
-    DEV u32 cursor() const { return (q4 << 3) + bq + 1u; }
+    u32 QA, bias;
+    DEV void open(u32 arr, u32 C) { bias = 8u * arr - 1u; QA = C + bias; }
+    DEV u32 cursor() const { return QA - bias; }
+    DEV u32 q_of(u32 C) const { return C + bias; }
     DEV u32 iter(u32 tabOff, u32 mask2)                                   // returns the four symbols, first in the low byte
     {
-        const hpar_lds_u32 np = (hpar_lds_u32)(uintptr_t)(arr + q4 + 12u);
-        const u32 n0 = np[0], n1 = np[1];                                  // the two dwords behind the window
-        const u32 c1 = hpar_cell(lo, mask2, tabOff);
-        u32 l = __builtin_amdgcn_alignbit(w1, w0, bq), h = __builtin_amdgcn_alignbit(w2, w1, bq);
+        const hpar_lds_u32 wp = (hpar_lds_u32)(uintptr_t)((QA >> 3) & ~3u);
+        const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        u32 l = __builtin_amdgcn_alignbit(w1, w0, QA), h = __builtin_amdgcn_alignbit(w2, w1, QA);   // (the shift is QA & 31: 8 * arr is a multiple of 32)
+        const u32 c1 = hpar_cell(l, mask2, tabOff);
         l = __builtin_amdgcn_alignbit(h, l, c1); h >>= (c1 & 31u);
         const u32 c2 = hpar_cell(l, mask2, tabOff);
         l = __builtin_amdgcn_alignbit(h, l, c2); h >>= (c2 & 31u);
         const u32 c3 = hpar_cell(l, mask2, tabOff);
-        l = __builtin_amdgcn_alignbit(h, l, c3); h >>= (c3 & 31u);
+        l = __builtin_amdgcn_alignbit(h, l, c3);
         const u32 c4 = hpar_cell(l, mask2, tabOff);
-        lo = __builtin_amdgcn_alignbit(h, l, c4);
         u32 word = __builtin_amdgcn_perm(c1, 0u, 0x03020105u);
         word = __builtin_amdgcn_perm(c2, word, 0x03020500u);
         word = __builtin_amdgcn_perm(c3, word, 0x03050100u);
         word = __builtin_amdgcn_perm(c4, word, 0x05020100u);
-        const u32 bqn = bq + ((c1 + c2 + c3 + c4) & 0xFFu);
-        const bool k1 = bqn >= 32u, k2 = bqn >= 64u;
-        w0 = k2 ? w2 : (k1 ? w1 : w0);
-        w1 = k2 ? n0 : (k1 ? w2 : w1);
-        w2 = k2 ? n1 : (k1 ? n0 : w2);
-        q4 += (bqn >> 5) << 2;
-        bq = bqn & 31u;
+        QA += (c1 + c2 + c3 + c4) & 0xFFu;
         return word;
     }
 };
 
-// decode from C up to the first boundary at or beyond `limit`, counting symbols: four at a time while that certainly stays below
-// the limit, then four at a time on trial -- the iteration that crosses the limit is taken back and redone symbol by symbol
+// decode from C up to the first boundary at or beyond `limit`, counting symbols: four at a time until an iteration crosses the limit; that
+// iteration is taken back and redone symbol by symbol
 DEV u32 hpar_run(u32 arr, u32& C, u32 limit, u32 tabOff, u32 mask2)
 {
     u32 n = 0;
     if (C < limit) {
         HparBulk bk; bk.open(arr, C);
-        while (C + HPAR_NEAR < limit) { (void)bk.iter(tabOff, mask2); n += 4; C = bk.cursor(); }
-        for (;;) {                                                         // (at most a dozen trial iterations)
-            const HparBulk keep = bk;
-            (void)bk.iter(tabOff, mask2);
-            const u32 Cn = bk.cursor();
-            if (Cn >= limit) { bk = keep; break; }
-            n += 4; C = Cn;
-        }
-        while (C < limit) { (void)hpar_single(arr, C, tabOff, mask2); ++n; }   // at most four
+        const u32 limQ = bk.q_of(limit);
+        u32 Qh;
+        do { Qh = bk.QA; (void)bk.iter(tabOff, mask2); n += 4; } while (bk.QA < limQ);
+        n -= 4; C = Qh - bk.bias;
+        while (C < limit) { (void)hpar_single(arr, C, tabOff, mask2); ++n; }   // one to four
     }
     return n;
+}
+
+// The same walk KEEPING its symbols: iteration k's four bytes stay in register sym[k] (the loop is fully unrolled so that every index is
+// static; all lanes step together, a lane whose range is done sits out).  The iteration that crosses the limit is kept whole -- its first
+// symbols are the range's last -- and redone symbol by symbol for the exact boundary and count.  A lane that needs more than HPAR_KEEP
+// iterations (a stretch of very short codes) counts on without keeping and reports `spill`: the piece then takes the re-decoding pass 2.
+#ifndef HPAR_KEEP
+#define HPAR_KEEP 48                  // iterations kept = 192 symbols per lane and piece (a lane's share of a stream averages 128)
+#endif
+DEV u32 hpar_run_keep(u32 arr, u32& C, u32 limit, u32 tabOff, u32 mask2, u32 (&sym)[HPAR_KEEP], bool& spill)
+{
+    u32 n = 0;
+    spill = false;
+    bool active = C < limit;
+    if (__any(active)) {
+        HparBulk bk; bk.open(arr, C);
+        const u32 limQ = bk.q_of(limit);
+        u32 Qh = bk.QA;
+#pragma unroll
+        for (int k = 0; k < HPAR_KEEP; ++k) {
+            if (active) {
+                Qh = bk.QA;
+                sym[k] = bk.iter(tabOff, mask2);
+                n = 4u * (u32)k;                                           // symbols in front of the iteration taken last
+                active = bk.QA < limQ;
+            }
+            if (!__any(active)) break;                                     // uniform
+        }
+        C = bk.cursor();
+        if (active) { spill = true; n += 4u + hpar_run(arr, C, limit, tabOff, mask2); }   // (rare)
+        else if (C >= limit && bk.QA != Qh) {                              // (took at least one iteration)
+            C = Qh - bk.bias;
+            while (C < limit) { (void)hpar_single(arr, C, tabOff, mask2); ++n; }     // one to four
+        }
+    }
+    return n;
+}
+
+// pass 2 from the registers: lane's n symbols to p -- single bytes up to a 4-byte boundary, then the register stream shifted by that many
+// bytes (v_alignbyte) in 16-byte stores, the last 1..15 bytes as dwords and bytes.  Static register indices throughout (unrolled).
+__device__ __attribute__((always_inline)) void hpar_store_kept(u8* p, u32 n, const u32 (&sym)[HPAR_KEEP])
+{
+    u32 a = (0u - (u32)(uintptr_t)p) & 3u;
+    a = a < n ? a : n;
+    {   const u32 w = sym[0];
+        if (a > 0) p[0] = (u8)w;
+        if (a > 1) p[1] = (u8)(w >> 8);
+        if (a > 2) p[2] = (u8)(w >> 16); }
+    p += a;
+    u32 left = n - a;
+#pragma unroll
+    for (int g = 0; g < HPAR_KEEP / 4; ++g) {
+        if (left == 0) continue;
+        u32 w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = 4 * g + t;
+            const u32 hi = k + 1 < HPAR_KEEP ? sym[k + 1 < HPAR_KEEP ? k + 1 : k] : 0u;
+            w[t] = __builtin_amdgcn_alignbyte(hi, sym[k], a);
+        }
+        if (left >= 16) { __builtin_memcpy(p, w, 16); p += 16; left -= 16; }
+        else {
+            if (left >= 4) __builtin_memcpy(p, &w[0], 4);
+            if (left >= 8) __builtin_memcpy(p + 4, &w[1], 4);
+            if (left >= 12) __builtin_memcpy(p + 8, &w[2], 4);
+            const u32 r = left >= 12 ? w[3] : left >= 8 ? w[2] : left >= 4 ? w[1] : w[0];
+            u8* const t = p + (left & ~3u);
+            const u32 m = left & 3u;
+            if (m > 0) t[0] = (u8)r;
+            if (m > 1) t[1] = (u8)(r >> 8);
+            if (m > 2) t[2] = (u8)(r >> 16);
+            left = 0;
+        }
+    }
+}
+
+// pass 2 through an LDS line buffer (the stream's staging area, idle once its links are verified): the piece's output is taken in chunks of
+// CH bytes of the 16-byte grid of the DESTINATION (logical byte x of the piece <-> global address gBase + x, gBase 16-byte aligned, the
+// piece's first byte at x = h).  A lane's run is [s, s + n): `a` single bytes up to the dword grid, then its register stream shifted by `a`
+// bytes (v_alignbyte) as dwords D0 + k, D0 = (s + a) / 4.  Per chunk, every lane whose first dword lies in the chunk or at most HPAR_KEEP
+// dwords in front of it drops ALL its words into the buffer, last word first, without asking which of them are real: a word beyond the
+// lane's last falls into the territory of a LATER lane at one of that lane's EARLIER words (runs follow one another in lane order), and
+// going downwards that lane writes there afterwards -- so the real word always lands last.  The buffer has HPAR_KEEP dwords of slack on
+// either side for what sticks out of the chunk.  Two instructions per word (v_alignbyte, ds_write_b32 at a static offset), no predicate.
+// Then the 1..3 bytes in front of each lane's first dword (behind all words: a neighbour's last word carries garbage there), and the wave
+// copies the chunk out with one aligned 16-byte store per lane, 1 KiB per instruction: every line of the destination is written once and
+// whole (the first and last 16-byte unit of a piece may be partial: those go byte by byte).
+// The workgroup is ONE wave: its LDS operations execute in order, so "everything before is visible to every lane" needs no barrier and, above
+// all, no wait for the wave's global stores (which __syncthreads' workgroup-scope fence brings along).  A compiler-level fence keeps the order.
+DEV void hpar_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+typedef __attribute__((address_space(3))) u32* hpar_lds_w32;
+typedef __attribute__((address_space(3))) u8* hpar_lds_w8;
+#define HPAR_FLUSH_SLACK (4u * HPAR_KEEP)
+template <u32 CH>
+DEV void hpar_flush_kept(u32 bufOff, u8* gBase, u32 h, u32 total, u32 s, u32 n, const u32 (&sym)[HPAR_KEEP], u32 lane)
+{
+    const u32 end = h + total;                                            // logical end of the piece's output
+    const u32 a0 = (0u - s) & 3u, a = a0 < n ? a0 : n;                    // bytes in front of my first whole dword
+    const u32 D0 = (s + a) >> 2;
+    const u32 nW = (n - a + 3u) >> 2;                                     // my dwords (the last may carry up to 3 bytes of garbage)
+    const u32 nWmax = __builtin_amdgcn_readfirstlane(wave_max_u32(nW));
+    const u32 chunk = bufOff + HPAR_FLUSH_SLACK;                          // LDS address of the chunk's first byte
+    for (u32 c0 = 0; c0 < end; c0 += CH) {                                // uniform
+        hpar_wave_sync();                                                 // (the buffer's previous content is done with)
+        const int rel = (int)D0 - (int)(c0 >> 2);                         // my first dword relative to the chunk
+        if (nW != 0 && rel >= -(int)HPAR_KEEP && rel < (int)(CH >> 2)) {     // (a lane without a whole dword has no territory: its D0 lies inside a neighbour's)
+            const u32 wordAddr = chunk + 4u * (u32)rel;                   // (>= bufOff)
+#pragma unroll
+            for (int k = HPAR_KEEP - 1; k >= 0; --k) {
+                if ((u32)k < nWmax) {                                     // uniform
+                    const u32 hi = sym[k + 1 < HPAR_KEEP ? k + 1 : k];
+                    *(hpar_lds_w32)(uintptr_t)(wordAddr + 4u * (u32)k) = __builtin_amdgcn_alignbyte(hi, sym[k], a);
+                }
+            }
+        }
+        hpar_wave_sync();
+        {   const u32 w = sym[0];
+#pragma unroll
+            for (u32 i = 0; i < 3; ++i) {
+                const u32 x = s + i;
+                if (i < a && x - c0 < CH) *(hpar_lds_w8)(uintptr_t)(chunk + (x - c0)) = (u8)(w >> (8u * i));
+            }
+        }
+        hpar_wave_sync();
+        // copy out: unit = 16 bytes at logical c0 + 16 u
+#pragma unroll
+        for (u32 r = 0; r < CH / 1024u; ++r) {
+            const u32 x = c0 + 1024u * r + 16u * lane;
+            if (x + 16u <= h || x >= end) continue;
+            typedef u32 hpar_v4 __attribute__((ext_vector_type(4)));
+            const hpar_v4 v = *(const __attribute__((address_space(3))) hpar_v4*)(uintptr_t)(chunk + (x - c0));
+#ifdef HPAR_ABL_NOGSTORE   // measurement aid: the line buffer is filled and read, the global stores are left out (results wrong)
+            if (v.x == 0x12345u && v.y == 0x777u) gBase[x] = 0;
+            continue;
+#endif
+            if (x >= h && x + 16u <= end) *(hpar_v4*)(gBase + x) = v;
+            else {
+                const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (u32 i = 0; i < 16; ++i) if (x + i >= h && x + i < end) gBase[x + i] = (u8)(w[i >> 2] >> (8u * (i & 3u)));
+            }
+        }
+    }
+}
+
+// ---- staging of (a piece of) a stream: consumption order -- array dword m = bit-reversed stream dword dTop - m, zeros below the stream's first
+// bit -- in units of four dwords.  Two steps so that a stream's loads can be issued EARLY (before the stores of the stream in front of it:
+// loads and stores share one in-order counter, a load issued behind a burst of stores is not seen before the stores are acknowledged):
+//   hpar_stage_load   : one 16-byte load per unit into registers, every load of a lane issued before anything waits; the units that touch either
+//                       end of the stream (dwords beyond its last byte, the partial top dword: one or two lanes) are put together afterwards;
+//   hpar_stage_commit : bit reversal and the LDS stores.
+template <u32 MAXU>
+DEV void hpar_stage_load(uint4 (&buf)[MAXU], const u8* sp, u32 L, u32 Sd, u32 mTop, u32 nd, u32 lane)
+{
+    const int dTop = (int)Sd - 1 - (int)mTop;
+    const u32 units = (nd + 3) / 4 + 4;                                   // + 16 dwords of slack (the stream goes on there, or zeros)
+    u32 edge = 0;
+#pragma unroll
+    for (u32 t = 0; t < MAXU; ++t) {
+        const u32 u = lane + 64 * t;
+        buf[t] = make_uint4(0, 0, 0, 0);
+        if (u >= units) continue;
+        const int dLo = dTop - 3 - 4 * (int)u;                            // lowest stream dword of the unit
+        if (dLo >= 0 && 4 * ((u32)dLo + 4) <= L) __builtin_memcpy(&buf[t], sp + 4 * dLo, 16);
+        else edge |= 1u << t;
+    }
+    if (__any(edge != 0)) {
+#pragma unroll
+        for (u32 t = 0; t < MAXU; ++t) {
+            if (!((edge >> t) & 1u)) continue;
+            const int dLo = dTop - 3 - 4 * (int)(lane + 64 * t);
+            u32 w[4] = { 0, 0, 0, 0 };
+            for (int i = 0; i < 4; ++i) {
+                const int d = dLo + i;
+                if (d < 0 || d >= (int)Sd) continue;
+                if (4 * (u32)d + 4 <= L) __builtin_memcpy(&w[i], sp + 4 * d, 4);
+                else for (u32 b8 = 4 * (u32)d; b8 < L; ++b8) w[i] |= (u32)sp[b8] << (8 * (b8 & 3u));
+            }
+            buf[t] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+template <u32 MAXU>
+DEV void hpar_stage_commit(const uint4 (&buf)[MAXU], u32* data, u32 nd, u32 lane)
+{
+    const u32 units = (nd + 3) / 4 + 4;
+#pragma unroll
+    for (u32 t = 0; t < MAXU; ++t) {
+        const u32 u = lane + 64 * t;
+        if (u < units) ((uint4*)data)[u] = make_uint4(__brev(buf[t].w), __brev(buf[t].z), __brev(buf[t].y), __brev(buf[t].x));
+    }
 }
 
 #ifdef HPAR_STATS            // development aid: repair rounds / bad links / cycles of the first blocks (scripts/hparstats.py)
@@ -130,20 +307,21 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hparStats(uns
 #endif
 // X2CAP: the instantiation that can also take double-symbol tables (it holds a whole table in registers while deriving the single-symbol
 // cells: 200 VGPRs).  The one-shot path and single-symbol caller tables use the lean instantiation.
+// (register budget: the kept symbols must not cost residency -- four waves per SIMD for the two small budgets, three for the large one)
 template <u32 DATA, bool X2CAP>
-__global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : DATA >= 8192u ? 3 : 4))) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x;
     const size_t slot = blockIdx.x;
     const size_t nTot = a.count ? (size_t)*a.count : a.nBlocks;
     if (slot >= nTot) return;                                            // uniform
-    const size_t b = a.list ? (size_t)a.list[slot] : slot;
+    const size_t b = a.list ? (size_t)__builtin_amdgcn_readfirstlane(a.list[slot]) : slot;
     if (a.meta && a.meta[b].state == 0) return;                          // (finished by the prepare kernel)
     if (a.onlyDeclined && a.results[b] != HUF_DECLINED) return;          // (second launch of the caller-table path: what the lean one left)
-    const u32 hdr = a.meta ? a.meta[b].hdrSize : 0;                      // (caller-built tables: the payload starts the block)
+    const u32 hdr = __builtin_amdgcn_readfirstlane(a.meta ? a.meta[b].hdrSize : 0u);                      // (caller-built tables: the payload starts the block)
     const u32* const gt = a.dtables + b * a.dtStrideU32;
-    const u32 desc = gt[0];
+    const u32 desc = __builtin_amdgcn_readfirstlane(gt[0]);
     const u32 dtLog = (desc >> 16) & 0xFFu;
     const u8* const in = view_ptr(a.csrc, b) + hdr;
     const size_t cSize = view_size(a.csrc, b) - hdr;
@@ -160,7 +338,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     const u32 seg = nStreams == 4 ? (u32)((dstSize + 3) / 4) : (u32)dstSize;
     const u32 jump = nStreams == 4 ? 6u : 0u;
     if (ok && nStreams == 4) {
-        len[0] = ld16(in); len[1] = ld16(in + 2); len[2] = ld16(in + 4);
+        len[0] = __builtin_amdgcn_readfirstlane(ld16(in)); len[1] = __builtin_amdgcn_readfirstlane(ld16(in + 2)); len[2] = __builtin_amdgcn_readfirstlane(ld16(in + 4));      // (uniform values: scalar registers)
         const size_t used = (size_t)len[0] + len[1] + len[2] + 6;
         if (used > cSize) ok = false; else len[3] = (u32)(cSize - used);
         if (3 * (size_t)seg >= dstSize) ok = false;
@@ -171,7 +349,7 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q >= nStreams) break;
-            const u32 last = len[q] ? sp[len[q] - 1] : 0;
+            const u32 last = __builtin_amdgcn_readfirstlane(len[q] ? (u32)sp[len[q] - 1] : 0u);
             if (len[q] < 8 || last == 0) ok = false;                      // (a stream beyond the LDS budget is staged and decoded in pieces, below)
             else T0[q] = 8u * (len[q] - 1) + hibit32(last);              // unread bits under the end mark (bitstream.h:285-290)
             if (T0[q] < HPAR_MIN_BITS) ok = false;
@@ -294,6 +472,14 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
     // lane 0 of the next piece starts (no speculation across pieces: they run one after the other), and the piece's 16 dwords of slack
     // hold the stream's next dwords instead of zeros.  One piece is the common case (the classes of k_huf_dprep fit their streams).
     constexpr u32 PDW = DATA / 4u - 24u;                                 // dwords of a piece: DATA bytes hold them, 16 dwords of slack and rounding to units
+    constexpr u32 MAXU = (DATA / 16 + 63) / 64;
+#ifndef HPAR_EARLY_LOADS
+#define HPAR_EARLY_LOADS 0
+#endif
+    constexpr bool EARLY = HPAR_EARLY_LOADS && DATA < 8192u;                                  // the next stream's loads in front of this stream's stores (registers permitting)
+    uint4 buf[MAXU];
+    bool staged = false;                                                 // buf holds the next piece to stage already
+    __syncthreads();                                                     // (the table is staged)
 #pragma unroll 1
     for (int q = 0; q < nStreams; ++q) {                                 // uniform: stream after stream
         const u32 L = len[q], Sd = (L + 3) / 4;
@@ -308,40 +494,16 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
                                                                          // (the loops address the bit BELOW the cursor: Q = C - 1; Cstart >= 1: the end mark)
             const u32 nd = Sd - mTop < PDW ? Sd - mTop : PDW;            // dwords of this piece
             const bool lastPiece = mTop + nd == Sd;
-            __syncthreads();                                             // (table staged / previous piece done)
-            // consumption order: array dword m = bit-reversed stream dword dTop - m; zeros below the stream's first bit.
-            // Units of four dwords, one 16-byte load each, all loads of a lane issued before the first LDS store; units that touch
-            // either end of the stream go dword by dword.
-            {   const int dTop = (int)Sd - 1 - (int)mTop;
-                const u32 units = (nd + 3) / 4 + 4;                      // + 16 dwords of slack (the stream goes on there, or zeros)
-                constexpr u32 MAXU = (DATA / 16 + 63) / 64;
-                uint4 buf[MAXU];
-#pragma unroll
-                for (u32 t = 0; t < MAXU; ++t) {
-                    const u32 u = lane + 64 * t;
-                    buf[t] = make_uint4(0, 0, 0, 0);
-                    if (u >= units) continue;
-                    const int dLo = dTop - 3 - 4 * (int)u;               // lowest stream dword of the unit
-                    if (dLo >= 0 && 4 * ((u32)dLo + 4) <= L) __builtin_memcpy(&buf[t], sp + 4 * dLo, 16);
-                    else {
-                        u32 w[4] = { 0, 0, 0, 0 };
-                        for (int i = 0; i < 4; ++i) {
-                            const int d = dLo + i;
-                            if (d < 0 || d >= (int)Sd) continue;
-                            if (4 * (u32)d + 4 <= L) __builtin_memcpy(&w[i], sp + 4 * d, 4);
-                            else for (u32 b8 = 4 * (u32)d; b8 < L; ++b8) w[i] |= (u32)sp[b8] << (8 * (b8 & 3u));
-                        }
-                        buf[t] = make_uint4(w[0], w[1], w[2], w[3]);
-                    }
-                }
-#pragma unroll
-                for (u32 t = 0; t < MAXU; ++t) {
-                    const u32 u = lane + 64 * t;
-                    if (u < units) ((uint4*)data)[u] = make_uint4(__brev(buf[t].w), __brev(buf[t].z), __brev(buf[t].y), __brev(buf[t].x));
-                }
-            }
-            __syncthreads();
+            if (!staged) hpar_stage_load<MAXU>(buf, sp, L, Sd, mTop, nd, lane);
+            staged = false;
+            hpar_wave_sync();                                            // (table staged / previous piece done: one wave, its LDS operations run in order)
+            hpar_stage_commit<MAXU>(buf, data, nd, lane);
+            hpar_wave_sync();
             HST({ const unsigned long long tB = __builtin_readcyclecounter(); tStage += tB - tA; tA = tB; })
+#if defined(HPAR_ABL) && HPAR_ABL == 1     // measurement aid: staging only (results wrong)
+            if (data[lane] == 0x12345u) out[lane] = 0;
+            break;
+#endif
             // cursors below are local to the piece's array: local = global - 32 * mTop
             const u32 C0 = Cstart - 32u * mTop;                          // exact: the stream's first code bit, or where the piece before ended
             const u32 CendL = (lastPiece ? Cend : 32u * (mTop + nd)) - 32u * mTop;
@@ -353,19 +515,25 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
             // ---- pass 1: warm up to my start, then my range
             u32 S = C0;
             if (lane > 0) { u32 C = aLo > warm ? cLo - warm : C0; (void)hpar_run(arr, C, cLo, tabOff, mask2); S = C; }
-            u32 E = S;
-            u32 n = hpar_run(arr, E, cHi, tabOff, mask2);
-            HST({ const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
+            // ---- my range, KEEPING the symbols in registers; verify / repair in the same loop (a repaired lane walks its range again).
+            u32 sym[HPAR_KEEP];
+#pragma unroll
+            for (int k = 0; k < HPAR_KEEP; ++k) sym[k] = 0;
+            u32 E = S, n = 0;
+            bool spill = false, todo = true;
             // ---- verify / repair.  A code that never falls into step (say 256 equal weights: every code 8 bits, a lane dropped off the
             //      byte grid stays off it) gains one exact lane per round -- the serial walk at the price of a wave.  Real data needs
             //      0..2 rounds; beyond HPAR_MAX_REPAIR the block is the serial decoder's (crafted input cannot pin a wave to a block).
             for (u32 round = 0;; ++round) {
+                if (todo) { E = S; n = hpar_run_keep(arr, E, cHi, tabOff, mask2, sym, spill); }
+                HST(if (round == 0) { const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
                 const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
                 const bool bad = lane > 0 && S != prevE;
                 if (!__any(bad)) break;
                 if (round == HPAR_MAX_REPAIR) { good = false; break; }              // uniform
                 HST(++stRounds; stBad += __builtin_popcountll(__ballot(bad));)
-                if (bad) { S = prevE; E = S; n = hpar_run(arr, E, cHi, tabOff, mask2); }
+                todo = bad;
+                if (bad) S = prevE;
             }
             if (!good) break;
             HST({ const unsigned long long tB = __builtin_readcyclecounter(); tRep += tB - tA; tA = tB; })
@@ -377,8 +545,34 @@ __global__ __launch_bounds__(64) void k_huf_decode_par(HufDecArgs a, u32* fbList
             // the last piece must regenerate exactly what is left of the segment and end exactly on the stream's first bit; a piece before
             // it must leave symbols to regenerate
             if (lastPiece ? (outBase + total != want || endC != CendL) : (outBase + total >= want)) { good = false; break; }   // uniform: not a stream the reference accepts as is
-            // ---- pass 2: my symbols again, stored sixteen at a time
-            {   u8* p = out + (size_t)q * seg + outBase + (incl - n);
+            // ---- the next stream's loads go out now, in front of this one's stores
+            if (EARLY && lastPiece && q + 1 < nStreams) {
+                const u32 L2 = len[q + 1], Sd2 = (L2 + 3) / 4, Cs2 = 32u * Sd2 - T0[q + 1];
+                const u32 mTop2 = (Cs2 - 1u) >> 5, nd2 = Sd2 - mTop2 < PDW ? Sd2 - mTop2 : PDW;
+                hpar_stage_load<MAXU>(buf, sp + L, L2, Sd2, mTop2, nd2, lane);
+                staged = true;
+            }
+            // ---- pass 2: my symbols out of the registers; only a piece with a spilled lane decodes them again
+#if defined(HPAR_ABL) && HPAR_ABL == 2     // measurement aid: no stores (results wrong)
+            if (!__any(spill)) { u32 x = 0;
+#pragma unroll
+                for (int k = 0; k < HPAR_KEEP; ++k) x ^= sym[k];
+                if (x == 0x12345u) out[lane] = 0; }
+#else
+#if defined(HPAR_DIRECT_STORE)              // A/B aid (EXPERIMENTS.md): every lane stores its own run straight from the registers
+            if (!__any(spill)) hpar_store_kept(out + (size_t)q * seg + outBase + (incl - n), n, sym);
+#else
+            if (!__any(spill)) {
+                u8* const g0 = out + (size_t)q * seg + outBase;
+                const u32 h = (u32)(uintptr_t)g0 & 15u;
+                constexpr u32 CH = DATA >= 8192u + 2u * HPAR_FLUSH_SLACK ? 8192u : DATA >= 4096u + 2u * HPAR_FLUSH_SLACK ? 4096u : 1024u;
+                static_assert(CH + 2u * HPAR_FLUSH_SLACK <= DATA, "the line buffer must fit the stream's staging area");
+                hpar_flush_kept<CH>(arr, g0 - h, h, total, h + (incl - n), n, sym, lane);
+            }
+#endif
+#endif
+            else {
+                u8* p = out + (size_t)q * seg + outBase + (incl - n);
                 u32 left = n, C = S;
 #ifdef HPAR_NO_STORE
                 u32 dummyAcc = 0;

@@ -199,9 +199,12 @@ hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s);
 // stream-parallel decoder (huf_decode_par.hip) with one of its three LDS budgets per staged stream, or the serial decoder (tiny and
 // irregular blocks, chosen by k_huf_dprep from the jump table; the parallel decoder appends what it declines to the serial lists)
 enum { HUF_DKIND_PAR_TINY = 0, HUF_DKIND_PAR_SMALL = 1, HUF_DKIND_PAR_LARGE = 2, HUF_DKIND_SERIAL = 3, HUF_DCLS_COUNT = 8 };
+#ifndef HPAR_USE_TINY
+#define HPAR_USE_TINY 0                 // round 6: the kept symbols (48 registers) bound the residency at 16 waves per CU; the smallest budget's 25 are out of reach and its
+#endif                                  // 2 KiB line buffer would take four output passes per stream -- its blocks go with the 4.5 KiB budget (18 by LDS)
 #define HPAR_DATA_TINY  2304u           // LDS budgets for one staged stream (+ 96 bytes of zero padding behind its end)
 #define HPAR_DATA_SMALL 4608u
-#define HPAR_DATA_LARGE (8192u + 256u)
+#define HPAR_DATA_LARGE (8192u + 384u)  // (also the line buffer of the output pass: 8 KiB + two slacks of 192 bytes)
 #define HPAR_MIN_BITS 4096u             // streams shorter than this go to the serial decoder (ranges must dwarf warm-up and codes)
 struct HufDPrepArgs {            // glue g6: HUF_readStats + HUF_readDTableX1 (+ raw / RLE decisions of HUF_decompress)
     BlockView csrc;
