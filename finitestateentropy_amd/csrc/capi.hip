@@ -714,8 +714,14 @@ int release_thread_scratch(void)                                  // the calling
 extern "C" int FSEHIP_releaseScratch(void)
 {
     const int r = release_thread_scratch();
-    frame_pool_release_scratch();                                 // ... and those of the frame calls' idle helper threads (frame.hip)
-    return r;
+    const int rp = frame_pool_release_scratch();                  // ... and those of the frame calls' idle helper threads (frame.hip)
+    return r ? r : rp;
+}
+extern "C" int FSEHIP_shutdown(void)
+{
+    const int r = release_thread_scratch();
+    const int rp = frame_pool_shutdown();
+    return r ? r : rp;
 }
 
 // result transport for one block: returns GENERIC when the device path itself fails

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#define FSEHIP_INTERNAL                  // (the library itself: the measurement aids are declared too)
 #include "../../include/fsehip.h"
 
 typedef uint8_t u8;

@@ -366,11 +366,13 @@ struct FrameJob {
     void* const* dsts; const size_t* caps; const void* const* srcs; const size_t* sizes; size_t* results; size_t n;
     unsigned bsid; int codec; int dev;
     std::atomic<size_t> next{ 0 };
+    int ranOn = -1;                                           // helpers the pool gave the job to (0: it has none)
+    std::atomic<int> releaseErr{ 0 };                         // releaseOnly: the first error a helper met giving its arena back
 };
 // `s`: the worker's stream (null: the null stream -- the lone caller, exactly the single-frame call)
 void frame_worker(FrameJob* j, hipStream_t s)
 {
-    if (j->releaseOnly) { (void)release_thread_scratch(); return; }
+    if (j->releaseOnly) { const int e = release_thread_scratch(); int none = 0; if (e) (void)j->releaseErr.compare_exchange_strong(none, e); return; }
     const bool ok = hipSetDevice(j->dev) == hipSuccess;
     for (;;) {
         const size_t i = j->next.fetch_add(1);
@@ -399,6 +401,7 @@ struct FramePool {
     std::mutex m; std::condition_variable work, done;
     std::vector<std::thread> threads;
     FrameJob* job = nullptr; unsigned wanted = 0, active = 0; unsigned long long gen = 0;
+    bool stop = false;                                        // FSEHIP_shutdown: the helpers leave their loops (their arenas and streams go with them)
     void loop(unsigned id)
     {
         unsigned long long seen = 0;
@@ -406,7 +409,8 @@ struct FramePool {
         for (;;) {
             FrameJob* j;
             {   std::unique_lock<std::mutex> lk(m);
-                work.wait(lk, [&] { return gen != seen; });
+                work.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) break;
                 seen = gen;
                 if (id >= wanted) continue;                      // this call asked for fewer helpers
                 j = job;
@@ -419,6 +423,21 @@ struct FramePool {
             frame_worker(j, s);
             {   std::lock_guard<std::mutex> lk(m); if (--active == 0) done.notify_all(); }
         }
+        (void)release_thread_scratch();
+        if (s) (void)hipStreamDestroy(s);
+    }
+    // FSEHIP_shutdown: ends and joins the helper threads (false: a batch call is running on them -- nothing was touched).  The pool
+    // starts new threads at the next batched frame call.
+    bool shutdown()
+    {
+        std::unique_lock<std::mutex> c(call, std::try_to_lock);
+        if (!c.owns_lock()) return false;
+        {   std::lock_guard<std::mutex> lk(m); stop = true; }
+        work.notify_all();
+        for (std::thread& t : threads) if (t.joinable()) t.join();
+        threads.clear();
+        {   std::lock_guard<std::mutex> lk(m); stop = false; }
+        return true;
     }
     // runs `j` on `helpers` pool threads beside the caller; false: the pool is busy (or cannot grow), nothing was started
     bool run(FrameJob& j, unsigned helpers)
@@ -428,7 +447,7 @@ struct FramePool {
         {   std::lock_guard<std::mutex> lk(m);
             try { while (!j.releaseOnly && threads.size() < helpers) { const unsigned id = (unsigned)threads.size(); threads.emplace_back([this, id] { loop(id); }); } }
             catch (...) { /* fewer helpers than asked for */ }
-            if (threads.empty()) return false;
+            if (threads.empty()) { j.ranOn = 0; return !j.releaseOnly ? false : true; }   // (nothing to release: not "busy")
             helpers = helpers < threads.size() ? helpers : (unsigned)threads.size();
             job = &j; wanted = helpers; active = helpers; ++gen;
         }
@@ -477,14 +496,18 @@ size_t run_frames(FrameJob& j, unsigned nThreads)
 }
 }   // namespace
 
-// FSEHIP_releaseScratch: the idle helpers of the pool give their arenas back too (a pool that serves a call right now is left alone)
-void frame_pool_release_scratch(void)
+// FSEHIP_releaseScratch: the idle helpers of the pool give their arenas back too.  Returns 0, the first error a helper met in hipFree, or
+// FSEHIP_SCRATCH_BUSY when a batched frame call is running on the pool right now (its helpers' arenas -- up to 64 x 1 GiB -- stay held).
+int frame_pool_release_scratch(void)
 {
     FramePool& p = frame_pool();
     FrameJob j; j.releaseOnly = true; j.compress = false; j.dsts = nullptr; j.caps = nullptr; j.srcs = nullptr; j.sizes = nullptr; j.results = nullptr;
     j.n = 0; j.bsid = 0; j.codec = 0; j.dev = 0;
-    (void)p.run(j, 64);
+    if (!p.run(j, 64)) return FSEHIP_SCRATCH_BUSY;
+    return j.releaseErr.load();
 }
+// FSEHIP_shutdown: see fsehip.h
+int frame_pool_shutdown(void) { return frame_pool().shutdown() ? 0 : FSEHIP_SCRATCH_BUSY; }
 
 extern "C" size_t FSEHIP_frame_compress_batch(void* const* dsts, const size_t* dstCapacities, const void* const* srcs, const size_t* srcSizes,
                                               size_t* results, size_t nFrames, unsigned blockSizeId, int codec, unsigned nThreads)

@@ -307,4 +307,5 @@ struct DevProps { int cus; int ldsPerCU; bool ok; };
 const DevProps& dev_props();
 hipError_t ensure_dyn_lds(const void* kernel, int bytes);
 int release_thread_scratch(void);          // capi.hip: gives the calling thread's host-call arena back
-void frame_pool_release_scratch(void);      // frame.hip: the same for the idle helper threads of the batched frame calls
+int frame_pool_release_scratch(void);       // frame.hip: the same for the idle helper threads of the batched frame calls (0, a hipError_t, or FSEHIP_SCRATCH_BUSY)
+int frame_pool_shutdown(void);              // frame.hip: ends and joins those threads

@@ -78,19 +78,34 @@ def _batch_p2p(ops, group):
     return dist.batch_isend_irecv(p2p) if p2p else []
 
 
-_HOST_GROUPS = {}
+_HOST_GROUPS = {}          # id(group) -> (group, its gloo side group): the entry is only trusted while it still holds the SAME group object
 
 
 def host_group(group=None):
     """the process group the few HOST integers of the pipelined job travel over: `group` itself when it is gloo, else a gloo group over
-    the same ranks, created once (collectively: every rank of `group` gets here at the same point of the job) and kept"""
+    the same ranks, created once (collectively: every rank of `group` gets here at the same point of the job) and kept until
+    `destroy_host_groups()` -- call that before destroying `group` (or the default group) if the process goes on to create others:
+    the cache is keyed by the group object and checked for identity, so a new group that happens to get a dead one's id() never
+    inherits its side group, but the side groups themselves are only released there."""
     if dist.get_backend(group) == "gloo":
         return group
-    key = id(group if group is not None else dist.group.WORLD)      # (a default group re-created later in the process gets a side group of its own)
-    if key not in _HOST_GROUPS:
+    g = group if group is not None else dist.group.WORLD
+    entry = _HOST_GROUPS.get(id(g))
+    if entry is None or entry[0] is not g:
         ranks = None if group is None else dist.get_process_group_ranks(group)
-        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
-    return _HOST_GROUPS[key]
+        entry = (g, dist.new_group(ranks=ranks, backend="gloo"))
+        _HOST_GROUPS[id(g)] = entry
+    return entry[1]
+
+
+def destroy_host_groups():
+    """release every gloo side group host_group() created (collective over each of them, like their creation)"""
+    for _, hg in list(_HOST_GROUPS.values()):
+        try:
+            dist.destroy_process_group(hg)
+        except Exception:       # the default group is gone already: its side groups went with it
+            pass
+    _HOST_GROUPS.clear()
 
 
 def host_totals(value, world, hgroup):
@@ -289,7 +304,10 @@ def sharded_codec_job_pipelined(corpus_root, n_blocks, block_bytes, rank, world,
     k has landed") and, once at the end, joins both lanes.  The packed sizes travel as host integers over a gloo side group; the host
     waits only for the event behind piece k - 1's compaction, after piece k's kernels are queued.  `gather_group`: a second process
     group over the same ranks for the way back -- RCCL serialises the operations of one communicator on one stream, so with a
-    communicator per direction the scatter of piece k + 1 and the gather of piece k - 1 really run side by side (default: `group`)."""
+    communicator per direction the scatter of piece k + 1 and the gather of piece k - 1 really run side by side (default: `group`).
+    Buffer lifetime: the scatter and gather lanes use `corpus_root`, the shard and the gathered buffers on their own streams WITHOUT
+    record_stream -- the caller owns them and must keep them alive (and unmodified) until this function has returned: it joins both lanes
+    into the compute stream before it does, so anything queued on the compute stream afterwards is ordered behind the transfers."""
     lo, hi = shard_range(n_blocks, rank, world)
     mine = shard_out if shard_out is not None else torch.empty((hi - lo, block_bytes), dtype=torch.uint8, device=device)
     ranges = [piece_ranges(*shard_range(n_blocks, r, world), pieces) for r in range(world)]      # [rank][piece] -> global rows

@@ -374,10 +374,14 @@ FSEHIP_API int FSEHIP_FSE_compressU16_batch(void* d_dst, size_t dstStride, size_
 FSEHIP_API int FSEHIP_FSE_decompressU16_batch(unsigned short* d_dst, size_t dstStrideBytes, size_t dstCapacity, size_t* d_results, const void* d_cSrc, size_t cStride,
                                               const size_t* d_cSizes, size_t uniformCSize, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
 
-/* Kernel timing probe for benchmarks: between probe_begin and probe_collect every kernel launch of the library is
+/* ---- UNSTABLE: measurement aids, not part of the codec API.  Process-wide switches meant for ONE thread that owns the device while they are on
+ * (bench.py's roofline figures); their numbering and meaning change with the kernels.  Declared only for a translation unit that defines
+ * FSEHIP_INTERNAL before including this header; a product caller has no business with them.
+ * Kernel timing probe for benchmarks: between probe_begin and probe_collect every kernel launch of the library is
  * bracketed by HIP events on its own stream.  probe_collect synchronises and returns, per kernel id
  * (0 hist, 1 fse_cprep, 2 fse_encode [lane per block], 3 fse_dprep, 4 fse_decode, 5 huf_cprep, 6 huf_encode, 7 huf_dprep,
  * 8 huf_decode, 9 fse_encode_wave [wave per block]), the summed duration in milliseconds and the number of launches.  Arrays hold 16 entries. */
+#ifdef FSEHIP_INTERNAL
 FSEHIP_API int FSEHIP_probe_begin(void);
 FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
 /* Cycle accounting inside the FSE decoder (the bound that actually holds for it is chain latency x LDS-resident blocks, not HBM):
@@ -389,6 +393,7 @@ FSEHIP_API int FSEHIP_probe_collect(double* totalMs16, unsigned* launches16);
  * [15] their cycles, [11] / [12] lifetime of the decoder waves in cycles / in ticks of the constant 100 MHz clock, [13] cycles before
  * the first phase (set-up), [14] cycles after the last (literal tail).  Synchronises the device; for benchmarks only. */
 FSEHIP_API int FSEHIP_debug_decodeTiming(int enable, unsigned long long* out16);
+#endif /* FSEHIP_INTERNAL */
 
 /* Sharding a batch over the GPUs of a node (one process per GPU; the reference's chunk loop, programs/bench.c:353-364,389-424, has no
  * carried dependence, so contiguous ranges of blocks need no collective on the data path): rank `rank` of `world` codes blocks
@@ -399,8 +404,18 @@ FSEHIP_API void FSEHIP_shardRange(size_t nBlocks, int rank, int world, size_t* f
 /* The calls on HOST pointers (layer 1, the frames) take their device scratch from an arena the calling thread keeps between calls
  * (grow-only, at most 1 GiB; larger buffers are allocated and freed per call): no hipMalloc / hipFree on the repeated-call path.
  * FSEHIP_releaseScratch() gives the calling thread's arena back (and those of the batched frame calls' idle helper threads); a thread that
- * exits without calling it leaves its arena to the process teardown. */
+ * exits without calling it leaves its arena to the process teardown.  Returns 0 when everything was given back, the hipError_t of the first
+ * hipFree that failed, hipErrorInvalidValue (1) when the calling thread is inside a call, or FSEHIP_SCRATCH_BUSY when a batched frame call
+ * is running on the helper pool right now: those helpers keep their arenas (up to 64 x 1 GiB) -- call again when it has returned.
+ *
+ * Threads.  The batched frame calls keep a pool of helper threads inside the library (created at the first such call; each holds a HIP stream
+ * and a scratch arena and sleeps on a condition variable between calls).  Consequences for the host process:
+ *   - do not dlclose() the library while the pool exists: FSEHIP_shutdown() ends and joins the helpers (and frees their arenas and the calling
+ *     thread's) first; it returns 0, or FSEHIP_SCRATCH_BUSY if a batch call is still running on them.  The pool restarts on demand.
+ *   - do not fork() and go on using the library in the child: neither the helper threads nor the HIP runtime's own state exist there. */
+#define FSEHIP_SCRATCH_BUSY (-2)
 FSEHIP_API int FSEHIP_releaseScratch(void);
+FSEHIP_API int FSEHIP_shutdown(void);
 
 /* The one allocation the batched calls make themselves: FSEHIP_FSE_decompress_usingDTable_batch (whose reference signature, lib/fse.h:247, has
  * no workspace) keeps the symbol bytes of its tables in a per-device scratch of 2 x CUs slots of 72 KB that the library allocates at the first such
