@@ -438,6 +438,53 @@ def using_tables_case(hip, codec_name, proba, src, pools, table_log, steps, warm
     return rec
 
 
+def ragged_case(hip, dev, n_blocks=20000, reps=5):
+    """Per-block sizes (programs/bench.c:353-364 chunks files: the last block of every file is short; a caller's batch is ragged in
+    general): n_blocks Proba14 blocks of 12,000 ... 32,768 bytes against the same number of uniform 32 KB blocks, both codecs, encode
+    and decode, best of `reps`, rate per uncompressed byte.  Round trip checked on every block."""
+    src = hip.probagen_batch(14, n_blocks, BLOCK, first_seed=1, device=dev)
+    rng = np.random.default_rng(3)
+    sizes = torch.from_numpy(rng.integers(12000, BLOCK + 1, n_blocks).astype(np.int64)).to(dev)
+    total_r, total_u = float(sizes.sum().item()), float(n_blocks * BLOCK)
+
+    def best_ms(f):
+        best = None
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); f(); b.record(); torch.cuda.synchronize()
+            t = a.elapsed_time(b)
+            best = t if best is None or t < best else best
+        return best
+
+    rec = {"blocks": n_blocks, "sizes": "uniform random 12000..32768 bytes (seed 3)", "mean_bytes": round(total_r / n_blocks, 1)}
+    cols = torch.arange(BLOCK, device=dev)[None, :]
+    for name in ("fse", "huf"):
+        comp = hip.fse_compress_batch if name == "fse" else hip.huf_compress_batch
+        r = {}
+        for kind, sz, tot in (("ragged", sizes, total_r), ("uniform", None, total_u)):
+            cd, cr = comp(src, 11, sizes=sz)
+            if name == "fse":
+                out, dr = hip.fse_decompress_batch(cd, cr, BLOCK, max_log=12)
+                dec = lambda: hip.fse_decompress_batch(cd, cr, BLOCK, max_log=12, dst=out, results=dr)
+            else:
+                dsz = sz if sz is not None else BLOCK
+                out, dr = hip.huf_decompress_batch(cd, cr, dsz)
+                dec = lambda: hip.huf_decompress_batch(cd, cr, dsz, dst=out, results=dr)
+            torch.cuda.synchronize()
+            want = sz if sz is not None else torch.full((n_blocks,), BLOCK, dtype=torch.int64, device=dev)
+            coded = cr > 1
+            ok = bool((dr[coded] == want[coded]).all()) and not bool((((out != src) & (cols < want[:, None])) & coded[:, None]).any())
+            e_ms = best_ms(lambda: comp(src, 11, sizes=sz, dst=cd, results=cr))
+            d_ms = best_ms(dec)
+            r[kind] = {"encode_GBps": round(tot / e_ms / 1e6, 1), "decode_GBps": round(tot / d_ms / 1e6, 1), "encode_ms": round(e_ms, 3), "decode_ms": round(d_ms, 3),
+                       "roundtrip_ok": ok, "blocks_coded": int(coded.sum().item())}
+            del cd, cr, out, dr
+        r["ragged_over_uniform_per_byte"] = {"encode": round(r["ragged"]["encode_GBps"] / r["uniform"]["encode_GBps"], 3),
+                                             "decode": round(r["ragged"]["decode_GBps"] / r["uniform"]["decode_GBps"], 3)}
+        rec[name] = r
+    return rec
+
+
 PLAIN = False          # --plain: see parse()
 
 
@@ -925,6 +972,11 @@ def main():
             if world > 1:
                 comm_leg = (total, cds5)              # runs LAST, under a watchdog (below): a transfer that never completes must not cost the line
             del s5, cds5
+        if want("ragged") and world == 1 and not PLAIN:
+            try:
+                configs["ragged"] = ragged_case(hip, dev)
+            except Exception as e:          # a report beside the BASELINE configurations, never a reason to lose the line
+                configs["ragged"] = {"error": repr(e)}
         if want("fse_u16") and hasattr(hip, "fse_compress_u16_batch"):
             configs["fse_u16"] = u16_case(hip, dev, args.u16_blocks, cs, barrier, reduce_max, world, rank)
 

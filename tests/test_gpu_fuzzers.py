@@ -35,6 +35,25 @@ def test_reference_huff0_fuzzer_on_device(hip):
     assert "Error" not in out, out[-2000:]
 
 
+@pytest.mark.parametrize("name", ["fuzzer-linked", "fuzzerHuff0-linked"])
+def test_reference_fuzzers_relinked_against_the_dropin_library(hip, name):
+    """LINK-level drop-in: the same fuzzers compiled against the reference's headers alone -- no force-include, no rename macro -- and linked
+    with libfse_dropin.so (csrc/dropin_alias.c: the reference's own symbol names forwarding to libfsehip.so) in front of the reference's
+    library: FSE_compress / FSE_decompress / HUF_* / HIST_count resolve to the device at link time; the binary must actually depend on it"""
+    exe = os.path.join(REFDIR, name)
+    if not os.path.exists(exe):
+        pytest.skip("%s not built (make -C oracle fuzzers, with libfse_dropin.so)" % name)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", exe], stdout=subprocess.PIPE).stdout.decode()
+    assert ("FSE_compress" in nm or "HUF_compress" in nm) and "FSEHIP_" not in nm, nm          # bound by the reference's names only
+    env = dict(os.environ, LD_DEBUG="bindings")
+    p = subprocess.run([exe, "-s1", "-i300"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    out, dbg = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and "Error" not in out, out[-2000:]
+    sym = "FSE_decompress" if name == "fuzzer-linked" else "HUF_decompress"
+    bound = [l for l in dbg.splitlines() if "symbol `%s'" % sym in l and "binding file" in l and name in l.split("to")[0]]
+    assert bound and all("libfse_dropin" in l for l in bound), bound[:3]                          # ... and resolved to the drop-in at load time
+
+
 @pytest.mark.parametrize("case", [1, 2, 3, 7, 8, 9, 13, 14, 20, 23, 30, 33, 42, 46])
 def test_reference_fullbench_on_device(hip, case):
     """programs/fullbench.c (the reference's per-function speed analyzer; `make test` runs `fullbench -i1`, programs/Makefile:135-139) bound

@@ -45,6 +45,25 @@ def test_dropin_names_cover_the_reference_prototypes():
         assert re.search(r"#define %s FSEHIP_%s\b" % (name, name), header), name
 
 
+def test_link_level_dropin_library_exports_the_reference_names():
+    """libfse_dropin.so (csrc/dropin_alias.c): every hot-path name of lib/fse.h, lib/huf.h, lib/hist.h as a real exported symbol, and a
+    dependency on libfsehip.so -- an object compiled against the reference's headers links against it unchanged"""
+    import subprocess
+    path = os.path.join(ROOT, "finitestateentropy_amd", "csrc", "libfse_dropin.so")
+    if not os.path.exists(path):
+        import finitestateentropy_amd
+        finitestateentropy_amd.build_library()
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, check=True).stdout.decode()
+    have = set(l.split()[-1] for l in out.splitlines() if " T " in l)
+    header = open(os.path.join(ROOT, "include", "fsehip.h")).read()
+    names = set(re.findall(r"#define (\w+) FSEHIP_\1\b", header))
+    assert len(names) >= 24 and names <= have, sorted(names - have)
+    assert {"FSE_isError", "HUF_isError", "FSE_getErrorName", "FSE_compressBound", "HUF_compressBound"} <= have
+    assert not any(n.startswith("FSEHIP_") for n in have)
+    need = subprocess.run(["readelf", "-d", path], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "libfsehip.so" in need
+
+
 def test_binding_rejects_what_the_raw_pointer_abi_cannot_take():
     from finitestateentropy_amd import api
     cpu = torch.zeros((4, 64), dtype=torch.uint8)
