@@ -487,7 +487,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : 
         const u32 Cend = 32u * Sd;                                       // global cursor (bits consumed from the top of dword Sd-1) at the stream's first bit
         u32 Cstart = Cend - T0[q];                                       // ... and at the first code bit (above it: padding, end mark); later: where the next piece starts
         u32 outBase = 0;                                                 // symbols regenerated by the pieces so far
-        const u32 warm = T0[q] > 6u * want ? HPAR_WARM + HPAR_WARM / 2 : HPAR_WARM;   // long codes resynchronise later (measured on 8-bit data: 128 -> 192 bits saves 4 %)
+        // warm-up distance: a decoder dropped at an arbitrary bit falls into step after a number of CODES, so the distance follows the stream's bits
+        // per symbol -- 24 codes' worth, at least 48 bits (round 6, per 100k blocks: P80 at 1.3 bits per symbol 2.78 -> 2.55 ms with 64 bits and
+        // still no repair round; P14 at 4.3: 96 bits no repairs, 64 bits a repair round in 8 % of the streams); long codes resynchronise later
+        // (8-bit data: 192 bits, where 128 cost 4 % and 96 a repair round per block)
+        u32 warm = T0[q] > 6u * want ? HPAR_WARM + HPAR_WARM / 2 : (24u * T0[q]) / (want ? want : 1u);
+        warm = warm < 48u ? 48u : (warm > HPAR_WARM + HPAR_WARM / 2 ? HPAR_WARM + HPAR_WARM / 2 : warm);
 #pragma unroll 1
         while (good && Cstart < Cend) {                                  // uniform: piece after piece
             const u32 mTop = (Cstart - 1u) >> 5;                         // array dword 0 = global dword mTop = stream dword Sd - 1 - mTop; the local cursor stays >= 1
