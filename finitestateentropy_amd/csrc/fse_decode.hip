@@ -563,16 +563,24 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // The one-shot path hands over a class's FSE_DBINS size-bin lists (internal.h), walked one after the other as if they were one
     // list sorted by compressed size.  Their lengths come in one 16-byte load; where the workgroup's first slot falls is uniform, and
     // its other slots are nearly always in the same bin.
-    static_assert(FSE_DBINS == 4, "the bin lengths are read as one uint4");
-    uint4 cn = make_uint4((u32)a.nBlocks, 0, 0, 0);
-    if (a.count) cn = *(const uint4*)a.count;
-    const size_t nTot = (size_t)cn.x + cn.y + cn.z + cn.w;
+    // (uniform: where the workgroup's first slot falls -- bin0, entry q0 of it -- is found once; its other slots are nearly always in the same bin)
+    size_t nTot = a.nBlocks, q0 = first;
+    u32 bin0 = 0;
+    if (a.count) {
+        nTot = 0;
+        bool found = false;
+        for (u32 i = 0; i < FSE_DBINS; ++i) {
+            const u32 c = a.count[i];
+            if (!found) { if (first < nTot + c || i == FSE_DBINS - 1) { found = true; bin0 = i; q0 = first - nTot; } }
+            nTot += c;
+        }
+    }
     if (first >= nTot) return;                                   // uniform: the grid is sized for the worst case
     auto slotBlock = [&](size_t g) -> size_t {                   // block of slot g of this workgroup (first + g < nTot)
         if (!a.list) return first + g;
-        size_t q = first + g; size_t i = 0;
-        if (q >= cn.x) { q -= cn.x; i = 1; if (q >= cn.y) { q -= cn.y; i = 2; if (q >= cn.z) { q -= cn.z; i = 3; } } }
-        return a.list[i * a.nBlocks + q];
+        size_t q = q0 + g; u32 i = bin0;
+        while (i < FSE_DBINS - 1) { const u32 c = a.count[i]; if (q < c) break; q -= c; ++i; }
+        return a.list[(size_t)i * a.nBlocks + q];
     };
     u8* const lds8 = (u8*)lds;
     const u32 tabStride = 2u << a.ldsLog;                        // bytes per LDS table slot

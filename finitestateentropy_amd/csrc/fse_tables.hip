@@ -152,14 +152,16 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
     // append my block to the list of its class and size bin: one atomic per list and wave
     if (cls >= 0) { const size_t bin = view_size(a.csrc, b) >> FSE_DBIN_LOG; cls = cls * FSE_DBINS + (int)(bin < FSE_DBINS - 1 ? bin : FSE_DBINS - 1); }
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int c = 0; c < FSE_DCLS_COUNT; ++c) {
+    unsigned long long todo = __ballot(cls >= 0);
+    while (todo) {                                                         // uniform: one round per list some block of this wave goes to
+        const int leader = __builtin_ctzll(todo);
+        const int c = __shfl(cls, leader, WAVE);
         const unsigned long long mask = __ballot(cls == c);
-        if (!mask) continue;                                               // uniform
-        const int leader = __builtin_ctzll(mask);
         u32 base = 0;
         if ((int)lane == leader) base = atomicAdd(&a.counts[c], (u32)__builtin_popcountll(mask));
         base = (u32)__shfl((int)base, leader, WAVE);
         if (cls == c) a.lists[(size_t)c * a.nBlocks + base + (u32)__builtin_popcountll(mask & below)] = (u32)b;
+        todo &= ~mask;
     }
 }
 

@@ -114,8 +114,13 @@ inline hipError_t launch_fse_encode_auto(FseEncArgs a, hipStream_t s)
 // Inside a class the blocks are binned by compressed size (FSE_DBINS bins of FSE_DBIN_BYTES): a workgroup lasts as long as its slowest
 // block, and how fast a block decodes follows its input rate -- a mixed batch (BASELINE config 5: P02 / P14 / P80 interleaved) otherwise
 // runs every workgroup at the pace of its P02 blocks.  List index = class * FSE_DBINS + bin.
-enum { FSE_DCLS_REV11 = 0, FSE_DCLS_REV12 = 1, FSE_DCLS_PLAIN = 2, FSE_DCLS_KINDS = 3, FSE_DBINS = 4, FSE_DCLS_COUNT = FSE_DCLS_KINDS * FSE_DBINS };
-#define FSE_DBIN_LOG 13          // 8 KiB of compressed bytes per bin (the last bin is open-ended)
+// (round 6: 16 bins of 2 KiB instead of 4 of 8 KiB -- a ragged batch of 12..32 KB blocks had blocks of 8 and 16 KB of payload in one workgroup,
+//  which lasts as long as the longer; per uncompressed byte it decoded at 0.83 of the uniform batch's rate)
+#ifndef FSE_DBINS_N
+#define FSE_DBINS_N 16
+#define FSE_DBIN_LOG 11          // 2 KiB of compressed bytes per bin (the last bin is open-ended)
+#endif
+enum { FSE_DCLS_REV11 = 0, FSE_DCLS_REV12 = 1, FSE_DCLS_PLAIN = 2, FSE_DCLS_KINDS = 3, FSE_DBINS = FSE_DBINS_N, FSE_DCLS_COUNT = FSE_DCLS_KINDS * FSE_DBINS };
 struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCount + FSE_buildDTable
     BlockView csrc;
     unsigned maxLog;
