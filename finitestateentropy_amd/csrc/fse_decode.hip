@@ -563,23 +563,35 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
     // The one-shot path hands over a class's FSE_DBINS size-bin lists (internal.h), walked one after the other as if they were one
     // list sorted by compressed size.  Their lengths come in one 16-byte load; where the workgroup's first slot falls is uniform, and
     // its other slots are nearly always in the same bin.
-    // (uniform: where the workgroup's first slot falls -- bin0, entry q0 of it -- is found once; its other slots are nearly always in the same bin)
+    // (uniform: where the workgroup's first slot falls -- bin0, entry q0 of it, cnt0 entries in that bin -- is found once, from the bin lengths
+    //  loaded together (16-byte loads, one memory latency); the workgroup's other slots are nearly always in the same bin)
+    static_assert(FSE_DBINS % 4 == 0, "the bin lengths are read as 16-byte vectors");
     size_t nTot = a.nBlocks, q0 = first;
-    u32 bin0 = 0;
+    u32 bin0 = 0, cnt0 = 0xFFFFFFFFu;
     if (a.count) {
-        nTot = 0;
+        uint4 cv[FSE_DBINS / 4];
+#pragma unroll
+        for (u32 i = 0; i < FSE_DBINS / 4; ++i) cv[i] = ((const uint4*)a.count)[i];
+        u64 before = 0;
         bool found = false;
+#pragma unroll
         for (u32 i = 0; i < FSE_DBINS; ++i) {
-            const u32 c = a.count[i];
-            if (!found) { if (first < nTot + c || i == FSE_DBINS - 1) { found = true; bin0 = i; q0 = first - nTot; } }
-            nTot += c;
+            const uint4 v = cv[i >> 2];
+            const u32 c = (i & 3u) == 0 ? v.x : (i & 3u) == 1 ? v.y : (i & 3u) == 2 ? v.z : v.w;
+            const bool here = !found & (((u64)first < before + c) | (i == FSE_DBINS - 1));
+            bin0 = here ? i : bin0; q0 = here ? (size_t)((u64)first - before) : q0; cnt0 = here ? c : cnt0;
+            found |= here;
+            before += c;
         }
+        nTot = (size_t)before;
     }
     if (first >= nTot) return;                                   // uniform: the grid is sized for the worst case
     auto slotBlock = [&](size_t g) -> size_t {                   // block of slot g of this workgroup (first + g < nTot)
         if (!a.list) return first + g;
         size_t q = q0 + g; u32 i = bin0;
-        while (i < FSE_DBINS - 1) { const u32 c = a.count[i]; if (q < c) break; q -= c; ++i; }
+        if (q >= cnt0) {                                         // (rare: the workgroup straddles bins)
+            while (i < FSE_DBINS - 1) { const u32 c = a.count[i]; if (q < c) break; q -= c; ++i; }
+        }
         return a.list[(size_t)i * a.nBlocks + q];
     };
     u8* const lds8 = (u8*)lds;

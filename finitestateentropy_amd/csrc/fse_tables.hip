@@ -158,7 +158,10 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
         const int c = __shfl(cls, leader, WAVE);
         const unsigned long long mask = __ballot(cls == c);
         u32 base = 0;
-        if ((int)lane == leader) base = atomicAdd(&a.counts[c], (u32)__builtin_popcountll(mask));
+        if ((int)lane == leader) {
+            base = atomicAdd(&a.counts[c], (u32)__builtin_popcountll(mask));
+            atomicAdd(&a.counts[FSE_DCLS_COUNT + c / FSE_DBINS], (u32)__builtin_popcountll(mask));     // the class's total (what its launches' surplus workgroups look at)
+        }
         base = (u32)__shfl((int)base, leader, WAVE);
         if (cls == c) a.lists[(size_t)c * a.nBlocks + base + (u32)__builtin_popcountll(mask & below)] = (u32)b;
         todo &= ~mask;
@@ -170,9 +173,31 @@ __global__ __launch_bounds__(64) void k_fse_dparse(FseDPrepArgs a)
 __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs, int firstList, int nLists, u32 ldsCapTs)
 {
     extern __shared__ __attribute__((aligned(16))) u8 wbLds[];
+    // the grid is sized for the worst case: a surplus workgroup (all of them in a launch for a class nobody belongs to) leaves after one look
+    // at the class totals
+    {   u32 total = 0;
+        for (int k = firstList / (int)FSE_DBINS; k < (firstList + nLists) / (int)FSE_DBINS; ++k) total += a.counts[FSE_DCLS_COUNT + k];
+        if (blockIdx.x >= total) return;                                   // uniform
+    }
+    // the list lengths are loaded together (16-byte loads, one memory latency), then scanned in registers
+    constexpr int MAXL = 2 * FSE_DBINS;                                    // a launch walks the lists of one or two classes
+    static_assert(FSE_DBINS % 4 == 0, "the list lengths are read as 16-byte vectors");
+    uint4 cv[MAXL / 4];
+#pragma unroll
+    for (int i = 0; i < MAXL / 4; ++i) cv[i] = 4 * i < nLists ? ((const uint4*)(a.counts + firstList))[i] : make_uint4(0, 0, 0, 0);
     u32 idx = blockIdx.x;
-    int c = firstList;
-    for (; c < firstList + nLists; ++c) { const u32 n = a.counts[c]; if (idx < n) break; idx -= n; }
+    int c = firstList + nLists;
+    {   u32 before = 0; bool found = false;
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i) {
+            const uint4 v = cv[i >> 2];
+            const u32 n = (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w;
+            const bool here = !found & (i < nLists) & (idx < before + n);      // (selects, not branches: the branchy form of the same scan in k_fse_decode lost an assignment)
+            c = here ? firstList + i : c; idx = here ? idx - before : idx;
+            found |= here;
+            before += n;
+        }
+    }
     if (c == firstList + nLists) return;                                   // uniform: beyond the last list
     const size_t b = a.lists[(size_t)c * a.nBlocks + idx];
     const u32 lane = threadIdx.x;
@@ -345,7 +370,7 @@ hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s)
 {
     if (a.nBlocks == 0) return hipSuccess;
     const u32 capTs = 1u << a.maxLog;
-    hipError_t e = launch_zero_u32(a.counts, FSE_DCLS_COUNT, s);
+    hipError_t e = launch_zero_u32(a.counts, FSE_DCLS_COUNT + FSE_DCLS_KINDS, s);      // the lists' lengths and the classes' totals
     if (e != hipSuccess) return e;
     probe_before(PK_FSE_DPREP, s);
     hipLaunchKernelGGL(k_fse_dparse, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);

@@ -130,7 +130,7 @@ struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCo
     s16* norms;                  // scratch between the two prepare kernels: 256 counters per block
     FseMeta* meta;               // state: 0 = result final, else 1 | fastMode << 1 | class << 2
     u32* lists;                  // FSE_DCLS_COUNT lists (class x size bin) of block indices, `nBlocks` entries apart
-    u32* counts;                 // their lengths (zeroed by the launcher)
+    u32* counts;                 // their lengths, then FSE_DCLS_KINDS class totals (zeroed by the launcher)
     size_t* results;
     size_t nBlocks;
     // packed batches with the bench loop's semantics (programs/bench.c:393-406): a record as long as the block (origSizes / uniformOrig)
