@@ -112,8 +112,8 @@ DEV u32 hpar_run(u32 arr, u32& C, u32 limit, u32 tabOff, u32 mask2)
 // symbols are the range's last -- and redone symbol by symbol for the exact boundary and count.  A lane that needs more than HPAR_KEEP
 // iterations (a stretch of very short codes) counts on without keeping and reports `spill`: the piece then takes the re-decoding pass 2.
 #ifndef HPAR_KEEP
-#define HPAR_KEEP 48                  // iterations kept = 192 symbols per lane and piece (a lane's share of a stream averages 128)
-#endif
+#define HPAR_KEEP 40                  // iterations kept = 160 symbols per lane and piece (a lane's share of a stream averages 128; 48 registers cost the
+#endif                                //  4.5 KiB class two of its 18 waves per CU: 2.91 -> 2.74 ms per 100k P14 blocks with 40 and five waves per SIMD)
 DEV u32 hpar_run_keep(u32 arr, u32& C, u32 limit, u32 tabOff, u32 mask2, u32 (&sym)[HPAR_KEEP], bool& spill)
 {
     u32 n = 0;
@@ -307,9 +307,11 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hparStats(uns
 #endif
 // X2CAP: the instantiation that can also take double-symbol tables (it holds a whole table in registers while deriving the single-symbol
 // cells: 200 VGPRs).  The one-shot path and single-symbol caller tables use the lean instantiation.
-// (register budget: the kept symbols must not cost residency -- four waves per SIMD for the two small budgets, three for the large one)
+// (register budget: the kept symbols must not cost residency -- five waves per SIMD (96 registers: 18 waves per CU by LDS) for the 4.5 KiB budget,
+//  three for the large one (12 by LDS); measured with the large budget for every block, i.e. 12 waves per CU and one output pass: P14 3.32 ms
+//  against 2.91 -- the kernel lives on waves per CU)
 template <u32 DATA, bool X2CAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : DATA >= 8192u ? 3 : 4))) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : DATA >= 8192u ? 3 : 5))) void k_huf_decode_par(HufDecArgs a, u32* fbList, u32* fbCount)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x;

@@ -208,7 +208,9 @@ enum { HUF_DKIND_PAR_TINY = 0, HUF_DKIND_PAR_SMALL = 1, HUF_DKIND_PAR_LARGE = 2,
 #define HPAR_USE_TINY 0                 // round 6: the kept symbols (48 registers) bound the residency at 16 waves per CU; the smallest budget's 25 are out of reach and its
 #endif                                  // 2 KiB line buffer would take four output passes per stream -- its blocks go with the 4.5 KiB budget (18 by LDS)
 #define HPAR_DATA_TINY  2304u           // LDS budgets for one staged stream (+ 96 bytes of zero padding behind its end)
+#ifndef HPAR_DATA_SMALL
 #define HPAR_DATA_SMALL 4608u
+#endif
 #define HPAR_DATA_LARGE (8192u + 384u)  // (also the line buffer of the output pass: 8 KiB + two slacks of 192 bytes)
 #define HPAR_MIN_BITS 4096u             // streams shorter than this go to the serial decoder (ranges must dwarf warm-up and codes)
 struct HufDPrepArgs {            // glue g6: HUF_readStats + HUF_readDTableX1 (+ raw / RLE decisions of HUF_decompress)
