@@ -566,7 +566,7 @@ hipError_t launch_huf_decode(HufDecArgs a, hipStream_t s)
         if (HPAR_USE_TINY) { e = launch_huf_decode_par(a, HPAR_DATA_TINY, nullptr, nullptr, s); a.classLo = HPAR_DATA_TINY; }
         if (e == hipSuccess) e = launch_huf_decode_par(a, HPAR_DATA_SMALL, nullptr, nullptr, s);
         a.classLo = HPAR_DATA_SMALL;
-        if (e == hipSuccess) e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
+        if (e == hipSuccess && !HPAR_ALL_SMALL) e = launch_huf_decode_par(a, HPAR_DATA_LARGE, nullptr, nullptr, s);
         a.classLo = 0;
         if (e == hipSuccess && a.acceptX2) e = launch_huf_decode_par_x2(a, s);
         a.onlyDeclined = 1;
@@ -597,6 +597,7 @@ hipError_t launch_huf_decode_classes(HufDecArgs a, u32* lists, u32* counts, hipS
         a.list = lists + (size_t)c * a.nBlocks; a.count = counts + c;
         a.ldsLog = (c & 1) ? FSEHIP_HUF_TABLELOG_MAX : HD_SLOT_LOG;
         if (kind == HUF_DKIND_PAR_TINY && !HPAR_USE_TINY) continue;           // (nothing is filed there)
+        if (kind == HUF_DKIND_PAR_LARGE && HPAR_ALL_SMALL) continue;
         if (kind == HUF_DKIND_SERIAL) e = huf_decode_launch(a, s);
         else e = launch_huf_decode_par(a, kind == HUF_DKIND_PAR_TINY ? HPAR_DATA_TINY : kind == HUF_DKIND_PAR_SMALL ? HPAR_DATA_SMALL : HPAR_DATA_LARGE, lists + (size_t)ser * a.nBlocks, counts + ser, s);
     }

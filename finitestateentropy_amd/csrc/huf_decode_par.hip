@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : 
     // (the waves per CU follow the budget: 25 / 18 / 12); a block of another class leaves at once -- its launch has marked or will take it
     if (ok && !a.meta && !a.list) {
         const u32 mx = max(max(len[0], len[1]), max(len[2], len[3])) + 96u;
-        if (mx <= a.classLo || (mx > DATA && DATA != HPAR_DATA_LARGE)) return;      // uniform
+        if (mx <= a.classLo || (!HPAR_ALL_SMALL && mx > DATA && DATA != HPAR_DATA_LARGE)) return;      // uniform
     }
     // declined: the serial decoder's block -- on its list (one-shot path) or marked in results[] (caller tables: no workspace)
     auto decline = [&]() { if (lane == 0) { if (fbList) fbList[atomicAdd(fbCount, 1u)] = (u32)b; else a.results[b] = HUF_DECLINED; } };
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : 
         while (good && Cstart < Cend) {                                  // uniform: piece after piece
             const u32 mTop = (Cstart - 1u) >> 5;                         // array dword 0 = global dword mTop = stream dword Sd - 1 - mTop; the local cursor stays >= 1
                                                                          // (the loops address the bit BELOW the cursor: Q = C - 1; Cstart >= 1: the end mark)
-            const u32 nd = Sd - mTop < PDW ? Sd - mTop : PDW;            // dwords of this piece
+            const u32 rest = Sd - mTop, nPc = (rest + PDW - 1u) / PDW;   // what is left of the stream goes in pieces of equal size
+            const u32 nd = nPc <= 1u ? rest : (rest + nPc - 1u) / nPc;   // dwords of this piece (<= PDW)
             const bool lastPiece = mTop + nd == Sd;
             if (!staged) hpar_stage_load<MAXU>(buf, sp, L, Sd, mTop, nd, lane);
             staged = false;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : 
             // ---- the next stream's loads go out now, in front of this one's stores
             if (EARLY && lastPiece && q + 1 < nStreams) {
                 const u32 L2 = len[q + 1], Sd2 = (L2 + 3) / 4, Cs2 = 32u * Sd2 - T0[q + 1];
-                const u32 mTop2 = (Cs2 - 1u) >> 5, nd2 = Sd2 - mTop2 < PDW ? Sd2 - mTop2 : PDW;
+                const u32 mTop2 = (Cs2 - 1u) >> 5, rest2 = Sd2 - mTop2, nPc2 = (rest2 + PDW - 1u) / PDW, nd2 = nPc2 <= 1u ? rest2 : (rest2 + nPc2 - 1u) / nPc2;
                 hpar_stage_load<MAXU>(buf, sp + L, L2, Sd2, mTop2, nd2, lane);
                 staged = true;
             }

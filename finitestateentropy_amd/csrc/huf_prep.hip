@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64) void k_huf_dprep(HufDPrepArgs a)
                     const size_t l3 = cSize - hdr - used;
                     const size_t mn = min(min(l0, l1), min(l2, l3)), mx = max(max(l0, l1), max(l2, l3));
                     // (a stream beyond the largest budget -- blocks of 64 / 128 KB -- is decoded in pieces by the class with the largest one)
-                    if (8 * mn >= HPAR_MIN_BITS + 8) kind = HPAR_USE_TINY && mx + 96 <= HPAR_DATA_TINY ? HUF_DKIND_PAR_TINY : mx + 96 <= HPAR_DATA_SMALL ? HUF_DKIND_PAR_SMALL : HUF_DKIND_PAR_LARGE;
+                    if (8 * mn >= HPAR_MIN_BITS + 8) kind = HPAR_USE_TINY && mx + 96 <= HPAR_DATA_TINY ? HUF_DKIND_PAR_TINY : (mx + 96 <= HPAR_DATA_SMALL || HPAR_ALL_SMALL) ? HUF_DKIND_PAR_SMALL : HUF_DKIND_PAR_LARGE;
                 }
             }
             sc[DS_CLS] = kind;

@@ -204,6 +204,9 @@ hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s);
 // stream-parallel decoder (huf_decode_par.hip) with one of its three LDS budgets per staged stream, or the serial decoder (tiny and
 // irregular blocks, chosen by k_huf_dprep from the jump table; the parallel decoder appends what it declines to the serial lists)
 enum { HUF_DKIND_PAR_TINY = 0, HUF_DKIND_PAR_SMALL = 1, HUF_DKIND_PAR_LARGE = 2, HUF_DKIND_SERIAL = 3, HUF_DCLS_COUNT = 8 };
+#ifndef HPAR_ALL_SMALL
+#define HPAR_ALL_SMALL 1                // round 6: streams beyond the 4.5 KiB budget are taken in equal PIECES by the same class (18 waves per CU) instead of whole by the
+#endif                                  // 8.4 KiB class (12 waves): P02 (7 KB streams) 3.90 -> 3.73 ms per 100k blocks; the large budget stays for double-symbol caller tables
 #ifndef HPAR_USE_TINY
 #define HPAR_USE_TINY 0                 // round 6: the kept symbols (48 registers) bound the residency at 16 waves per CU; the smallest budget's 25 are out of reach and its
 #endif                                  // 2 KiB line buffer would take four output passes per stream -- its blocks go with the 4.5 KiB budget (18 by LDS)
