@@ -329,6 +329,9 @@ hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s)
     {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_encode, (int)maxLds); if (e != hipSuccess) return e; }
     size_t img = a.dstCapacity + 16;
     if (img > maxLds - 1100) img = maxLds - 1100;
+#ifdef HUF_ENC_IMG_MAX      // A/B aid: a smaller output image (more workgroups per CU; blocks whose streams do not fit fall back to the two-pass / global paths)
+    if (img > HUF_ENC_IMG_MAX) img = HUF_ENC_IMG_MAX;
+#endif
     img = (img + 15) & ~(size_t)15;
     const size_t ldsBytes = (256 + 8) * 4 + img;
     const unsigned threads = (a.streams == 4 || a.split1X) ? HUF_ENC_THREADS : 64;
