@@ -130,7 +130,13 @@ DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, co
     return rowBase;
 }
 
-__global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u32 imgBytes)
+#ifndef HUF_ENC_WAVES_PER_EU
+#define HUF_ENC_WAVES_PER_EU 5          // 96 registers per lane (see launch_huf_encode)
+#endif
+#ifndef HUF_ENC_IMG_MAX
+#define HUF_ENC_IMG_MAX 30720u
+#endif
+__global__ __launch_bounds__(HUF_ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HUF_ENC_WAVES_PER_EU))) void k_huf_encode(HufEncArgs a, u32 imgBytes)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     u32* const ct = lds;                 // 256 HUF_CElt
@@ -268,6 +274,45 @@ __global__ __launch_bounds__(HUF_ENC_THREADS) void k_huf_encode(HufEncArgs a, u3
     u8* const dstAl = dst - lead;
     const size_t imgWords = (lead + total + 3) >> 2;
     const bool inLds = (imgWords * 4 <= imgBytes);
+    // The four streams of a block that compresses by less than 6 % do not fit the image together: they are emitted in two HALVES -- the jump
+    // table and streams 0, 1, then streams 2, 3 (every stream starts on a byte) -- each through the image like a block of its own.
+    if (!inLds && streams == 4 && start[2] + 8 <= imgBytes && (total - start[2]) + 8 <= imgBytes) {
+        for (int hf = 0; hf < 2; ++hf) {                                  // uniform
+            const size_t off = hf ? start[2] : 0, len = hf ? total - start[2] : start[2];
+            u8* const dH = dst + off;
+            const u32 leadH = (u32)((uintptr_t)dH & 3u);
+            u8* const dHAl = dH - leadH;
+            const size_t wordsH = (leadH + len + 3) >> 2;
+            for (size_t i = tid; i < wordsH; i += blockDim.x) img[i] = 0;
+            __syncthreads();
+            if ((int)(wave >> 1) == hf) {
+                const u64 base = 8 * ((u64)leadH + start[wave] - off);
+                u64 pos = base;
+                HeTile cur = tile0;
+                for (u32 j0 = 0; j0 < myLen; j0 += HE_TILE) {
+                    HeTile nxt = cur;
+                    if (j0 + HE_TILE < myLen) he_load_tile(nxt, seg, myLen, j0 + HE_TILE, lane);
+                    __asm__ volatile("" ::: "memory");
+                    pos = he_emit_tile<false>(img, pos, cur, myLen, j0, ct, lane);
+                    cur = nxt;
+                }
+                if (lane == 0) or_bits<false>(img, base + sh[wave], 1, 1);                       // the stream's end mark
+            }
+            if (hf == 0 && tid < 3) or_bits<false>(img, 8 * ((u64)leadH + 2 * tid), ssize[tid], 16);     // the jump table
+            __syncthreads();
+            {   const u8* ib = (const u8*)img;
+                const size_t end = leadH + len;
+                for (size_t w = tid; w < wordsH; w += blockDim.x) {
+                    const size_t lo = 4 * w, hi = 4 * w + 4;
+                    if (lo >= leadH && hi <= end) ((u32*)dHAl)[w] = img[w];
+                    else for (size_t i = (lo > leadH ? lo : leadH); i < (hi < end ? hi : end); ++i) dHAl[i] = ib[i];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) a.results[b] = result;
+        return;
+    }
     if (inLds) {
         for (size_t i = tid; i < imgWords; i += blockDim.x) img[i] = 0;
     } else {
@@ -329,9 +374,11 @@ hipError_t launch_huf_encode(const HufEncArgs& a, hipStream_t s)
     {   const hipError_t e = ensure_dyn_lds((const void*)k_huf_encode, (int)maxLds); if (e != hipSuccess) return e; }
     size_t img = a.dstCapacity + 16;
     if (img > maxLds - 1100) img = maxLds - 1100;
-#ifdef HUF_ENC_IMG_MAX      // A/B aid: a smaller output image (more workgroups per CU; blocks whose streams do not fit fall back to the two-pass / global paths)
+    // Round 6: the image is capped at HUF_ENC_IMG_MAX = 30 KiB so that FIVE workgroups (20 waves, with 96 registers per lane) share a CU's 160 KB
+    // instead of four: encode call per 100k blocks P80 2.23 -> 2.07 ms, P14 2.65 -> 2.49, P02 3.80 -> 3.61.  (32 KiB - the code table, 5 x 32 KiB
+    // = all 160 KB, was measured too and is not granted five times; 28 KiB regions no longer hold P02's 7.1 KB streams.)  A block whose four
+    // streams total more than the image (it compresses by less than 6 %) is emitted in two halves, below.
     if (img > HUF_ENC_IMG_MAX) img = HUF_ENC_IMG_MAX;
-#endif
     img = (img + 15) & ~(size_t)15;
     const size_t ldsBytes = (256 + 8) * 4 + img;
     const unsigned threads = (a.streams == 4 || a.split1X) ? HUF_ENC_THREADS : 64;

@@ -584,3 +584,36 @@ def test_huf_1x_roundtrip_on_the_device_full_size(hip, oracle):
         assert bool((q4 == size).all()) and torch.equal(o4, big), size
         _, ores, odst = oracle.compress_batch(1, big.cpu().numpy()[:8])
         assert (r4.cpu().numpy()[:8] == ores.astype(np.int64)).all()
+
+
+def test_huf_compress_barely_compressible_blocks_in_two_halves(hip, oracle):
+    """Blocks that compress by 0.5 ... 6 %: their four streams total more than the encoder's 30 KiB LDS image (five workgroups per CU since
+    round 6), so k_huf_encode emits them in two halves (jump table + streams 0, 1, then streams 2, 3); below that the one-pass path, above it
+    "not compressible" -- sizes, bytes and round trip against the reference across the whole band, whole and ragged blocks, odd destinations"""
+    rng = np.random.default_rng(606)
+    n, size = 96, 32768
+    blocks = np.zeros((n, size), np.uint8)
+    for b in range(n):
+        extra = 0.002 + 0.0016 * b                                            # share of the block that is one favoured byte: 0.2 ... 15 %
+        x = rng.integers(0, 256, size, dtype=np.uint8)
+        k = int(extra * size)
+        x[rng.choice(size, k, replace=False)] = 77
+        blocks[b] = x
+    src = torch.from_numpy(blocks).cuda()
+    sizes = torch.full((n,), size, dtype=torch.int64, device="cuda")
+    sizes[1::3] = torch.from_numpy(rng.integers(20000, size, len(range(1, n, 3)))).cuda()
+    dst, res = hip.huf_compress_batch(src, table_log=11, sizes=sizes)
+    res_h, dst_h, sz_h = res.cpu().numpy(), dst.cpu().numpy(), sizes.cpu().numpy()
+    band = 0
+    for b in range(n):
+        r, out = oracle.huf_compress2(blocks[b][:sz_h[b]], 255, 11)
+        assert res_h[b] == s64(r), (b, sz_h[b], res_h[b], r)
+        if r > 1:
+            assert (dst_h[b][:r] == out[:r]).all(), (b, sz_h[b], r)
+            band += r > 30720
+    assert band >= 8, band                                                     # the two-halves path was really taken
+    coded = res > 1
+    out, dres = hip.huf_decompress_batch(dst[coded].contiguous(), res[coded].contiguous(), sizes[coded].contiguous())
+    out_h, dres_h = out.cpu().numpy(), dres.cpu().numpy()
+    for i, b in enumerate(np.nonzero(coded.cpu().numpy())[0]):
+        assert dres_h[i] == sz_h[b] and (out_h[i][:sz_h[b]] == blocks[b][:sz_h[b]]).all(), b
