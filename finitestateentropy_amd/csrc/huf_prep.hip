@@ -49,8 +49,12 @@ extern "C" __attribute__((visibility("default"))) int FSEHIP_debug_hpTiming(unsi
 //   decompress     G = 1: 1.17 / 1.37 ms   2: 0.61 / 0.74   4: 0.42 / 0.83   8: 0.64 / 1.14   16: 1.48 / 2.29
 // (few blocks per wave = small LDS footprint = many waves per CU to hide the LDS / cross-lane latencies of the wide steps;
 //  one block per wave leaves the serial steps with a single busy lane)
+#ifndef HP_G_COMPRESS
 #define HP_G_COMPRESS 2
+#endif
+#ifndef HP_G_DECOMPRESS
 #define HP_G_DECOMPRESS 4
+#endif
 
 // ---- LDS slot of one block (bytes) ------------------------------------------------------------------------------------
 #define HP_KEYS   0                     // u32[256] sorted keys, rank order (count = key >> 9)
