@@ -541,7 +541,10 @@ hipError_t launch_fse_encode_wave(FseEncArgs a, hipStream_t s)
     if (a.nBlocks == 0) return hipSuccess;
     const bool tt4 = a.maxTableLog <= 11;                                   // states fit 12 bits: 4-byte symbolTT entries
     const u32 tableWords = (2 + (1u << (a.maxTableLog - 1)) + (tt4 ? 256 : 512) + 2 + 31) & ~31u;    // rings start 128-byte aligned
-    const u32 slotWords = tableWords + WV_LANES * (WV_RING / 4);
+#ifndef WV_EXTRA_LDS_WORDS
+#define WV_EXTRA_LDS_WORDS 0u       // A/B aid: unused LDS per block, i.e. fewer waves per CU (how much does the kernel live on residency?)
+#endif
+    const u32 slotWords = tableWords + WV_LANES * (WV_RING / 4) + WV_EXTRA_LDS_WORDS;
     const size_t ldsBytes = 4 * (size_t)slotWords * WV_BPW * FSE_WV_WAVES;
     const size_t perGroup = (size_t)WV_BPW * FSE_WV_WAVES;
     probe_before(PK_FSE_ENCODE_WAVE, s);
