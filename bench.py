@@ -997,7 +997,15 @@ def main():
             os._exit(0)
         timer = threading.Timer(float(args.comm_timeout), give_up)
         timer.daemon = True
-        timer.start()
+        # every rank arms its watchdog at the same moment: rank 0 gets here after its CPU baseline (tens of seconds), the others at once -- they
+        # wait for it in a collective first, so that their timers do not count the root's host work as communication time (rank 0 arms its
+        # own timer in front of that collective: a transport that cannot even do a barrier must not cost the line either)
+        if rank == 0:
+            timer.start()
+        if dist is not None:
+            dist.barrier()
+        if rank != 0:
+            timer.start()
         total5, cds = comm_leg
         try:
             rec = with_comm_case(args, hip, shard, dev, rank, world, total5, cds, srcpool, barrier, reduce_max, sharing)

@@ -317,6 +317,26 @@ class FseHip:
                                                     _stream()), "FSE_readNCount_batch")
         return norms, msv, tls, res
 
+    def fse_build_ctable_from_norm_batch(self, norms, max_symbol_values, table_log):
+        """FSE_buildCTable per row of `norms` (n, 256) int16: (ctables (n, FSE_CTABLE_SIZE_U32(table_log, 255)) int32, results = 0 or error)"""
+        n = norms.shape[0]
+        ct = torch.zeros((n, 1 + (1 << max(min(table_log, 12) - 1, 0)) + 512), dtype=torch.int32, device=norms.device)
+        res = torch.zeros(n, dtype=torch.int64, device=norms.device)
+        _check(self.lib.FSEHIP_FSE_buildCTable_fromNorm_batch(_ptr(ct), SZ(ct.stride(0)), _ptr(norms), SZ(norms.stride(0)), _ptr(max_symbol_values),
+                                                              C.c_uint(table_log), SZ(n), _ptr(res), _stream()), "FSE_buildCTable_fromNorm_batch")
+        return ct, res
+
+    def fse_build_dtable_from_norm_batch(self, norms, max_symbol_values, table_log):
+        """FSE_buildDTable per row of `norms` (n, 256) int16: (dtables (n, FSE_DTABLE_SIZE_U32(table_log)) int32, results = 0 or error)"""
+        n = norms.shape[0]
+        dt = torch.zeros((n, 1 + (1 << max(min(table_log, 12), 1))), dtype=torch.int32, device=norms.device)
+        res = torch.zeros(n, dtype=torch.int64, device=norms.device)
+        self.lib.FSEHIP_FSE_buildDTable_fromNorm_batch_workspaceSize.restype = SZ
+        ws = torch.empty(int(self.lib.FSEHIP_FSE_buildDTable_fromNorm_batch_workspaceSize(SZ(n), C.c_uint(table_log))), dtype=torch.uint8, device=norms.device)
+        _check(self.lib.FSEHIP_FSE_buildDTable_fromNorm_batch(_ptr(dt), SZ(dt.stride(0)), _ptr(norms), SZ(norms.stride(0)), _ptr(max_symbol_values),
+                                                              C.c_uint(table_log), SZ(n), _ptr(res), _ptr(ws), SZ(ws.numel()), _stream()), "FSE_buildDTable_fromNorm_batch")
+        return dt, res
+
     # ------------------------------------------------------------------ packed (variable-length) batches
     def compact_batch(self, slots, results, src, sizes=None, packed=None, offsets=None):
         """FSEHIP_compact_batch: (packed uint8 (capacity,), offsets int64 (n + 1,)); offsets[n] = the packed size"""
@@ -372,6 +392,64 @@ class FseHip:
     def fse_decompress_using_dtable(self, csrc, dt, cap):
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_FSE_decompress_usingDTable", cap, csrc, dt.ctypes.data_as(VP))
+
+    # the table glue on host pointers (lib/fse.h:119-163, :222-241): same argument order as the reference, numpy in / out
+    def fse_optimal_tablelog(self, max_tl, src_size, max_sv):
+        self.lib.FSEHIP_FSE_optimalTableLog.restype = C.c_uint
+        return int(self.lib.FSEHIP_FSE_optimalTableLog(C.c_uint(max_tl), SZ(src_size), C.c_uint(max_sv)))
+
+    def fse_ncount_write_bound(self, max_sv, table_log):
+        self.lib.FSEHIP_FSE_NCountWriteBound.restype = SZ
+        return int(self.lib.FSEHIP_FSE_NCountWriteBound(C.c_uint(max_sv), C.c_uint(table_log)))
+
+    def fse_normalize_count(self, table_log, count, total, max_sv):
+        count = np.ascontiguousarray(count, dtype=np.uint32)
+        norm = np.full(max(256, max_sv + 1) + 4, 0x5A5A, dtype=np.int16)
+        self.lib.FSEHIP_FSE_normalizeCount.restype = SZ
+        r = int(self.lib.FSEHIP_FSE_normalizeCount(norm.ctypes.data_as(VP), C.c_uint(table_log), count.ctypes.data_as(VP), SZ(total), C.c_uint(max_sv)))
+        assert (norm[max(max_sv, 0) + 1:] == 0x5A5A).all() or max_sv > 255, "FSE_normalizeCount wrote past normalizedCounter[maxSymbolValue]"
+        return r, norm[:256]
+
+    def fse_write_ncount(self, cap, norm, max_sv, table_log):
+        norm = np.ascontiguousarray(norm, dtype=np.int16)
+        out = np.full(max(cap, 1) + 8, 0xA5, dtype=np.uint8)
+        self.lib.FSEHIP_FSE_writeNCount.restype = SZ
+        r = int(self.lib.FSEHIP_FSE_writeNCount(out.ctypes.data_as(VP), SZ(cap), norm.ctypes.data_as(VP), C.c_uint(max_sv), C.c_uint(table_log)))
+        assert (out[cap:] == 0xA5).all(), "FSE_writeNCount wrote past bufferSize"
+        return r, out[:cap]
+
+    def fse_read_ncount(self, src, max_sv=255):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        norm = np.zeros(max(256, max_sv + 1), dtype=np.int16)
+        msv, tl = C.c_uint(max_sv), C.c_uint(0)
+        self.lib.FSEHIP_FSE_readNCount.restype = SZ
+        r = int(self.lib.FSEHIP_FSE_readNCount(norm.ctypes.data_as(VP), C.byref(msv), C.byref(tl), src.ctypes.data_as(VP), SZ(src.size)))
+        return r, int(msv.value), int(tl.value), norm
+
+    def fse_build_ctable(self, norm, max_sv, table_log, wksp_bytes=None):
+        norm = np.ascontiguousarray(norm, dtype=np.int16)
+        words = 1 + (1 << max(min(table_log, 12) - 1, 0)) + 2 * (min(max_sv, 255) + 1)
+        ct = np.zeros(words + 4, dtype=np.uint32)
+        ct[words:] = 0xA5A5A5A5
+        if wksp_bytes is None:
+            self.lib.FSEHIP_FSE_buildCTable.restype = SZ
+            r = int(self.lib.FSEHIP_FSE_buildCTable(ct.ctypes.data_as(VP), norm.ctypes.data_as(VP), C.c_uint(max_sv), C.c_uint(table_log)))
+        else:
+            ws = np.zeros(max(wksp_bytes, 1), dtype=np.uint8)
+            self.lib.FSEHIP_FSE_buildCTable_wksp.restype = SZ
+            r = int(self.lib.FSEHIP_FSE_buildCTable_wksp(ct.ctypes.data_as(VP), norm.ctypes.data_as(VP), C.c_uint(max_sv), C.c_uint(table_log), ws.ctypes.data_as(VP), SZ(wksp_bytes)))
+        assert (ct[words:] == 0xA5A5A5A5).all(), "FSE_buildCTable wrote past FSE_CTABLE_SIZE_U32(tableLog, maxSymbolValue)"
+        return r, ct[:words]
+
+    def fse_build_dtable(self, norm, max_sv, table_log):
+        norm = np.ascontiguousarray(norm, dtype=np.int16)
+        words = 1 + (1 << max(min(table_log, 12), 0))
+        dt = np.zeros(words + 4, dtype=np.uint32)
+        dt[words:] = 0xA5A5A5A5
+        self.lib.FSEHIP_FSE_buildDTable.restype = SZ
+        r = int(self.lib.FSEHIP_FSE_buildDTable(dt.ctypes.data_as(VP), norm.ctypes.data_as(VP), C.c_uint(max_sv), C.c_uint(table_log)))
+        assert (dt[words:] == 0xA5A5A5A5).all(), "FSE_buildDTable wrote past FSE_DTABLE_SIZE_U32(tableLog)"
+        return r, dt[:words]
 
     def fse_compress2(self, src, max_sv=255, table_log=11, cap=None):
         return self._single("FSEHIP_FSE_compress2", fse_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(table_log))

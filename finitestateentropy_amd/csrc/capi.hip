@@ -576,6 +576,51 @@ extern "C" int FSEHIP_FSE_buildDTable_batch(FSEHIP_FSE_DTable* d_dtables, size_t
     return 0;
 }
 
+// ---- the table builders on counters the caller supplies (fsehip.h "Table glue, step by step")
+extern "C" int FSEHIP_FSE_buildCTable_fromNorm_batch(FSEHIP_FSE_CTable* d_ctables, size_t ctableStrideU32, const short* d_norms, size_t normStride,
+                                                     const unsigned* d_maxSymbolValues, unsigned tableLog, size_t nBlocks, size_t* d_results, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    if (!d_ctables || !d_norms || !d_maxSymbolValues || !d_results || normStride < 256) return (int)hipErrorInvalidValue;
+    if (tableLog >= 1 && tableLog <= FSEHIP_FSE_MAX_TABLELOG && ctableStrideU32 < FSEHIP_FSE_CTABLE_SIZE_U32(tableLog, 255)) return (int)hipErrorInvalidValue;
+    return (int)launch_fse_ctable_from_norm((const s16*)d_norms, normStride, d_maxSymbolValues, tableLog, d_ctables, ctableStrideU32, d_results, nBlocks, (hipStream_t)stream);
+}
+extern "C" size_t FSEHIP_FSE_buildDTable_fromNorm_batch_workspaceSize(size_t nBlocks, unsigned tableLog) { return FSEHIP_FSE_decompress_batch_workspaceSize(nBlocks, tableLog); }
+extern "C" int FSEHIP_FSE_buildDTable_fromNorm_batch(FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, const short* d_norms, size_t normStride,
+                                                     const unsigned* d_maxSymbolValues, unsigned tableLog, size_t nBlocks, size_t* d_results,
+                                                     void* d_workspace, size_t workspaceBytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if ((uintptr_t)d_workspace & 255u) return (int)hipErrorInvalidValue;
+    if (nBlocks == 0) return 0;
+    if (!d_dtables || !d_norms || !d_maxSymbolValues || !d_results || normStride < 256) return (int)hipErrorInvalidValue;
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return batch_arg_error(d_results, nullptr, 0, 0, nBlocks, FSEHIP_ERROR(tableLog_tooLarge), 0, s);   // lib/fse_decompress.c:84
+    const unsigned maxLog = tableLog ? tableLog : 1;                     // (tableLog 0: refused per block, GENERIC)
+    if (dtableStrideU32 < FSEHIP_FSE_DTABLE_SIZE_U32(maxLog)) return (int)hipErrorInvalidValue;
+    const size_t per = fse_dws_per_block(maxLog);
+    if (workspaceBytes < per + WS_SLACK) return (int)hipErrorInvalidValue;
+    size_t chunk = (workspaceBytes - WS_SLACK) / per;
+    if (chunk > nBlocks) chunk = nBlocks;
+    u8* p = (u8*)d_workspace;
+    FseMeta* meta = (FseMeta*)p; p += align_up(chunk * sizeof(FseMeta), 256);
+    s16* norms = (s16*)p; p += align_up(chunk * 512, 256);
+    u16* atab = (u16*)p; p += align_up((chunk * 2) << maxLog, 256);
+    u8* symtab = p; p += align_up(chunk << maxLog, 256);
+    u32* lists = (u32*)p; p += align_up(chunk * FSE_DCLS_COUNT * sizeof(u32), 256);
+    u32* counts = (u32*)p;
+    for (size_t b0 = 0; b0 < nBlocks; b0 += chunk) {
+        const size_t nb = (nBlocks - b0) < chunk ? (nBlocks - b0) : chunk;
+        FseDPrepArgs d;
+        d.csrc = mkview(nullptr, 0, nullptr, 0);
+        d.maxLog = maxLog; d.atab = atab; d.symtab = symtab; d.norms = norms; d.meta = meta; d.lists = lists; d.counts = counts;
+        d.results = d_results + b0; d.nBlocks = nb; d.rawRle = 0; d.origSizes = nullptr; d.uniformOrig = 0;
+        CK(launch_fse_dprep_from_norm(d, (const s16*)d_norms + b0 * normStride, normStride, d_maxSymbolValues + b0, tableLog, s));
+        CK(launch_fse_export_dtables(d, d_dtables + b0 * dtableStrideU32, dtableStrideU32, s));
+        CK(launch_hdr_results(meta, sizeof(FseMeta), d_results + b0, nb, s));   // (hdrSize 0: FSE_buildDTable returns 0)
+    }
+    return 0;
+}
+
 static const size_t HUF_BCT_PER_BLOCK = 1024 + 4 + 8 + sizeof(HufMeta);
 extern "C" size_t FSEHIP_HUF_buildCTable_batch_workspaceSize(size_t nBlocks)
 {
@@ -919,6 +964,121 @@ extern "C" size_t FSEHIP_FSE_decompress_wksp(void* dst, size_t dstCapacity, cons
             if (tl <= ml) HK(hipMemcpy(workSpace, ddt.p, 4 * ((size_t)1 + ((size_t)1 << tl)), hipMemcpyDeviceToHost));
         }
     }
+    return r;
+}
+
+// ---- the table glue on host pointers, reference signatures (lib/fse.h:111-163, :222-241): what a caller of the "advanced" flow -- count, normalise,
+//      write the header, build the table, code with it -- finds under the reference's names in libfse_dropin.so.  FSE_optimalTableLog and
+//      FSE_NCountWriteBound are arithmetic on the arguments (lib/fse_compress.c:186-190, :325-347); the others are batches of one.
+extern "C" unsigned FSEHIP_FSE_optimalTableLog(unsigned maxTableLog, size_t srcSize, unsigned maxSymbolValue)
+{
+    auto hb = [](u32 v) { return 31u - (u32)__builtin_clz(v); };       // lib/bitstream.h:139 (v != 0: srcSize > 1 and maxSymbolValue >= 1 are the reference's preconditions too)
+    const u32 maxBitsSrc = hb((u32)(srcSize - 1)) - 2;
+    const u32 minBitsSrc = hb((u32)srcSize) + 1, minBitsSymbols = hb(maxSymbolValue) + 2;
+    const u32 minBits = minBitsSrc < minBitsSymbols ? minBitsSrc : minBitsSymbols;
+    u32 tl = maxTableLog ? maxTableLog : FSEHIP_FSE_DEFAULT_TABLELOG;
+    if (maxBitsSrc < tl) tl = maxBitsSrc;
+    if (minBits > tl) tl = minBits;
+    if (tl < FSEHIP_FSE_MIN_TABLELOG) tl = FSEHIP_FSE_MIN_TABLELOG;
+    if (tl > FSEHIP_FSE_MAX_TABLELOG) tl = FSEHIP_FSE_MAX_TABLELOG;
+    return tl;
+}
+extern "C" size_t FSEHIP_FSE_NCountWriteBound(unsigned maxSymbolValue, unsigned tableLog)
+{
+    return maxSymbolValue ? (size_t)((((maxSymbolValue + 1) * tableLog) >> 3) + 3) : (size_t)FSEHIP_FSE_NCOUNTBOUND;
+}
+extern "C" size_t FSEHIP_FSE_normalizeCount(short* normalizedCounter, unsigned tableLog, const unsigned* count, size_t total, unsigned maxSymbolValue)
+{
+    if (maxSymbolValue > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);      // (byte alphabets; the reference would index beyond its FSE_MAX_SYMBOL_VALUE-sized users' arrays)
+    DevBuf dn, dc, dt, dm, dr;
+    HK(dn.alloc(512)); HK(dc.alloc(1024)); HK(dt.alloc(8)); HK(dm.alloc(4)); HK(dr.alloc(8));
+    HK(hipMemcpy(dc.p, count, 4 * ((size_t)maxSymbolValue + 1), hipMemcpyHostToDevice));
+    HK(hipMemcpy(dt.p, &total, 8, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dm.p, &maxSymbolValue, 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_normalizeCount_batch((short*)dn.p, 256, tableLog, (const unsigned*)dc.p, 256, (const size_t*)dt.p, (const unsigned*)dm.p, 1, (size_t*)dr.p, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r)) HK(hipMemcpy(normalizedCounter, dn.p, 2 * ((size_t)maxSymbolValue + 1), hipMemcpyDeviceToHost));
+    return r;
+}
+extern "C" size_t FSEHIP_FSE_writeNCount(void* buffer, size_t bufferSize, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog)
+{
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return FSEHIP_ERROR(tableLog_tooLarge);   // lib/fse_compress.c:281-282
+    if (tableLog < FSEHIP_FSE_MIN_TABLELOG || maxSymbolValue > 255) return FSEHIP_ERROR(GENERIC);
+    const size_t cap = bufferSize < 512 ? bufferSize : 512;                      // (no header is longer than FSE_NCOUNTBOUND = 512 bytes)
+    DevBuf dh, dn, dm, dr;
+    HK(dh.alloc(512)); HK(dn.alloc(512)); HK(dm.alloc(4)); HK(dr.alloc(8));
+    HK(hipMemset(dn.p, 0, 512));
+    HK(hipMemcpy(dn.p, normalizedCounter, 2 * ((size_t)maxSymbolValue + 1), hipMemcpyHostToDevice));
+    HK(hipMemcpy(dm.p, &maxSymbolValue, 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_writeNCount_batch(dh.p, 512, cap, (const short*)dn.p, 256, (const unsigned*)dm.p, tableLog, 1, (size_t*)dr.p, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(buffer, dh.p, r, hipMemcpyDeviceToHost));
+    return r;
+}
+extern "C" size_t FSEHIP_FSE_readNCount(short* normalizedCounter, unsigned* maxSVPtr, unsigned* tableLogPtr, const void* rBuffer, size_t rBuffSize)
+{
+    const unsigned limit = *maxSVPtr;
+    if (limit > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);
+    const size_t n = rBuffSize < 1024 ? rBuffSize : 1024;                          // (a header describes at most 256 symbols: it ends long before)
+    DevBuf dh, dn, dm, dl, dr;
+    HK(dh.alloc(n ? n : 1)); HK(dn.alloc(512)); HK(dm.alloc(4)); HK(dl.alloc(4)); HK(dr.alloc(8));
+    if (n) HK(hipMemcpy(dh.p, rBuffer, n, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dm.p, &limit, 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_FSE_readNCount_batch((short*)dn.p, 256, (unsigned*)dm.p, (unsigned*)dl.p, dh.p, n, nullptr, n, 1, (size_t*)dr.p, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (FSEHIP_isError(r)) return r;
+    HK(hipMemcpy(normalizedCounter, dn.p, 2 * ((size_t)limit + 1), hipMemcpyDeviceToHost));   // (the reference clears [0, limit] first: lib/entropy_common.c:68)
+    HK(hipMemcpy(maxSVPtr, dm.p, 4, hipMemcpyDeviceToHost));
+    HK(hipMemcpy(tableLogPtr, dl.p, 4, hipMemcpyDeviceToHost));
+    return r;
+}
+static size_t fse_norm_to_device(DevBuf& dn, DevBuf& dm, const short* normalizedCounter, unsigned maxSymbolValue)
+{
+    HK(dn.alloc(512)); HK(dm.alloc(4));
+    HK(hipMemset(dn.p, 0, 512));
+    HK(hipMemcpy(dn.p, normalizedCounter, 2 * ((size_t)maxSymbolValue + 1), hipMemcpyHostToDevice));
+    HK(hipMemcpy(dm.p, &maxSymbolValue, 4, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" size_t FSEHIP_FSE_buildCTable(FSEHIP_FSE_CTable* ct, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog)
+{
+    if (maxSymbolValue > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return FSEHIP_ERROR(tableLog_tooLarge);   // lib/fse_compress.c:86 with the 4096-byte workspace of :172-176
+    if (tableLog == 0 || tableLog == 1 || tableLog == 3) return FSEHIP_ERROR(GENERIC);   // (no table, or an even FSE_TABLESTEP: fsehip.h)
+    const size_t words = FSEHIP_FSE_CTABLE_SIZE_U32(tableLog, 255);
+    DevBuf dn, dm, dct, dr;
+    { const size_t e = fse_norm_to_device(dn, dm, normalizedCounter, maxSymbolValue); if (e) return e; }
+    HK(dct.alloc(4 * words)); HK(dr.alloc(8));
+    HK((hipError_t)FSEHIP_FSE_buildCTable_fromNorm_batch((unsigned*)dct.p, words, (const short*)dn.p, 256, (const unsigned*)dm.p, tableLog, 1, (size_t*)dr.p, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r)) HK(hipMemcpy(ct, dct.p, 4 * (size_t)FSEHIP_FSE_CTABLE_SIZE_U32(tableLog, maxSymbolValue), hipMemcpyDeviceToHost));
+    return r;
+}
+// lib/fse.h:341 (lib/fse_compress.c:70-87): the workspace is checked as the reference checks it and then left alone
+extern "C" size_t FSEHIP_FSE_buildCTable_wksp(FSEHIP_FSE_CTable* ct, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize)
+{
+    (void)workSpace;
+    if (tableLog > 31 || ((size_t)1 << tableLog) > wkspSize) return FSEHIP_ERROR(tableLog_tooLarge);
+    return FSEHIP_FSE_buildCTable(ct, normalizedCounter, maxSymbolValue, tableLog);
+}
+extern "C" size_t FSEHIP_FSE_buildDTable(FSEHIP_FSE_DTable* dt, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog)
+{
+    if (maxSymbolValue > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);       // lib/fse_decompress.c:83-84
+    if (tableLog > FSEHIP_FSE_MAX_TABLELOG) return FSEHIP_ERROR(tableLog_tooLarge);
+    if (tableLog == 0 || tableLog == 1 || tableLog == 3) return FSEHIP_ERROR(GENERIC);   // (no table, or an even FSE_TABLESTEP: fsehip.h)
+    const size_t words = FSEHIP_FSE_DTABLE_SIZE_U32(tableLog);
+    const size_t wsB = FSEHIP_FSE_buildDTable_fromNorm_batch_workspaceSize(1, tableLog);
+    DevBuf dn, dm, ddt, dws, dr;
+    { const size_t e = fse_norm_to_device(dn, dm, normalizedCounter, maxSymbolValue); if (e) return e; }
+    HK(ddt.alloc(4 * words)); HK(dws.alloc(wsB)); HK(dr.alloc(8));
+    HK((hipError_t)FSEHIP_FSE_buildDTable_fromNorm_batch((unsigned*)ddt.p, words, (const short*)dn.p, 256, (const unsigned*)dm.p, tableLog, 1, (size_t*)dr.p, dws.p, wsB, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r)) HK(hipMemcpy(dt, ddt.p, 4 * words, hipMemcpyDeviceToHost));
     return r;
 }
 

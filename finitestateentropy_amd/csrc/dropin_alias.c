@@ -1,4 +1,4 @@
-/* dropin_alias.c -- libfse_dropin.so: the reference's OWN symbol names (lib/hist.h:30,46,54, lib/fse.h:76,90,104,174,247,315,335,
+/* dropin_alias.c -- libfse_dropin.so: the reference's OWN symbol names (lib/hist.h:30,46,54, lib/fse.h:76,90,104,119-163,174,222-247,315,335,341,
  * lib/huf.h:66,82,95,164,190,275-277,289-290, lib/error_public.h / fse.h:124-128) as real exported functions that forward to libfsehip.so.
  * include/fsehip.h renames at COMPILE time (FSEHIP_DROPIN_NAMES); this is the LINK-time form: an object file or application already
  * compiled against the reference's headers is relinked with `-lfse_dropin -lfsehip` instead of the reference's lib/ *.o and runs on
@@ -30,6 +30,16 @@ DROPIN size_t FSE_decompress(void* dst, size_t cap, const void* src, size_t n) {
 DROPIN size_t FSE_decompress_wksp(void* dst, size_t cap, const void* src, size_t n, FSEHIP_FSE_DTable* ws, unsigned maxLog) { return FSEHIP_FSE_decompress_wksp(dst, cap, src, n, ws, maxLog); }
 DROPIN size_t FSE_compress_usingCTable(void* dst, size_t cap, const void* src, size_t n, const FSEHIP_FSE_CTable* ct) { return FSEHIP_FSE_compress_usingCTable(dst, cap, src, n, ct); }
 DROPIN size_t FSE_decompress_usingDTable(void* dst, size_t cap, const void* src, size_t n, const FSEHIP_FSE_DTable* dt) { return FSEHIP_FSE_decompress_usingDTable(dst, cap, src, n, dt); }
+
+/* the table glue of the advanced flow, lib/fse.h:119-163, :222-241, :341 */
+DROPIN unsigned FSE_optimalTableLog(unsigned maxTl, size_t n, unsigned msv) { return FSEHIP_FSE_optimalTableLog(maxTl, n, msv); }
+DROPIN size_t FSE_normalizeCount(short* norm, unsigned tl, const unsigned* count, size_t n, unsigned msv) { return FSEHIP_FSE_normalizeCount(norm, tl, count, n, msv); }
+DROPIN size_t FSE_NCountWriteBound(unsigned msv, unsigned tl) { return FSEHIP_FSE_NCountWriteBound(msv, tl); }
+DROPIN size_t FSE_writeNCount(void* buf, size_t cap, const short* norm, unsigned msv, unsigned tl) { return FSEHIP_FSE_writeNCount(buf, cap, norm, msv, tl); }
+DROPIN size_t FSE_readNCount(short* norm, unsigned* msv, unsigned* tl, const void* src, size_t n) { return FSEHIP_FSE_readNCount(norm, msv, tl, src, n); }
+DROPIN size_t FSE_buildCTable(FSEHIP_FSE_CTable* ct, const short* norm, unsigned msv, unsigned tl) { return FSEHIP_FSE_buildCTable(ct, norm, msv, tl); }
+DROPIN size_t FSE_buildCTable_wksp(FSEHIP_FSE_CTable* ct, const short* norm, unsigned msv, unsigned tl, void* ws, size_t wsn) { return FSEHIP_FSE_buildCTable_wksp(ct, norm, msv, tl, ws, wsn); }
+DROPIN size_t FSE_buildDTable(FSEHIP_FSE_DTable* dt, const short* norm, unsigned msv, unsigned tl) { return FSEHIP_FSE_buildDTable(dt, norm, msv, tl); }
 
 DROPIN size_t HUF_compress(void* dst, size_t cap, const void* src, size_t n) { return FSEHIP_HUF_compress(dst, cap, src, n); }
 DROPIN size_t HUF_compress2(void* dst, size_t cap, const void* src, size_t n, unsigned msv, unsigned tl) { return FSEHIP_HUF_compress2(dst, cap, src, n, msv, tl); }

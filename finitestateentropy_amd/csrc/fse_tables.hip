@@ -16,6 +16,46 @@
 // ---------------------------------------------------------------------------------------------------
 //  prepare kernels
 // ---------------------------------------------------------------------------------------------------
+// FSE_buildCTable_wksp (lib/fse_compress.c:66-169) from the normalised counters a wave holds in registers (lane l: symbols 4l .. 4l+3, zero beyond
+// maxSV): the table is written straight to global memory, symbolTT entries coalesced, stateTable entries as scattered 2-byte stores inside the
+// block's 4 KiB (the L2 merges them) -- an LDS image would cost 6 KiB per build, i.e. occupancy.  Shared by k_fse_cprep (counters it has just
+// normalised) and k_fse_ctable_from_norm (the caller's counters: FSE_buildCTable as a call of its own).  Uses __syncthreads(): the workgroup is the wave.
+DEV void fse_wave_build_ctable(const WaveBuildLds& w, const int nn[4], u32 maxSV, u32 tl, u32* img, u32 lane)
+{
+    u16* const cumAll = w.cumP;                                            // [256] first stateTable slot of every symbol (the core leaves cumP to its caller)
+    *(uint2*)(w.nrm + 4 * lane) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
+    __syncthreads();
+    const u32 ts = 1u << tl;
+    u16* const stateTable = (u16*)(img + 1);
+    u32* const tt = img + 1 + (ts >> 1);                                   // tl >= 1 here (lib/fse_compress.c:75: one word of state table when tableLog is 0)
+    {   // per symbol (lane l: symbols 4l..4l+3): cumulative slot, symbolTT (fse_compress.c:136-166)
+        u32 eff[4], laneSum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { eff[i] = nn[i] == -1 ? 1u : (u32)nn[i]; laneSum += eff[i]; }
+        u32 total;
+        u32 run = wb_scan_excl(laneSum, lane, &total);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 s = 4 * lane + i;
+            cumAll[s] = (u16)run;
+            if (s <= maxSV) {
+                if (nn[i] == 0) { tt[2 * s] = 0; tt[2 * s + 1] = ((tl + 1) << 16) - ts; }
+                else if (nn[i] == -1 || nn[i] == 1) { tt[2 * s] = run - 1u; tt[2 * s + 1] = (tl << 16) - ts; }
+                else {
+                    const u32 maxBitsOut = tl - hibit32((u32)nn[i] - 1);
+                    tt[2 * s] = run - (u32)nn[i];
+                    tt[2 * s + 1] = (maxBitsOut << 16) - ((u32)nn[i] << maxBitsOut);
+                }
+            }
+            run += eff[i];
+        }
+        if (lane == 0) img[0] = tl | (maxSV << 16);
+    }
+    __syncthreads();
+    wave_spread_rank(w, maxSV, tl, lane, [&](u32 s) { return (u32)cumAll[s]; },
+                     [&](u32 u, u32 s, u32 r, u32 first) { (void)s; stateTable[first + r] = (u16)(ts + u); });   // :125-133
+}
+
 // Compress side: k_fse_cprep, one wave per block -- everything between the histogram and the hot loop
 // (lib/fse_compress.c:632-665): the early outs of FSE_compress_wksp, the table log, the normalised counters and the NCount
 // header (wave_glue.h: every symbol handled independently, totals by wave reductions, bit offsets by scans), then
@@ -75,41 +115,7 @@ __global__ __launch_bounds__(64) void k_fse_cprep(FseCPrepArgs a, u32 capTs)
     }
     m.tableLog = tl; m.maxSV = maxSV;
     if (lane == 0) a.meta[b] = m;
-    // ---- FSE_buildCTable: the table is written straight to global memory, symbolTT entries coalesced, stateTable entries as
-    // scattered 2-byte stores inside the block's 4 KiB (the L2 merges them) -- an LDS image would cost 6 KiB per build, i.e. occupancy.
-    u32* const img = a.ctables + b * a.ctStrideU32;
-    u16* const cumAll = w.cumP;                                            // [256] first stateTable slot of every symbol (the core leaves cumP to its caller)
-    *(uint2*)(w.nrm + 4 * lane) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
-    __syncthreads();
-    const u32 ts = 1u << tl;
-    u16* const stateTable = (u16*)(img + 1);
-    u32* const tt = img + 1 + (ts >> 1);                                   // tl >= FSE_MIN_TABLELOG here
-    {   // per symbol (lane l: symbols 4l..4l+3): cumulative slot, symbolTT (fse_compress.c:136-166)
-        u32 eff[4], laneSum = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { eff[i] = nn[i] == -1 ? 1u : (u32)nn[i]; laneSum += eff[i]; }
-        u32 total;
-        u32 run = wb_scan_excl(laneSum, lane, &total);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 s = 4 * lane + i;
-            cumAll[s] = (u16)run;
-            if (s <= maxSV) {
-                if (nn[i] == 0) { tt[2 * s] = 0; tt[2 * s + 1] = ((tl + 1) << 16) - ts; }
-                else if (nn[i] == -1 || nn[i] == 1) { tt[2 * s] = run - 1u; tt[2 * s + 1] = (tl << 16) - ts; }
-                else {
-                    const u32 maxBitsOut = tl - hibit32((u32)nn[i] - 1);
-                    tt[2 * s] = run - (u32)nn[i];
-                    tt[2 * s + 1] = (maxBitsOut << 16) - ((u32)nn[i] << maxBitsOut);
-                }
-            }
-            run += eff[i];
-        }
-        if (lane == 0) img[0] = tl | (maxSV << 16);
-    }
-    __syncthreads();
-    wave_spread_rank(w, maxSV, tl, lane, [&](u32 s) { return (u32)cumAll[s]; },
-                     [&](u32 u, u32 s, u32 r, u32 first) { (void)s; stateTable[first + r] = (u16)(ts + u); });   // :125-133
+    fse_wave_build_ctable(w, nn, maxSV, tl, a.ctables + b * a.ctStrideU32, lane);
 }
 
 // Decompress side, two kernels:
@@ -222,7 +228,9 @@ __global__ __launch_bounds__(64) void k_fse_dbuild(FseDPrepArgs a, u32 capTs, in
     });
     u32* const A32 = (u32*)(a.atab + b * capTs);
     u32* const S32 = (u32*)(a.symtab + b * capTs);
-    if (rev) {
+    if (ts < 4u) {                                                         // uniform: a table of two cells (FSE_buildDTable on a caller's counters; no header says tableLog 1)
+        if (lane < ts) { const u32 x = rev ? __brev(lane) >> (32u - tl) : lane; (a.atab + b * capTs)[lane] = w.cell[wb_ci(x)]; (a.symtab + b * capTs)[lane] = w.symTab[wb_si(x)]; }
+    } else if (rev) {
         const u32 rs = 32u - tl;                                           // tl >= FSE_MIN_TABLELOG = 5
         for (u32 i = lane; i < ts / 2; i += 64)
             A32[i] = (u32)w.cell[wb_ci(__brev(2u * i) >> rs)] | ((u32)w.cell[wb_ci(__brev(2u * i + 1u) >> rs)] << 16);
@@ -263,6 +271,89 @@ hipError_t launch_fse_export_dtables(const FseDPrepArgs& a, u32* dtables, size_t
 {
     if (a.nBlocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fse_export_dtable, dim3((unsigned)a.nBlocks), dim3(256), 0, s, a, 1u << a.maxLog, dtables, dtStrideU32);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+//  FSE_buildCTable / FSE_buildDTable on normalised counters the CALLER supplies (lib/fse.h:162-163 / :240-241): the table builders as calls of
+//  their own, beside the forms that start from the blocks (FSE_buildCTable_batch) or from the headers (FSE_buildDTable_batch).  One wave per
+//  table.  What the reference leaves undefined is refused: counters that do not describe a table of 1 << tableLog cells (it asserts in the
+//  CTable builder, lib/fse_compress.c:127, and returns GENERIC from the DTable builder, lib/fse_decompress.c:107), counters below -1, tableLog 0,
+//  and the table logs 1 and 3, whose FSE_TABLESTEP (lib/fse.h:683) is even: the reference's spread then writes cell 0 over and over and leaves the
+//  other cells as it found them (every table log from FSE_MIN_TABLELOG = 5 up, and 2 and 4, has an odd step).
+// ---------------------------------------------------------------------------------------------------
+DEV size_t fse_norm_load_checked(int nn[4], const s16* nb, u32 maxSV, u32 tl, u32 maxTl, u32 lane)
+{
+    if (maxSV > 255u) return FERR(maxSymbolValue_tooLarge);                // lib/fse_decompress.c:83 (FSE_MAX_SYMBOL_VALUE)
+    if (tl > maxTl) return FERR(tableLog_tooLarge);                        // :84; the CTable builder's workspace check, lib/fse_compress.c:86
+    if (tl == 0 || tl == 1 || tl == 3) return FERR(GENERIC);               // FSE_TABLESTEP(2) = 4, FSE_TABLESTEP(8) = 8: the reference's spread never leaves cell 0 there
+    u32 cells = 0; bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nn[i] = 4 * lane + i <= maxSV ? (int)nb[4 * lane + i] : 0;
+        bad |= nn[i] < -1;
+        cells += nn[i] == -1 ? 1u : nn[i] > 0 ? (u32)nn[i] : 0u;
+    }
+    cells = wg_sum<64>(cells);
+    return (wg_any<64>(bad, lane) || cells != (1u << tl)) ? FERR(GENERIC) : 0;
+}
+__global__ __launch_bounds__(64) void k_fse_ctable_from_norm(const s16* norms, size_t normStride, const u32* maxSVs, u32 tl, u32* ctables, size_t ctStrideU32,
+                                                            size_t* results, u32 capTs)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 wbLds[];
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const u32 maxSV = maxSVs[b];
+    int nn[4] = { 0, 0, 0, 0 };
+    const size_t r = fse_norm_load_checked(nn, norms + b * normStride, maxSV, tl, FSE_MAX_TL, lane);
+    if (lane == 0) results[b] = r;
+    if (is_err(r)) return;                                                 // uniform
+    fse_wave_build_ctable(wave_build_carve(wbLds, capTs), nn, maxSV, tl, ctables + b * ctStrideU32, lane);
+}
+hipError_t launch_fse_ctable_from_norm(const s16* norms, size_t normStride, const u32* maxSVs, u32 tl, u32* ctables, size_t ctStrideU32, size_t* results,
+                                       size_t nBlocks, hipStream_t s)
+{
+    if (nBlocks == 0) return hipSuccess;
+    const u32 capTs = 1u << (tl >= 1 && tl <= FSE_MAX_TL ? tl : FSE_MAX_TL);
+    hipLaunchKernelGGL(k_fse_ctable_from_norm, dim3((unsigned)nBlocks), dim3(64), wave_build_lds_bytes(capTs), s, norms, normStride, maxSVs, tl, ctables, ctStrideU32,
+                       results, capTs);
+    return hipGetLastError();
+}
+
+// the counters -> what k_fse_dparse leaves behind for k_fse_dbuild (meta, counters in scratch, the block filed under its decoder class)
+__global__ __launch_bounds__(64) void k_fse_dmeta_from_norm(FseDPrepArgs a, const s16* norms, size_t normStride, const u32* maxSVs, u32 tl)
+{
+    const size_t b = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const u32 maxSV = maxSVs[b];
+    int nn[4] = { 0, 0, 0, 0 };
+    const size_t r = fse_norm_load_checked(nn, norms + b * normStride, maxSV, tl, a.maxLog, lane);
+    FseMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = tl; m.maxSV = maxSV; m.pace = 0;
+    if (!is_err(r)) {
+        *(uint2*)(a.norms + b * 256 + 4 * lane) = make_uint2(((u32)nn[0] & 0xFFFFu) | ((u32)nn[1] << 16), ((u32)nn[2] & 0xFFFFu) | ((u32)nn[3] << 16));
+        int top = nn[0] > nn[1] ? nn[0] : nn[1]; top = nn[2] > top ? nn[2] : top; top = nn[3] > top ? nn[3] : top;
+        top = wave_max_i32(top);
+        const u32 cls = tl <= FSE_DEC_FAST_MAXLOG ? (u32)FSE_DCLS_REV11 : 2 * top > (1 << tl) ? (u32)FSE_DCLS_PLAIN : (u32)FSE_DCLS_REV12;   // as k_fse_dparse
+        m.state = 1u | (cls << 2);
+        if (lane == 0) {
+            const u32 at = atomicAdd(&a.counts[cls * FSE_DBINS], 1u);      // (size bin 0: there is no stream)
+            atomicAdd(&a.counts[FSE_DCLS_COUNT + cls], 1u);
+            a.lists[(size_t)cls * FSE_DBINS * a.nBlocks + at] = (u32)b;
+        }
+    }
+    if (lane == 0) { a.meta[b] = m; if (is_err(r)) a.results[b] = r; }
+}
+hipError_t launch_fse_dprep_from_norm(const FseDPrepArgs& a, const s16* norms, size_t normStride, const u32* maxSVs, u32 tl, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    const u32 capTs = 1u << a.maxLog;
+    hipError_t e = launch_zero_u32(a.counts, FSE_DCLS_COUNT + FSE_DCLS_KINDS, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fse_dmeta_from_norm, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, norms, normStride, maxSVs, tl);
+    const u32 capA = a.maxLog < FSE_DEC_FAST_MAXLOG ? capTs : (1u << FSE_DEC_FAST_MAXLOG);
+    hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capA), s, a, capTs, (int)FSE_DCLS_REV11 * FSE_DBINS, (int)FSE_DBINS, capA);
+    if (a.maxLog > FSE_DEC_FAST_MAXLOG)
+        hipLaunchKernelGGL(k_fse_dbuild, dim3((unsigned)a.nBlocks), dim3(64), wave_build_lds_bytes(capTs), s, a, capTs, (int)FSE_DCLS_REV12 * FSE_DBINS, 2 * (int)FSE_DBINS, capTs);
     return hipGetLastError();
 }
 

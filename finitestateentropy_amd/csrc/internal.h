@@ -54,6 +54,9 @@ hipError_t launch_fse_glue_normalize(s16* norms, size_t normStride, u32 tl, cons
 hipError_t launch_fse_glue_write_ncount(u8* headers, size_t headerStride, size_t headerCapacity, const s16* norms, size_t normStride, const u32* maxSVs, u32 tl,
                                         size_t* results, size_t nBlocks, hipStream_t s);
 hipError_t launch_fse_glue_read_ncount(s16* norms, size_t normStride, u32* maxSVs, u32* tableLogs, const BlockView& headers, size_t* results, size_t nBlocks, hipStream_t s);
+// FSE_buildCTable on the caller's normalised counters (one table log per call, lib/fse.h:162), FSE_buildDTable likewise (declared below FseDPrepArgs)
+hipError_t launch_fse_ctable_from_norm(const s16* norms, size_t normStride, const u32* maxSVs, u32 tl, u32* ctables, size_t ctStrideU32, size_t* results,
+                                       size_t nBlocks, hipStream_t s);
 
 struct FseEncArgs {              // a2: FSE_compress_usingCTable, one lane per block
     u8* dst; size_t dstStride; size_t dstCapacity;
@@ -138,6 +141,7 @@ struct FseDPrepArgs {            // glue g2,g3,g4 (decompress side): FSE_readNCo
     int rawRle; const size_t* origSizes; size_t uniformOrig;
 };
 hipError_t launch_fse_dprep(const FseDPrepArgs& a, hipStream_t s);
+hipError_t launch_fse_dprep_from_norm(const FseDPrepArgs& a, const s16* norms, size_t normStride, const u32* maxSVs, u32 tl, hipStream_t s);
 
 struct FseDecArgs {              // a3: FSE_decompress_usingDTable, one lane per block
     u8* dst; size_t dstStride; size_t dstCapacity;

@@ -112,6 +112,24 @@ FSEHIP_API size_t FSEHIP_FSE_decompress(void* dst, size_t dstCapacity, const voi
  * reference would have built there) */
 FSEHIP_API size_t FSEHIP_FSE_compress_wksp(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
 FSEHIP_API size_t FSEHIP_FSE_decompress_wksp(void* dst, size_t dstCapacity, const void* cSrc, size_t cSrcSize, FSEHIP_FSE_DTable* workSpace, unsigned maxLog);
+/* The steps between the histogram and the hot loops under their own names -- the reference's "advanced" flow (lib/fse.h:107-163, :218-241: count,
+ * FSE_optimalTableLog, FSE_normalizeCount, FSE_writeNCount, FSE_buildCTable, FSE_compress_usingCTable / FSE_readNCount, FSE_buildDTable,
+ * FSE_decompress_usingDTable), each a batch of one on the device routines the one-shot calls run (csrc/wave_glue.h, ncount_reader.h,
+ * fse_wave_build.h); FSE_optimalTableLog and FSE_NCountWriteBound are arithmetic on their arguments (lib/fse_compress.c:186-190, :325-347).
+ * lib/fse.h:119, :137, :144, :150, :162 (+ :341 the _wksp form: workspace checked as lib/fse_compress.c:86 checks it, then left alone), :222, :240.
+ * Where the reference is undefined the call refuses: normalised counters that do not add up to 1 << tableLog cells or go below -1 (the CTable
+ * builder asserts, lib/fse_compress.c:127; the DTable builder returns GENERIC, lib/fse_decompress.c:107) -> GENERIC from both builders;
+ * tableLog 0, 1 or 3 -> GENERIC (FSE_TABLESTEP(2) and (8) are even, lib/fse.h:683: the reference's spread never leaves cell 0 and the rest of its table is
+ * whatever the memory held; 2, 4 and everything from FSE_MIN_TABLELOG up are exact); maxSymbolValue > 255 -> maxSymbolValue_tooLarge (byte alphabets; FSE_buildDTable says so itself, :83).  A failed
+ * FSE_writeNCount / FSE_readNCount leaves its output untouched (the reference may have written part of it). */
+FSEHIP_API unsigned FSEHIP_FSE_optimalTableLog(unsigned maxTableLog, size_t srcSize, unsigned maxSymbolValue);
+FSEHIP_API size_t FSEHIP_FSE_normalizeCount(short* normalizedCounter, unsigned tableLog, const unsigned* count, size_t srcSize, unsigned maxSymbolValue);
+FSEHIP_API size_t FSEHIP_FSE_NCountWriteBound(unsigned maxSymbolValue, unsigned tableLog);
+FSEHIP_API size_t FSEHIP_FSE_writeNCount(void* buffer, size_t bufferSize, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog);
+FSEHIP_API size_t FSEHIP_FSE_readNCount(short* normalizedCounter, unsigned* maxSymbolValuePtr, unsigned* tableLogPtr, const void* rBuffer, size_t rBuffSize);
+FSEHIP_API size_t FSEHIP_FSE_buildCTable(FSEHIP_FSE_CTable* ct, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog);
+FSEHIP_API size_t FSEHIP_FSE_buildCTable_wksp(FSEHIP_FSE_CTable* ct, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_FSE_buildDTable(FSEHIP_FSE_DTable* dt, const short* normalizedCounter, unsigned maxSymbolValue, unsigned tableLog);
 
 /* lib/huf.h:290, :190 */
 FSEHIP_API size_t FSEHIP_HUF_compress1X_usingCTable(void* dst, size_t dstSize, const void* src, size_t srcSize, const FSEHIP_HUF_CElt* CTable);
@@ -286,6 +304,18 @@ FSEHIP_API int FSEHIP_FSE_writeNCount_batch(void* d_headers, size_t headerStride
 FSEHIP_API int FSEHIP_FSE_readNCount_batch(short* d_norms, size_t normStride, unsigned* d_maxSymbolValues, unsigned* d_tableLogs,
                                            const void* d_headers, size_t headerStride, const size_t* d_headerSizes, size_t uniformHeaderSize,
                                            size_t nBlocks, size_t* d_results, void* stream);
+/*   buildCTable_fromNorm / buildDTable_fromNorm : FSE_buildCTable (lib/fse.h:162, lib/fse_compress.c:66-177) and FSE_buildDTable (lib/fse.h:240,
+ *                    lib/fse_decompress.c:71-126) on normalised counters the CALLER supplies -- d_norms + b*normStride holds
+ *                    normalizedCounter[0 .. d_maxSymbolValues[b]] (normStride >= 256), one tableLog (2, 4 .. 12) per call; tables in the reference's
+ *                    layouts (ctableStrideU32 >= FSE_CTABLE_SIZE_U32(tableLog, 255), dtableStrideU32 >= FSE_DTABLE_SIZE_U32(tableLog));
+ *                    d_results[b] = 0 or an error (see the single calls above for what is refused).  The DTable form needs the workspace of
+ *                    FSEHIP_FSE_buildDTable_fromNorm_batch_workspaceSize(nBlocks, tableLog). */
+FSEHIP_API int FSEHIP_FSE_buildCTable_fromNorm_batch(FSEHIP_FSE_CTable* d_ctables, size_t ctableStrideU32, const short* d_norms, size_t normStride,
+                                                     const unsigned* d_maxSymbolValues, unsigned tableLog, size_t nBlocks, size_t* d_results, void* stream);
+FSEHIP_API size_t FSEHIP_FSE_buildDTable_fromNorm_batch_workspaceSize(size_t nBlocks, unsigned tableLog);
+FSEHIP_API int FSEHIP_FSE_buildDTable_fromNorm_batch(FSEHIP_FSE_DTable* d_dtables, size_t dtableStrideU32, const short* d_norms, size_t normStride,
+                                                     const unsigned* d_maxSymbolValues, unsigned tableLog, size_t nBlocks, size_t* d_results,
+                                                     void* d_workspace, size_t workspaceBytes, void* stream);
 
 /* ---- Packed (variable-length) batches.  The batched compressors write fixed-stride slots like the reference bench's buffers
  * (programs/bench.c:514-516); what the reference's container stores (programs/fileio.c:343-400) and what is worth moving between GPUs
@@ -454,6 +484,16 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define HUF_compress4X_wksp FSEHIP_HUF_compress4X_wksp
 #define HUF_compress1X_wksp FSEHIP_HUF_compress1X_wksp
 #define HUF_decompress4X1_DCtx_wksp FSEHIP_HUF_decompress4X1_DCtx_wksp
+#endif
+#ifdef FSEHIP_DROPIN_GLUE_NAMES      /* separate switch: the table glue (a program that wants the reference's own builders beside the device's hot loops leaves it off) */
+#define FSE_optimalTableLog FSEHIP_FSE_optimalTableLog
+#define FSE_normalizeCount FSEHIP_FSE_normalizeCount
+#define FSE_NCountWriteBound FSEHIP_FSE_NCountWriteBound
+#define FSE_writeNCount FSEHIP_FSE_writeNCount
+#define FSE_readNCount FSEHIP_FSE_readNCount
+#define FSE_buildCTable FSEHIP_FSE_buildCTable
+#define FSE_buildCTable_wksp FSEHIP_FSE_buildCTable_wksp
+#define FSE_buildDTable FSEHIP_FSE_buildDTable
 #endif
 #ifdef FSEHIP_DROPIN_U16_NAMES       /* separate switch: programs/fuzzer.c declares FSE_countU16 with another (stale) prototype */
 #define FSE_countU16 FSEHIP_FSE_countU16
