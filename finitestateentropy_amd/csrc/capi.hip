@@ -1400,6 +1400,10 @@ extern "C" size_t FSEHIP_HUF_compress2(void* dst, size_t dstCapacity, const void
 {
     return huf_compress_host(4, dst, dstCapacity, src, srcSize, maxSymbolValue, tableLog);
 }
+extern "C" size_t FSEHIP_HUF_compress1X(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog)   // lib/huf.h:288 (huf_compress.c:750-756)
+{
+    return huf_compress_host(1, dst, dstSize, src, srcSize, maxSymbolValue, tableLog);
+}
 // lib/huf.h:95, :289 (lib/huf_compress.c:727-768 -> HUF_compress_internal :637-724): the workspace is validated as :654-655 validate it
 // (alignment first, then size) and then left alone; the 1X form writes one stream without a jump table (HUF_singleStream, :615-617)
 extern "C" size_t FSEHIP_HUF_compress4X_wksp(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog,
@@ -1419,21 +1423,19 @@ extern "C" size_t FSEHIP_HUF_compress1X_wksp(void* dst, size_t dstCapacity, cons
 // lib/huf.h:164 (lib/huf_decompress.c:417-438): HUF_readDTableX1_wksp into the caller's DTable -- whose descriptor carries the table-log limit
 // (HUF_CREATE_STATIC_DTABLEX1) and receives {tableType 0, tableLog}, the cells behind it -- then the four streams behind the header.  The
 // workspace is checked as :137 checks it ((16 + 64) words) and then left alone.
-extern "C" size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize,
-                                                     void* workSpace, size_t wkspSize)
+// HUF_readDTableX1_wksp (lib/huf_decompress.c:118-185) on a block that is in device memory already: dctx (host) receives descriptor and cells as the
+// reference leaves them, ddt (device) the same table for a decoder call behind it.  Returns the header size or an error code.
+static size_t huf_read_x1_host(FSEHIP_HUF_DTable* dctx, const void* d_src, size_t cSrcSize, DevBuf& ddt)
 {
-    (void)workSpace;
-    if (wkspSize < 4 * (16 + 64)) return FSEHIP_ERROR(tableLog_tooLarge);
     const u32 desc = dctx[0];
     unsigned mtl = desc & 0xFFu;                                   // DTableDesc.maxTableLog: tables up to mtl + 1 fit (:149)
     if (mtl > FSEHIP_HUF_TABLELOG_MAX - 1) mtl = FSEHIP_HUF_TABLELOG_MAX - 1;      // (HUF_readStats refuses table logs above 12 anyway)
     const unsigned mtlDev = mtl ? mtl : 1;                          // the batch call reads 0 as "default"; a limit of 0 is enforced below
     const size_t dtU32 = 1 + ((size_t)1 << mtlDev);
     const size_t wsB = FSEHIP_HUF_readDTableX1_batch_workspaceSize(1);
-    DevBuf dsrc, ddst, ddt, dws, dres;
-    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstSize)); HK(ddt.alloc(4 * dtU32)); HK(dws.alloc(wsB)); HK(dres.alloc(8));
-    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
-    HK((hipError_t)FSEHIP_HUF_readDTableX1_batch((u32*)ddt.p, dtU32, mtlDev, (size_t*)dres.p, dsrc.p, cSrcSize, nullptr, cSrcSize, 1, dws.p, wsB, nullptr));
+    DevBuf dws, dres;
+    HK(ddt.alloc(4 * dtU32)); HK(dws.alloc(wsB)); HK(dres.alloc(8));
+    HK((hipError_t)FSEHIP_HUF_readDTableX1_batch((u32*)ddt.p, dtU32, mtlDev, (size_t*)dres.p, d_src, cSrcSize, nullptr, cSrcSize, 1, dws.p, wsB, nullptr));
     size_t hSize = 0;
     HK(hipMemcpy(&hSize, dres.p, 8, hipMemcpyDeviceToHost));
     if (FSEHIP_isError(hSize)) return hSize;
@@ -1445,13 +1447,79 @@ extern "C" size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, vo
     dctx[0] = (desc & 0xFF0000FFu) | (tl << 16);                    // maxTableLog and the reserved byte stay the caller's (:150-152)
     const u32 dNew = dctx[0];
     HK(hipMemcpy(ddt.p, &dNew, 4, hipMemcpyHostToDevice));
+    return hSize;
+}
+// HUF_decompress4X1_DCtx_wksp / HUF_decompress1X1_DCtx_wksp (lib/huf_decompress.c:377-389, :416-436): the table from the block's header into dctx, then the
+// four streams (or the one stream) behind it
+static size_t huf_x1_dctx_host(int streams, FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize)
+{
+    DevBuf dsrc, ddst, dres, ddt;                                   // (in the order they are carved: ddt inside huf_read_x1_host)
+    HK(dsrc.alloc(cSrcSize)); HK(ddst.alloc(dstSize)); HK(dres.alloc(8));
+    HK(hipMemcpy(dsrc.p, cSrc, cSrcSize, hipMemcpyHostToDevice));
+    const size_t hSize = huf_read_x1_host(dctx, dsrc.p, cSrcSize, ddt);
+    if (FSEHIP_isError(hSize)) return hSize;
     if (hSize >= cSrcSize) return FSEHIP_ERROR(srcSize_wrong);
-    HK((hipError_t)FSEHIP_HUF_decompress4X1_usingDTable_batch(ddst.p, dstSize, nullptr, dstSize, (size_t*)dres.p, (const u8*)dsrc.p + hSize, cSrcSize - hSize, nullptr, cSrcSize - hSize,
-                                                              (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
+    if (streams == 4)
+        HK((hipError_t)FSEHIP_HUF_decompress4X1_usingDTable_batch(ddst.p, dstSize, nullptr, dstSize, (size_t*)dres.p, (const u8*)dsrc.p + hSize, cSrcSize - hSize, nullptr, cSrcSize - hSize,
+                                                                  (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
+    else
+        HK((hipError_t)FSEHIP_HUF_decompress1X1_usingDTable_batch(ddst.p, dstSize, nullptr, dstSize, (size_t*)dres.p, (const u8*)dsrc.p + hSize, cSrcSize - hSize, nullptr, cSrcSize - hSize,
+                                                                  (const u32*)ddt.p, 0, FSEHIP_HUF_TABLELOG_MAX, 1, nullptr));
     size_t r = 0;
     HK(hipMemcpy(&r, dres.p, 8, hipMemcpyDeviceToHost));
     if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, ddst.p, r <= dstSize ? r : dstSize, hipMemcpyDeviceToHost));
     return r;
+}
+extern "C" size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize,
+                                                     void* workSpace, size_t wkspSize)
+{
+    (void)workSpace;
+    if (wkspSize < 4 * (16 + 64)) return FSEHIP_ERROR(tableLog_tooLarge);
+    return huf_x1_dctx_host(4, dctx, dst, dstSize, cSrc, cSrcSize);
+}
+// the rest of the single-symbol family, lib/huf.h:141-143,161-167,209-211,299-304 (lib/huf_decompress.c:118-192, :377-404, :439-452): the forms without a
+// workspace are the reference's wrappers around the forms with one; a DTable on the stack where the reference has one (HUF_CREATE_STATIC_DTABLEX1 with
+// HUF_TABLELOG_MAX - 1: descriptor 0x0100000B)
+extern "C" size_t FSEHIP_HUF_decompress4X1_DCtx(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize)
+{
+    return huf_x1_dctx_host(4, dctx, dst, dstSize, cSrc, cSrcSize);
+}
+extern "C" size_t FSEHIP_HUF_decompress4X1(void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize)
+{
+    std::vector<u32> dt(FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1), 0);
+    dt[0] = (u32)(FSEHIP_HUF_TABLELOG_MAX - 1) * 0x01000001u;
+    return huf_x1_dctx_host(4, dt.data(), dst, dstSize, cSrc, cSrcSize);
+}
+extern "C" size_t FSEHIP_HUF_decompress1X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize,
+                                                     void* workSpace, size_t wkspSize)
+{
+    (void)workSpace;
+    if (wkspSize < 4 * (16 + 64)) return FSEHIP_ERROR(tableLog_tooLarge);
+    return huf_x1_dctx_host(1, dctx, dst, dstSize, cSrc, cSrcSize);
+}
+extern "C" size_t FSEHIP_HUF_decompress1X1_DCtx(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize)
+{
+    return huf_x1_dctx_host(1, dctx, dst, dstSize, cSrc, cSrcSize);
+}
+extern "C" size_t FSEHIP_HUF_decompress1X1(void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize)
+{
+    std::vector<u32> dt(FSEHIP_HUF_DTABLE_SIZE_U32(FSEHIP_HUF_TABLELOG_MAX - 1), 0);
+    dt[0] = (u32)(FSEHIP_HUF_TABLELOG_MAX - 1) * 0x01000001u;
+    return huf_x1_dctx_host(1, dt.data(), dst, dstSize, cSrc, cSrcSize);
+}
+extern "C" size_t FSEHIP_HUF_readDTableX1_wksp(FSEHIP_HUF_DTable* DTable, const void* src, size_t srcSize, void* workSpace, size_t wkspSize)
+{
+    (void)workSpace;
+    if (wkspSize < 4 * (16 + 64)) return FSEHIP_ERROR(tableLog_tooLarge);
+    DevBuf dsrc, ddt;
+    HK(dsrc.alloc(srcSize));
+    HK(hipMemcpy(dsrc.p, src, srcSize, hipMemcpyHostToDevice));
+    return huf_read_x1_host(DTable, dsrc.p, srcSize, ddt);
+}
+extern "C" size_t FSEHIP_HUF_readDTableX1(FSEHIP_HUF_DTable* DTable, const void* src, size_t srcSize)
+{
+    u32 ws[FSEHIP_HUF_DECOMPRESS_WORKSPACE_SIZE / 4];
+    return FSEHIP_HUF_readDTableX1_wksp(DTable, src, srcSize, ws, sizeof(ws));
 }
 extern "C" size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)   // huf_compress.c:795-798
 {

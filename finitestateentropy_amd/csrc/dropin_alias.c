@@ -45,8 +45,17 @@ DROPIN size_t HUF_compress(void* dst, size_t cap, const void* src, size_t n) { r
 DROPIN size_t HUF_compress2(void* dst, size_t cap, const void* src, size_t n, unsigned msv, unsigned tl) { return FSEHIP_HUF_compress2(dst, cap, src, n, msv, tl); }
 DROPIN size_t HUF_compress4X_wksp(void* dst, size_t cap, const void* src, size_t n, unsigned msv, unsigned tl, void* ws, size_t wsn) { return FSEHIP_HUF_compress4X_wksp(dst, cap, src, n, msv, tl, ws, wsn); }
 DROPIN size_t HUF_compress1X_wksp(void* dst, size_t cap, const void* src, size_t n, unsigned msv, unsigned tl, void* ws, size_t wsn) { return FSEHIP_HUF_compress1X_wksp(dst, cap, src, n, msv, tl, ws, wsn); }
+DROPIN size_t HUF_compress1X(void* dst, size_t cap, const void* src, size_t n, unsigned msv, unsigned tl) { return FSEHIP_HUF_compress1X(dst, cap, src, n, msv, tl); }
 DROPIN size_t HUF_decompress(void* dst, size_t orig, const void* src, size_t n) { return FSEHIP_HUF_decompress(dst, orig, src, n); }
 DROPIN size_t HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dn, const void* src, size_t n, void* ws, size_t wsn) { return FSEHIP_HUF_decompress4X1_DCtx_wksp(dctx, dst, dn, src, n, ws, wsn); }
+/* the header-reading single-symbol decoders, lib/huf.h:141-143,161-163,209-211,299-304 */
+DROPIN size_t HUF_readDTableX1(FSEHIP_HUF_DTable* dt, const void* src, size_t n) { return FSEHIP_HUF_readDTableX1(dt, src, n); }
+DROPIN size_t HUF_readDTableX1_wksp(FSEHIP_HUF_DTable* dt, const void* src, size_t n, void* ws, size_t wsn) { return FSEHIP_HUF_readDTableX1_wksp(dt, src, n, ws, wsn); }
+DROPIN size_t HUF_decompress4X1(void* dst, size_t dn, const void* src, size_t n) { return FSEHIP_HUF_decompress4X1(dst, dn, src, n); }
+DROPIN size_t HUF_decompress4X1_DCtx(FSEHIP_HUF_DTable* dctx, void* dst, size_t dn, const void* src, size_t n) { return FSEHIP_HUF_decompress4X1_DCtx(dctx, dst, dn, src, n); }
+DROPIN size_t HUF_decompress1X1(void* dst, size_t dn, const void* src, size_t n) { return FSEHIP_HUF_decompress1X1(dst, dn, src, n); }
+DROPIN size_t HUF_decompress1X1_DCtx(FSEHIP_HUF_DTable* dctx, void* dst, size_t dn, const void* src, size_t n) { return FSEHIP_HUF_decompress1X1_DCtx(dctx, dst, dn, src, n); }
+DROPIN size_t HUF_decompress1X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dn, const void* src, size_t n, void* ws, size_t wsn) { return FSEHIP_HUF_decompress1X1_DCtx_wksp(dctx, dst, dn, src, n, ws, wsn); }
 DROPIN size_t HUF_compress1X_usingCTable(void* dst, size_t cap, const void* src, size_t n, const FSEHIP_HUF_CElt* ct) { return FSEHIP_HUF_compress1X_usingCTable(dst, cap, src, n, ct); }
 DROPIN size_t HUF_compress4X_usingCTable(void* dst, size_t cap, const void* src, size_t n, const FSEHIP_HUF_CElt* ct) { return FSEHIP_HUF_compress4X_usingCTable(dst, cap, src, n, ct); }
 DROPIN size_t HUF_decompress4X_usingDTable(void* dst, size_t cap, const void* src, size_t n, const FSEHIP_HUF_DTable* dt) { return FSEHIP_HUF_decompress4X_usingDTable(dst, cap, src, n, dt); }

@@ -151,8 +151,19 @@ FSEHIP_API size_t FSEHIP_HUF_decompress(void* dst, size_t originalSize, const vo
  * the 1X form writes a single stream without jump table) and lib/huf.h:164 (dctx: a DTable whose descriptor holds the table-log limit, as
  * HUF_CREATE_STATIC_DTABLEX1 leaves it; it receives the table read from the block's header, lib/huf_decompress.c:417-431) */
 FSEHIP_API size_t FSEHIP_HUF_compress4X_wksp(void* dst, size_t dstCapacity, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_HUF_compress1X(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog);   /* lib/huf.h:288: HUF_compress1X_wksp with a workspace of its own */
 FSEHIP_API size_t FSEHIP_HUF_compress1X_wksp(void* dst, size_t dstSize, const void* src, size_t srcSize, unsigned maxSymbolValue, unsigned tableLog, void* workSpace, size_t wkspSize);
 FSEHIP_API size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize, void* workSpace, size_t wkspSize);
+/* the rest of the single-symbol family (lib/huf.h:141-143 HUF_decompress4X1, :161-163 its DCtx form, :209-211 HUF_readDTableX1[_wksp], :299-304 the 1X1
+ * forms; lib/huf_decompress.c:118-192, :377-404, :439-452): the header's table into the caller's DTable / DCtx, then the four streams (4X1) or the single
+ * stream (1X1) behind it.  Workspaces are checked as the reference checks them ((16 + 64) words, tableLog_tooLarge) and then left alone. */
+FSEHIP_API size_t FSEHIP_HUF_readDTableX1(FSEHIP_HUF_DTable* DTable, const void* src, size_t srcSize);
+FSEHIP_API size_t FSEHIP_HUF_readDTableX1_wksp(FSEHIP_HUF_DTable* DTable, const void* src, size_t srcSize, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_HUF_decompress4X1(void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize);
+FSEHIP_API size_t FSEHIP_HUF_decompress4X1_DCtx(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize);
+FSEHIP_API size_t FSEHIP_HUF_decompress1X1(void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize);
+FSEHIP_API size_t FSEHIP_HUF_decompress1X1_DCtx(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize);
+FSEHIP_API size_t FSEHIP_HUF_decompress1X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize, void* workSpace, size_t wkspSize);
 
 /* =================================================================================================
  *  Layer 2 -- batched, DEVICE pointers.  Block b lives at base + b*stride.  `d_sizes` may be
@@ -483,9 +494,10 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define FSE_decompress_wksp FSEHIP_FSE_decompress_wksp
 #define HUF_compress4X_wksp FSEHIP_HUF_compress4X_wksp
 #define HUF_compress1X_wksp FSEHIP_HUF_compress1X_wksp
+#define HUF_compress1X FSEHIP_HUF_compress1X
 #define HUF_decompress4X1_DCtx_wksp FSEHIP_HUF_decompress4X1_DCtx_wksp
 #endif
-#ifdef FSEHIP_DROPIN_GLUE_NAMES      /* separate switch: the table glue (a program that wants the reference's own builders beside the device's hot loops leaves it off) */
+#ifdef FSEHIP_DROPIN_GLUE_NAMES      /* separate switch: the table glue and the header-reading single-symbol decoders (a program that wants the reference's own builders beside the device's hot loops leaves it off) */
 #define FSE_optimalTableLog FSEHIP_FSE_optimalTableLog
 #define FSE_normalizeCount FSEHIP_FSE_normalizeCount
 #define FSE_NCountWriteBound FSEHIP_FSE_NCountWriteBound
@@ -494,6 +506,13 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define FSE_buildCTable FSEHIP_FSE_buildCTable
 #define FSE_buildCTable_wksp FSEHIP_FSE_buildCTable_wksp
 #define FSE_buildDTable FSEHIP_FSE_buildDTable
+#define HUF_readDTableX1 FSEHIP_HUF_readDTableX1
+#define HUF_readDTableX1_wksp FSEHIP_HUF_readDTableX1_wksp
+#define HUF_decompress4X1 FSEHIP_HUF_decompress4X1
+#define HUF_decompress4X1_DCtx FSEHIP_HUF_decompress4X1_DCtx
+#define HUF_decompress1X1 FSEHIP_HUF_decompress1X1
+#define HUF_decompress1X1_DCtx FSEHIP_HUF_decompress1X1_DCtx
+#define HUF_decompress1X1_DCtx_wksp FSEHIP_HUF_decompress1X1_DCtx_wksp
 #endif
 #ifdef FSEHIP_DROPIN_U16_NAMES       /* separate switch: programs/fuzzer.c declares FSE_countU16 with another (stale) prototype */
 #define FSE_countU16 FSEHIP_FSE_countU16

@@ -205,3 +205,64 @@ def test_huf_decompress4x1_dctx_wksp(hip, ref, checker):
                 part = np.ascontiguousarray(comp[:cut])
                 (rg, _), (rr, _) = _both(hip, ref, "HUF_decompress4X1_DCtx_wksp", dctx, out, SZ(src.size), part, SZ(cut), ws, SZ(wsz))
                 assert rg == rr, (src.size, tl, cut, wsz, rg, rr)
+
+
+def test_huf_single_symbol_family_under_the_reference_names(hip, ref, checker):
+    """HUF_readDTableX1[_wksp], HUF_decompress4X1[_DCtx], HUF_decompress1X1[_DCtx[_wksp]] (lib/huf.h:141-143,161-163,209-211,299-304): the same
+    arguments into the device call and the reference -- results, regenerated bytes and the table left in the caller's DTable / DCtx; whole,
+    truncated and damaged blocks; table-log limits below the block's table; workspaces one byte short"""
+    ws = np.zeros(512, np.uint32)
+    rng = np.random.default_rng(9)
+    checked = 0
+    for src in _blocks(checker):
+        for tl in (11, 8):
+            for streams in (4, 1):
+                comp = np.zeros(src.size + src.size // 2 + 600, np.uint8)
+                (r, ag), (rr, ar) = _both(hip, ref, "HUF_compress2" if streams == 4 else "HUF_compress1X", comp, SZ(comp.size), src, SZ(src.size), U(255), U(tl))
+                assert r == rr and (r >= (1 << 63) or (ag[0][:r] == ar[0][:r]).all()), (streams, src.size, tl, r, rr)
+                comp = ar[0]
+                if r <= 1 or r >= (1 << 63):
+                    continue
+                comp = np.ascontiguousarray(comp[:r])
+                fam = "4X1" if streams == 4 else "1X1"
+                variants = [(comp, r)] + [(np.ascontiguousarray(comp[:cut]), cut) for cut in (r - 1, r // 2, 3)]
+                hit = comp.copy(); hit[int(rng.integers(0, r))] ^= 1 << int(rng.integers(0, 8))
+                variants.append((hit, r))
+                for part, n in variants:
+                    out = np.zeros(src.size + 8, np.uint8)
+                    (rg, ag), (rr, ar) = _both(hip, ref, "HUF_decompress" + fam, out, SZ(src.size), part, SZ(n))
+                    assert rg == rr, (fam, src.size, tl, n, rg, rr)
+                    if rg < (1 << 64) - 9:
+                        assert (ag[0][:rg] == ar[0][:rg]).all(), (fam, src.size, tl, n)
+                        checked += 1
+                    for max_tl in (12, 9, 6):
+                        dctx = np.zeros(1 + (1 << 11), np.uint32)
+                        dctx[0] = (max_tl - 1) * 0x01000001
+                        out = np.zeros(src.size + 8, np.uint8)
+                        (rg, ag), (rr, ar) = _both(hip, ref, "HUF_decompress%s_DCtx" % fam, dctx, out, SZ(src.size), part, SZ(n))
+                        assert rg == rr, (fam, "DCtx", src.size, tl, max_tl, n, rg, rr)
+                        if rg < (1 << 64) - 9:
+                            htl = (int(ar[0][0]) >> 16) & 0xFF
+                            assert (ag[1][:rg] == ar[1][:rg]).all() and (ag[0][:1 + (1 << htl) // 2] == ar[0][:1 + (1 << htl) // 2]).all()
+                    if streams == 1:
+                        for wsz in (2048, 320, 319):
+                            dctx = np.zeros(1 + (1 << 11), np.uint32)
+                            dctx[0] = 11 * 0x01000001
+                            out = np.zeros(src.size + 8, np.uint8)
+                            (rg, _), (rr, _) = _both(hip, ref, "HUF_decompress1X1_DCtx_wksp", dctx, out, SZ(src.size), part, SZ(n), ws, SZ(wsz))
+                            assert rg == rr, ("1X1_DCtx_wksp", src.size, tl, n, wsz, rg, rr)
+                    # the table alone
+                    for max_tl in (12, 10, 7):
+                        dt = np.zeros(1 + (1 << 11), np.uint32)
+                        dt[0] = (max_tl - 1) * 0x01000001
+                        (rg, ag), (rr, ar) = _both(hip, ref, "HUF_readDTableX1", dt, part, SZ(n))
+                        assert rg == rr, ("readDTableX1", src.size, tl, max_tl, n, rg, rr)
+                        if rg < (1 << 64) - 9:
+                            htl = (int(ar[0][0]) >> 16) & 0xFF
+                            assert (ag[0][:1 + (1 << htl) // 2] == ar[0][:1 + (1 << htl) // 2]).all(), ("readDTableX1", src.size, tl, max_tl)
+                    for wsz in (320, 319):
+                        dt = np.zeros(1 + (1 << 11), np.uint32)
+                        dt[0] = 11 * 0x01000001
+                        (rg, _), (rr, _) = _both(hip, ref, "HUF_readDTableX1_wksp", dt, part, SZ(n), ws, SZ(wsz))
+                        assert rg == rr, ("readDTableX1_wksp", wsz, rg, rr)
+    assert checked > 20
