@@ -666,6 +666,30 @@ extern "C" int FSEHIP_HUF_buildCTable_batch(FSEHIP_HUF_CElt* d_ctables, size_t c
     return 0;
 }
 
+// ---- the Huff0 table glue on counters / tables the caller supplies (fsehip.h "Table glue, step by step"): HUF_buildCTable and HUF_writeCTable
+extern "C" int FSEHIP_HUF_buildCTable_fromCount_batch(FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32, const unsigned* d_counts, size_t countStride,
+                                                      const unsigned* d_maxSymbolValues, unsigned maxNbBits, size_t nBlocks, size_t* d_results, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    if (!d_ctables || !d_counts || !d_maxSymbolValues || !d_results || ctableStrideU32 < 256 || countStride != 256) return (int)hipErrorInvalidValue;
+    HufCPrepArgs c;
+    c.counts = d_counts; c.maxSVs = d_maxSymbolValues; c.histResults = nullptr; c.src = mkview(nullptr, 0, nullptr, 0);
+    c.dst = nullptr; c.dstStride = 0; c.dstCapacity = 0; c.maxSVReq = 255; c.huffLogReq = maxNbBits;
+    c.ctables = d_ctables; c.ctStrideU32 = ctableStrideU32; c.meta = nullptr; c.results = d_results; c.nBlocks = nBlocks;
+    return (int)launch_huf_cprep_glue(c, 1, (hipStream_t)stream);
+}
+extern "C" int FSEHIP_HUF_writeCTable_batch(void* d_headers, size_t headerStride, size_t headerCapacity, const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
+                                            const unsigned* d_maxSymbolValues, unsigned huffLog, size_t nBlocks, size_t* d_results, void* stream)
+{
+    if (nBlocks == 0) return 0;
+    if (!d_headers || !d_ctables || !d_maxSymbolValues || !d_results || ctableStrideU32 < 256 || (ctableStrideU32 & 3) || headerCapacity > headerStride) return (int)hipErrorInvalidValue;
+    HufCPrepArgs c;
+    c.counts = nullptr; c.maxSVs = d_maxSymbolValues; c.histResults = nullptr; c.src = mkview(nullptr, 0, nullptr, 0);
+    c.dst = (u8*)d_headers; c.dstStride = headerStride; c.dstCapacity = headerCapacity; c.maxSVReq = 255; c.huffLogReq = huffLog;
+    c.ctables = (u32*)d_ctables; c.ctStrideU32 = ctableStrideU32; c.meta = nullptr; c.results = d_results; c.nBlocks = nBlocks;
+    return (int)launch_huf_cprep_glue(c, 2, (hipStream_t)stream);
+}
+
 static const size_t HUF_RDT_PER_BLOCK = sizeof(HufMeta) + HUF_DCLS_COUNT * sizeof(u32);
 extern "C" size_t FSEHIP_HUF_readDTableX1_batch_workspaceSize(size_t nBlocks)
 {
@@ -1520,6 +1544,43 @@ extern "C" size_t FSEHIP_HUF_readDTableX1(FSEHIP_HUF_DTable* DTable, const void*
 {
     u32 ws[FSEHIP_HUF_DECOMPRESS_WORKSPACE_SIZE / 4];
     return FSEHIP_HUF_readDTableX1_wksp(DTable, src, srcSize, ws, sizeof(ws));
+}
+// lib/huf.h:204-218 (lib/huf_compress.c:334-421): HUF_buildCTable[_wksp] on the caller's counters, HUF_writeCTable (lib/huf.h:205, lib/huf_compress.c:113-148) on the
+// caller's table -- batches of one on the phases of k_huf_cprep (huf_prep.hip).  The workspace is checked as the reference checks it (:345-348) and left alone.
+extern "C" size_t FSEHIP_HUF_buildCTable(FSEHIP_HUF_CElt* tree, const unsigned* count, unsigned maxSymbolValue, unsigned maxNbBits)
+{
+    if (maxSymbolValue > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);       // :350
+    DevBuf dc, dm, dct, dr;
+    HK(dc.alloc(1024)); HK(dm.alloc(4)); HK(dct.alloc(1024)); HK(dr.alloc(8));
+    HK(hipMemset(dc.p, 0, 1024));
+    HK(hipMemcpy(dc.p, count, 4 * ((size_t)maxSymbolValue + 1), hipMemcpyHostToDevice));
+    HK(hipMemcpy(dm.p, &maxSymbolValue, 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HUF_buildCTable_fromCount_batch((u32*)dct.p, 256, (const unsigned*)dc.p, 256, (const unsigned*)dm.p, maxNbBits, 1, (size_t*)dr.p, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r)) HK(hipMemcpy(tree, dct.p, 4 * ((size_t)maxSymbolValue + 1), hipMemcpyDeviceToHost));
+    return r;
+}
+extern "C" size_t FSEHIP_HUF_buildCTable_wksp(FSEHIP_HUF_CElt* tree, const unsigned* count, unsigned maxSymbolValue, unsigned maxNbBits, void* workSpace, size_t wkspSize)
+{
+    if ((size_t)workSpace & 3) return FSEHIP_ERROR(GENERIC);
+    if (wkspSize < 4352) return FSEHIP_ERROR(workSpace_tooSmall);                 // sizeof(HUF_buildCTable_wksp_tables): 512 nodes of 8 bytes + 32 rank positions of 8
+    return FSEHIP_HUF_buildCTable(tree, count, maxSymbolValue, maxNbBits);
+}
+extern "C" size_t FSEHIP_HUF_writeCTable(void* dst, size_t maxDstSize, const FSEHIP_HUF_CElt* CTable, unsigned maxSymbolValue, unsigned huffLog)
+{
+    if (maxSymbolValue > 255) return FSEHIP_ERROR(maxSymbolValue_tooLarge);       // :123
+    const size_t cap = maxDstSize < 512 ? maxDstSize : 512;                       // (no header is longer than 1 + 255 bytes)
+    DevBuf dh, dct, dm, dr;
+    HK(dh.alloc(512)); HK(dct.alloc(1024)); HK(dm.alloc(4)); HK(dr.alloc(8));
+    HK(hipMemset(dct.p, 0, 1024));
+    HK(hipMemcpy(dct.p, CTable, 4 * ((size_t)maxSymbolValue + 1), hipMemcpyHostToDevice));
+    HK(hipMemcpy(dm.p, &maxSymbolValue, 4, hipMemcpyHostToDevice));
+    HK((hipError_t)FSEHIP_HUF_writeCTable_batch(dh.p, 512, cap, (const u32*)dct.p, 256, (const unsigned*)dm.p, huffLog, 1, (size_t*)dr.p, nullptr));
+    size_t r = 0;
+    HK(hipMemcpy(&r, dr.p, 8, hipMemcpyDeviceToHost));
+    if (!FSEHIP_isError(r) && r > 0) HK(hipMemcpy(dst, dh.p, r, hipMemcpyDeviceToHost));
+    return r;
 }
 extern "C" size_t FSEHIP_HUF_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)   // huf_compress.c:795-798
 {

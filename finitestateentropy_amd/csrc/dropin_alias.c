@@ -48,6 +48,10 @@ DROPIN size_t HUF_compress1X_wksp(void* dst, size_t cap, const void* src, size_t
 DROPIN size_t HUF_compress1X(void* dst, size_t cap, const void* src, size_t n, unsigned msv, unsigned tl) { return FSEHIP_HUF_compress1X(dst, cap, src, n, msv, tl); }
 DROPIN size_t HUF_decompress(void* dst, size_t orig, const void* src, size_t n) { return FSEHIP_HUF_decompress(dst, orig, src, n); }
 DROPIN size_t HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, void* dst, size_t dn, const void* src, size_t n, void* ws, size_t wsn) { return FSEHIP_HUF_decompress4X1_DCtx_wksp(dctx, dst, dn, src, n, ws, wsn); }
+/* the Huff0 table calls on the caller's statistics, lib/huf.h:204-218 */
+DROPIN size_t HUF_buildCTable(FSEHIP_HUF_CElt* t, const unsigned* count, unsigned msv, unsigned maxNb) { return FSEHIP_HUF_buildCTable(t, count, msv, maxNb); }
+DROPIN size_t HUF_buildCTable_wksp(FSEHIP_HUF_CElt* t, const unsigned* count, unsigned msv, unsigned maxNb, void* ws, size_t wsn) { return FSEHIP_HUF_buildCTable_wksp(t, count, msv, maxNb, ws, wsn); }
+DROPIN size_t HUF_writeCTable(void* dst, size_t cap, const FSEHIP_HUF_CElt* t, unsigned msv, unsigned huffLog) { return FSEHIP_HUF_writeCTable(dst, cap, t, msv, huffLog); }
 /* the header-reading single-symbol decoders, lib/huf.h:141-143,161-163,209-211,299-304 */
 DROPIN size_t HUF_readDTableX1(FSEHIP_HUF_DTable* dt, const void* src, size_t n) { return FSEHIP_HUF_readDTableX1(dt, src, n); }
 DROPIN size_t HUF_readDTableX1_wksp(FSEHIP_HUF_DTable* dt, const void* src, size_t n, void* ws, size_t wsn) { return FSEHIP_HUF_readDTableX1_wksp(dt, src, n, ws, wsn); }

@@ -275,7 +275,13 @@ DEV void hp_repair_lengths(u8* nb, const u32* keys, u16* last, int n, int debt, 
 
 enum { SC_DEBT = SC_RESULT_LO, SC_NLAST = SC_RESULT_HI };                 // (the result words are free until phase E)
 
-template <int G_>
+// MODE 0: the one-shot path (counts from k_hist, everything between the histogram and the hot loop).
+// MODE 1: HUF_buildCTable on the CALLER's counters (lib/huf_compress.c:334-409): phases A-E1 without the early outs of HUF_compress_internal and with
+//         the caller's length limit as it is (no HUF_optimalTableLog); results[b] = the table log, as the reference returns it.
+// MODE 2: HUF_writeCTable on the CALLER's table (lib/huf_compress.c:113-148): the code lengths come from a.ctables, phases E1 (weights) - G;
+//         results[b] = the header size.
+enum { HPM_ONESHOT = 0, HPM_BUILD = 1, HPM_WRITE = 2 };
+template <int G_, int MODE = HPM_ONESHOT>
 __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
 {
     constexpr u32 HP_G = G_, HP_GL = 64 / G_;      // blocks per wave; lanes per block when all blocks are worked on at once
@@ -289,7 +295,9 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
 #pragma unroll
     for (u32 g = 0; g < HP_G; ++g) {
         const size_t b = b0 + g < a.nBlocks ? b0 + g : a.nBlocks - 1;
-        cvAll[g] = ((const uint4*)(a.counts + b * 256))[lane]; topAll[g] = a.histResults[b]; msvAll[g] = a.maxSVs[b];
+        if (MODE == HPM_WRITE) cvAll[g] = ((const uint4*)(a.ctables + b * a.ctStrideU32))[lane];     // the caller's HUF_CElt entries of symbols 4*lane .. 4*lane+3
+        else cvAll[g] = ((const uint4*)(a.counts + b * 256))[lane];
+        topAll[g] = MODE == HPM_ONESHOT ? a.histResults[b] : 0; msvAll[g] = a.maxSVs[b];
     }
 #pragma unroll
     for (u32 g = 0; g < HP_G; ++g) {
@@ -297,29 +305,65 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         u32* const sc = (u32*)(slot + HP_SCAL);
         const size_t b = b0 + g;
         if (b >= a.nBlocks) { if (lane == 0) sc[SC_STATE] = 0; continue; }  // uniform
-        const size_t n = view_size(a.src, b);
-        size_t result = 0; bool go = false;
-        const size_t top = topAll[g];
-        if (!n || !a.dstCapacity) result = 0;                              // huf_compress.c:656-657
-        else if (n > FSEHIP_HUF_BLOCKSIZE_MAX) result = FERR(srcSize_wrong);
-        else if (is_err(top)) result = top;
-        else if (top == n) { if (lane == 0) a.dst[b * a.dstStride] = view_ptr(a.src, b)[0]; result = 1; }   // rle (:673)
-        else if (top <= (n >> 7) + 4) result = 0;                          // not compressible enough (:674)
-        else go = true;
-        if (!go) {
-            if (lane == 0) { sc[SC_STATE] = 0; HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0; a.meta[b] = m; a.results[b] = result; }
+        const size_t n = MODE == HPM_ONESHOT ? view_size(a.src, b) : 0;
+        const u32 maxSV = msvAll[g];
+        if (MODE == HPM_WRITE) {
+            // HUF_writeCTable: the lengths of the caller's table instead of a tree; a length above huffLog indexes beyond the reference's
+            // bitsToWeight[] (lib/huf_compress.c:127-130, symbols below maxSymbolValue only) and a huffLog above 12 overruns it: refused
+            const uint4 cv = cvAll[g];
+            const u32 e[4] = { cv.x, cv.y, cv.z, cv.w };
+            const u32 huffLog = a.huffLogReq;
+            size_t result = 0;
+            u32 w4 = 0; bool over = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const u32 sy = 4 * lane + i, nbv = sy <= maxSV ? (e[i] >> 16) & 0xFFu : 0u; over |= sy < maxSV && nbv > huffLog; w4 |= nbv << (8 * i); }
+            if (maxSV > 255u) result = FERR(maxSymbolValue_tooLarge);      // :123
+            else if (huffLog > HUF_MAX_TL || __any(over)) result = FERR(GENERIC);
+            if (result) { if (lane == 0) { sc[SC_STATE] = 0; a.results[b] = result; } continue; }      // uniform
+            if (maxSV < 255u && lane == (maxSV >> 2)) w4 &= (0x100u << (8 * (maxSV & 3u))) - 1u;    // (nothing beyond maxSV; the last symbol's length is only used to be left out)
+            ((u32*)(slot + HP_NBSYM))[lane] = w4;
+            if (lane == 0) { sc[SC_STATE] = 1; sc[SC_MAXSV] = maxSV; sc[SC_LOG] = huffLog; sc[SC_LEAVES] = 0; }
             continue;
         }
-        const u32 maxSV = msvAll[g];
-        const u32 huffLog = wg_optimal_tablelog(a.huffLogReq ? a.huffLogReq : HUF_DEF_TL, n, maxSV, 1);   // :691
+        size_t result = 0; bool go = false;
+        if (MODE == HPM_ONESHOT) {
+            const size_t top = topAll[g];
+            if (!n || !a.dstCapacity) result = 0;                              // huf_compress.c:656-657
+            else if (n > FSEHIP_HUF_BLOCKSIZE_MAX) result = FERR(srcSize_wrong);
+            else if (is_err(top)) result = top;
+            else if (top == n) { if (lane == 0) a.dst[b * a.dstStride] = view_ptr(a.src, b)[0]; result = 1; }   // rle (:673)
+            else if (top <= (n >> 7) + 4) result = 0;                          // not compressible enough (:674)
+            else go = true;
+        } else go = true;
         const uint4 cv = cvAll[g];
         u32 k[4] = { cv.x, cv.y, cv.z, cv.w };
+        u32 huffLog;
+        if (MODE == HPM_BUILD) {
+            // HUF_buildCTable_wksp: the caller's limit as it is (0 = default, lib/huf_compress.c:349); the sort keys hold 23 bits of count
+            bool big = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const u32 s = 4 * lane + i; k[i] = (s <= maxSV && k[i]) ? (k[i] << 9) | (1u << 8) | (255u - s) : 0u; }
+            for (int i = 0; i < 4; ++i) big |= 4 * lane + i <= maxSV && k[i] >= (1u << 23);
+            huffLog = a.huffLogReq ? a.huffLogReq : HUF_DEF_TL;
+            if (maxSV > 255u) { result = FERR(maxSymbolValue_tooLarge); go = false; }   // :350
+            else if (__any(big)) { result = FERR(GENERIC); go = false; }
+        } else huffLog = go ? wg_optimal_tablelog(a.huffLogReq ? a.huffLogReq : HUF_DEF_TL, n, maxSV, 1) : 0;   // :691
         u32 present = 0;
+        if (go) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) present += k[i] != 0;
-        present = wg_sum<64>(present);
+            for (int i = 0; i < 4; ++i) { const u32 s = 4 * lane + i; k[i] = (s <= maxSV && k[i]) ? (k[i] << 9) | (1u << 8) | (255u - s) : 0u; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) present += k[i] != 0;
+            present = wg_sum<64>(present);
+            // no symbol at all: the reference walks off the front of its node table (:357); more symbols than codes of the limit's length: its repair never ends
+            if (MODE == HPM_BUILD && (present == 0 || (huffLog <= HUF_MAX_TL && present > (1u << huffLog)))) { result = FERR(GENERIC); go = false; }
+        }
+        if (!go) {
+            if (lane == 0) {
+                sc[SC_STATE] = 0; a.results[b] = result;
+                if (MODE == HPM_ONESHOT) { HufMeta m; m.state = 0; m.hdrSize = 0; m.tableLog = 0; m.maxSV = 0; a.meta[b] = m; }
+            }
+            continue;
+        }
         if (maxSV < 64) {                                                  // uniform: one key per lane is enough
             // symbols 0..63 sit four per lane in lanes 0..15: bring symbol `lane` to lane `lane`
             u32 one[1];
@@ -339,21 +383,26 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
     HPT_MARK
 
     // ---- phase B (serial, lane g on block g): the tree
-    if (lane < HP_G) {
+    if (MODE != HPM_WRITE && lane < HP_G) {
         u8* const slot = hpLds + lane * HP_SLOT;
         const u32* const sc = (const u32*)(slot + HP_SCAL);
-        if (sc[SC_STATE]) hp_merge((const u32*)(slot + HP_KEYS), (u32*)(slot + HP_ICNT), slot + HP_PAR, sc[SC_LEAVES]);
+        if (sc[SC_STATE] && (MODE == HPM_ONESHOT || sc[SC_LEAVES] >= 2)) hp_merge((const u32*)(slot + HP_KEYS), (u32*)(slot + HP_ICNT), slot + HP_PAR, sc[SC_LEAVES]);
     }
     __syncthreads();
     HPT_MARK
 
     // ---- phase C (wide): leaf depths by chasing the parent links; when the tree is too high, the cut to the limit, its debt
     //      and the class boundaries for the repair
+    if (MODE != HPM_WRITE)
     for (u32 g = 0; g < HP_G; ++g) {
         u8* const slot = hpLds + g * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
         if (!sc[SC_STATE]) continue;                                       // uniform
         const u32 L = sc[SC_LEAVES], root = L - 2, M = sc[SC_LOG];
+        if (MODE == HPM_BUILD && L < 2) {                                  // uniform: one symbol in use -- the reference's walk gives it one bit (lib/huf_compress.c:357-378 with nonNullRank 0)
+            if (lane == 0) { slot[HP_NBRANK] = 1; sc[SC_LOG] = 1; }
+            continue;
+        }
         const u8* const par = slot + HP_PAR;
         u32 p[4], d[4];
 #pragma unroll
@@ -369,6 +418,10 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         for (int i = 0; i < 4; ++i) { const u32 r = lane + 64u * i; if (r < L) deepest = d[i] > deepest ? d[i] : deepest; }
         const u32 largest = wg_max<64>(deepest);                           // = depth of the last leaf
         int debt = 0;
+        if (MODE == HPM_BUILD && M > HUF_MAX_TL && largest > HUF_MAX_TL) { // uniform: HUF_setMaxHeight returns min(largest, limit), and what exceeds HUF_TABLELOG_MAX is refused (:385)
+            if (lane == 0) { sc[SC_STATE] = 0; a.results[b0 + g] = FERR(GENERIC); }
+            continue;
+        }
         if (largest > M) {                                                 // uniform
             // classes of equal length are contiguous runs of ranks in ascending length: class counts give the boundaries
             Pk cnt = { 0, 0 };
@@ -397,7 +450,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
     HPT_MARK
 
     // ---- phase D (serial): repair of the cut lengths
-    if (lane < HP_G) {
+    if (MODE != HPM_WRITE && lane < HP_G) {
         u8* const slot = hpLds + lane * HP_SLOT;
         u32* const sc = (u32*)(slot + HP_SCAL);
         if (sc[SC_STATE] && (sc[SC_LOG] & 0x100u)) {
@@ -419,13 +472,15 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         const size_t b = b0 + g;
         const u32 L = sc[SC_LEAVES], maxSV = sc[SC_MAXSV], huffLog = sc[SC_LOG];
         u8* const nbSym = slot + HP_NBSYM;
-        ((u32*)nbSym)[lane] = 0;
+        if (MODE != HPM_WRITE) ((u32*)nbSym)[lane] = 0;                    // (HUF_writeCTable: the caller's lengths are there since phase A)
         {   u32* const img = (u32*)(slot + HP_HDR); for (u32 i = lane; i < 72; i += 64) img[i] = 0; }
         __syncthreads();
+        if (MODE != HPM_WRITE) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32 r = lane + 64u * i;
             if (r < L) nbSym[255u - (((const u32*)(slot + HP_KEYS))[r] & 255u)] = slot[HP_NBRANK + r];
+        }
         }
         __syncthreads();
         const u32 w4 = ((const u32*)nbSym)[lane];                          // lengths of symbols 4*lane .. 4*lane+3
@@ -443,11 +498,13 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
                 carry = (carry + pk_get(tot, len)) >> 1;
             }
         }
-        {   u32 e[4];
+        if (MODE != HPM_WRITE) {
+            u32 e[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] = 4 * lane + i <= maxSV ? ((val[i] & 0xFFFFu) | (nb[i] << 16)) : 0u;   // zeroed beyond maxSV (:697-699)
             ((uint4*)(a.ctables + b * a.ctStrideU32))[lane] = make_uint4(e[0], e[1], e[2], e[3]);
         }
+        if (MODE == HPM_BUILD) { if (lane == 0) a.results[b] = huffLog; continue; }          // HUF_buildCTable is done: it returns the table log (:408)
         // weights (symbols 0 .. maxSV-1; the last one is implied): weight v has the symbols of length huffLog + 1 - v, less the
         // last symbol; statistics for the small FSE coder (huf_compress.c:63-103)
         const u32 lastNb = (u32)nbSym[maxSV];
@@ -471,6 +528,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
     }
     __syncthreads();
     HPT_MARK
+    if (MODE == HPM_BUILD) return;
 
     // ---- phase E2 (all blocks of the wave at once, 64 / G lanes per block): table log, counters and NCount header of the weights
     {   const u32 g = lane / HP_GL, sub = lane % HP_GL;
@@ -554,7 +612,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
         const u32* const sc = (const u32*)(slot + HP_SCAL);
         if (!sc[SC_STATE]) continue;                                       // uniform
         const size_t b = b0 + g;
-        const size_t n = view_size(a.src, b);
+        const size_t n = MODE == HPM_ONESHOT ? view_size(a.src, b) : 0;
         const u32 maxSV = sc[SC_MAXSV], huffLog = sc[SC_LOG], hs = sc[SC_HDR];
         const size_t err = (size_t)sc[SC_RESULT_LO] | ((size_t)sc[SC_RESULT_HI] << 32);
         u8* const dst = a.dst + b * a.dstStride;
@@ -578,6 +636,7 @@ __global__ __launch_bounds__(64) void k_huf_cprep(HufCPrepArgs a)
             if (lane == 0) dst[0] = (u8)(128 + (maxSV - 1));
             h = (maxSV + 1) / 2 + 1;
         }
+        if (MODE == HPM_WRITE) { if (lane == 0) a.results[b] = h ? h : result; continue; }   // HUF_writeCTable returns the header size
         if (h) {
             if (h + 12ul >= n) result = 0;                                 // :715
             else { m.state = 1; m.hdrSize = (u32)h; m.tableLog = huffLog; m.maxSV = maxSV; }
@@ -868,6 +927,16 @@ hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* /*unused
     probe_before(PK_HUF_CPREP, s);
     hipLaunchKernelGGL(k_huf_cprep<HP_G_COMPRESS>, dim3((unsigned)((a.nBlocks + HP_G_COMPRESS - 1) / HP_G_COMPRESS)), dim3(64), HP_G_COMPRESS * HP_SLOT, s, a);
     probe_after(PK_HUF_CPREP, s);
+    return hipGetLastError();
+}
+// HUF_buildCTable on the caller's counters (mode 1: a.counts, a.maxSVs, a.huffLogReq in; a.ctables, a.results out) / HUF_writeCTable on the caller's
+// tables (mode 2: a.ctables, a.maxSVs, a.huffLogReq in; a.dst, a.results out)
+hipError_t launch_huf_cprep_glue(const HufCPrepArgs& a, int mode, hipStream_t s)
+{
+    if (a.nBlocks == 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.nBlocks + HP_G_COMPRESS - 1) / HP_G_COMPRESS));
+    if (mode == HPM_BUILD) hipLaunchKernelGGL((k_huf_cprep<HP_G_COMPRESS, HPM_BUILD>), grid, dim3(64), HP_G_COMPRESS * HP_SLOT, s, a);
+    else hipLaunchKernelGGL((k_huf_cprep<HP_G_COMPRESS, HPM_WRITE>), grid, dim3(64), HP_G_COMPRESS * HP_SLOT, s, a);
     return hipGetLastError();
 }
 hipError_t launch_huf_dprep(const HufDPrepArgs& a, hipStream_t s)

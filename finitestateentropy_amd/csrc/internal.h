@@ -191,6 +191,7 @@ struct HufCPrepArgs {            // glue g5-g7: lib/huf_compress.c:637-724 minus
     size_t nBlocks;
 };
 hipError_t launch_huf_cprep(const HufCPrepArgs& a, hipStream_t s, void* nodeScratch /* 4 KiB per block */);
+hipError_t launch_huf_cprep_glue(const HufCPrepArgs& a, int mode /* 1: HUF_buildCTable on a.counts, 2: HUF_writeCTable on a.ctables */, hipStream_t s);
 
 struct HufEncArgs {              // a4: HUF_compress4X_usingCTable (streams = 4) / 1X (streams = 1), one workgroup per block
     u8* dst; size_t dstStride; size_t dstCapacity;

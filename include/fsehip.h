@@ -157,6 +157,13 @@ FSEHIP_API size_t FSEHIP_HUF_decompress4X1_DCtx_wksp(FSEHIP_HUF_DTable* dctx, vo
 /* the rest of the single-symbol family (lib/huf.h:141-143 HUF_decompress4X1, :161-163 its DCtx form, :209-211 HUF_readDTableX1[_wksp], :299-304 the 1X1
  * forms; lib/huf_decompress.c:118-192, :377-404, :439-452): the header's table into the caller's DTable / DCtx, then the four streams (4X1) or the single
  * stream (1X1) behind it.  Workspaces are checked as the reference checks them ((16 + 64) words, tableLog_tooLarge) and then left alone. */
+/* lib/huf.h:204-218 (lib/huf_compress.c:113-148, :334-421): the compress-side table calls on the caller's own statistics -- HUF_buildCTable[_wksp] from
+ * count[0 .. maxSymbolValue] (returns the table log; tree[0 .. maxSymbolValue] receives the codes), HUF_writeCTable from such a table (returns the header
+ * size).  Refused where the reference is undefined: no symbol in use, a count of 2^23 or more (blocks are at most HUF_BLOCKSIZE_MAX = 128 KB), more
+ * symbols in use than codes of maxNbBits bits, a code length above huffLog or a huffLog above 12 in HUF_writeCTable -> GENERIC. */
+FSEHIP_API size_t FSEHIP_HUF_buildCTable(FSEHIP_HUF_CElt* tree, const unsigned* count, unsigned maxSymbolValue, unsigned maxNbBits);
+FSEHIP_API size_t FSEHIP_HUF_buildCTable_wksp(FSEHIP_HUF_CElt* tree, const unsigned* count, unsigned maxSymbolValue, unsigned maxNbBits, void* workSpace, size_t wkspSize);
+FSEHIP_API size_t FSEHIP_HUF_writeCTable(void* dst, size_t maxDstSize, const FSEHIP_HUF_CElt* CTable, unsigned maxSymbolValue, unsigned huffLog);
 FSEHIP_API size_t FSEHIP_HUF_readDTableX1(FSEHIP_HUF_DTable* DTable, const void* src, size_t srcSize);
 FSEHIP_API size_t FSEHIP_HUF_readDTableX1_wksp(FSEHIP_HUF_DTable* DTable, const void* src, size_t srcSize, void* workSpace, size_t wkspSize);
 FSEHIP_API size_t FSEHIP_HUF_decompress4X1(void* dst, size_t dstSize, const void* cSrc, size_t cSrcSize);
@@ -293,6 +300,13 @@ FSEHIP_API size_t FSEHIP_HUF_buildCTable_batch_workspaceSize(size_t nBlocks);
 FSEHIP_API int FSEHIP_HUF_buildCTable_batch(FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32, void* d_headers, size_t headerStride, size_t headerCapacity,
                                             size_t* d_results, const void* d_src, size_t srcStride, const size_t* d_sizes, size_t uniformSize,
                                             unsigned maxSymbolValue, unsigned tableLog, size_t nBlocks, void* d_workspace, size_t workspaceBytes, void* stream);
+/*   HUF_buildCTable_fromCount / HUF_writeCTable : the two halves of HUF_buildCTable_batch on the CALLER's statistics -- d_counts + b*256 holds
+ *                            count[0 .. d_maxSymbolValues[b]] (countStride must be 256), d_ctables + b*ctableStrideU32 the 256 HUF_CElt of table b
+ *                            (ctableStrideU32 >= 256, a multiple of 4); d_results[b] = the table log / the header size, or an error. */
+FSEHIP_API int FSEHIP_HUF_buildCTable_fromCount_batch(FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32, const unsigned* d_counts, size_t countStride,
+                                                      const unsigned* d_maxSymbolValues, unsigned maxNbBits, size_t nBlocks, size_t* d_results, void* stream);
+FSEHIP_API int FSEHIP_HUF_writeCTable_batch(void* d_headers, size_t headerStride, size_t headerCapacity, const FSEHIP_HUF_CElt* d_ctables, size_t ctableStrideU32,
+                                            const unsigned* d_maxSymbolValues, unsigned huffLog, size_t nBlocks, size_t* d_results, void* stream);
 FSEHIP_API size_t FSEHIP_HUF_readDTableX1_batch_workspaceSize(size_t nBlocks);
 FSEHIP_API int FSEHIP_HUF_readDTableX1_batch(FSEHIP_HUF_DTable* d_dtables, size_t dtableStrideU32, unsigned maxTableLog, size_t* d_results,
                                              const void* d_src, size_t srcStride, const size_t* d_srcSizes, size_t uniformSrcSize,
@@ -506,6 +520,9 @@ FSEHIP_API const char* FSEHIP_versionString(void);
 #define FSE_buildCTable FSEHIP_FSE_buildCTable
 #define FSE_buildCTable_wksp FSEHIP_FSE_buildCTable_wksp
 #define FSE_buildDTable FSEHIP_FSE_buildDTable
+#define HUF_buildCTable FSEHIP_HUF_buildCTable
+#define HUF_buildCTable_wksp FSEHIP_HUF_buildCTable_wksp
+#define HUF_writeCTable FSEHIP_HUF_writeCTable
 #define HUF_readDTableX1 FSEHIP_HUF_readDTableX1
 #define HUF_readDTableX1_wksp FSEHIP_HUF_readDTableX1_wksp
 #define HUF_decompress4X1 FSEHIP_HUF_decompress4X1

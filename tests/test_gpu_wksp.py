@@ -266,3 +266,82 @@ def test_huf_single_symbol_family_under_the_reference_names(hip, ref, checker):
                         (rg, _), (rr, _) = _both(hip, ref, "HUF_readDTableX1_wksp", dt, part, SZ(n), ws, SZ(wsz))
                         assert rg == rr, ("readDTableX1_wksp", wsz, rg, rr)
     assert checked > 20
+
+
+def test_huf_build_and_write_ctable_under_the_reference_names(hip, ref, checker):
+    """HUF_buildCTable[_wksp] on the caller's counters and HUF_writeCTable on the caller's table (lib/huf.h:204-218): the same arguments into the
+    device call and the reference -- table logs, codes, header bytes; histograms of real blocks, flat and steep ones (trees deeper than the limit:
+    the cut and its repair), a single symbol in use, limits 0 (default) .. 15, workspaces misaligned and one byte short, destinations too small"""
+    rng = np.random.default_rng(21)
+    hists = []
+    for src in _blocks(checker):
+        c = np.bincount(src, minlength=256).astype(np.uint32)
+        hists.append((c, int(np.nonzero(c)[0].max())))
+    fib = np.zeros(256, np.uint32); a, b = 1, 1
+    for i in range(30):
+        fib[3 * i] = a; a, b = b, a + b                         # steep: the unlimited tree is 29 levels deep
+    hists.append((fib, 87))
+    hists.append((rng.integers(1, 5, 256).astype(np.uint32), 255))                       # flat: every length 8
+    hists.append((np.where(rng.random(256) < 0.1, rng.integers(1, 100000, 256), 0).astype(np.uint32), 255))
+    one = np.zeros(256, np.uint32); one[77] = 1234
+    hists.append((one, 77)); hists.append((one, 200))
+    two = np.zeros(256, np.uint32); two[3] = 5; two[250] = 5
+    hists.append((two, 250))
+    wksp = np.zeros(1200, np.uint32)
+    built = []
+    for count, msv in hists:
+        used = int((count[:msv + 1] != 0).sum())
+        for limit in (0, 11, 12, 8, 5, 15, 3):
+            lim = limit or 11
+            if used == 0 or (lim <= 12 and used > (1 << lim)):
+                continue                                          # undefined in the reference (refused on the device: below)
+            tree = np.zeros(256, np.uint32)
+            if limit > 12:
+                # a limit above HUF_TABLELOG_MAX: the reference returns GENERIC when the tree is deeper than 12 (lib/huf_compress.c:385) -- but its
+                # HUF_setMaxHeight has overrun rankLast[] by then when the tree is deeper than the limit by 13 or more ("stack smashing detected"
+                # with the steep histogram), so the reference is only asked what a tree of at most 12 levels gives, at limit 12
+                f = hip.lib.FSEHIP_HUF_buildCTable; f.restype = SZ
+                g = tree.copy()
+                rg = int(f(_p(g), _p(count), U(msv), U(limit)))
+                (r12, a12), _ = _both(hip, ref, "HUF_buildCTable", tree, count, U(msv), U(12))
+                deep = bool((a12[0][:msv + 1] >> 16).max() == 12) and used > 12       # (12 after a cut, or exactly 12 levels: then both answers are right)
+                assert (rg == r12 and (g == a12[0]).all()) or (deep and rg == (1 << 64) - 1), ("HUF_buildCTable", msv, used, limit, rg, r12)
+                continue
+            (rg, ag), (rr, ar) = _both(hip, ref, "HUF_buildCTable", tree, count, U(msv), U(limit))
+            assert rg == rr, ("HUF_buildCTable", msv, used, limit, rg, rr)
+            if rg < (1 << 64) - 200:
+                assert (ag[0][:msv + 1] == ar[0][:msv + 1]).all(), ("HUF_buildCTable", msv, used, limit, np.nonzero(ag[0][:msv + 1] != ar[0][:msv + 1])[0][:8])
+                built.append((ar[0].copy(), msv, rr))
+        tree = np.zeros(256, np.uint32)
+        for off, size in ((0, 4352), (0, 4351), (1, 4400), (0, 4800)):
+            res = []
+            for lib, fname in ((hip.lib, "FSEHIP_HUF_buildCTable_wksp"), (ref.lib, "HUF_buildCTable_wksp")):
+                f = getattr(lib, fname); f.restype = SZ
+                raw = wksp.view(np.uint8)
+                res.append(int(f(_p(tree.copy()), _p(count), U(msv), U(11), C.c_void_p(raw[off:].ctypes.data), SZ(size))))
+            assert res[0] == res[1] or used == 0, ("HUF_buildCTable_wksp", off, size, res)
+    assert len(built) > 40
+    generic = (1 << 64) - 1
+    tree = np.zeros(256, np.uint32)
+    f = hip.lib.FSEHIP_HUF_buildCTable; f.restype = SZ
+    assert int(f(_p(tree), _p(np.zeros(256, np.uint32)), U(255), U(11))) == generic                      # no symbol in use
+    assert int(f(_p(tree), _p(np.ones(256, np.uint32)), U(255), U(7))) == generic                        # 256 symbols, codes of 7 bits
+    assert int(f(_p(tree), _p(np.ones(256, np.uint32)), U(256), U(11))) == (1 << 64) - 6                  # maxSymbolValue_tooLarge (:350)
+    for tree, msv, log in built:
+        full = None
+        for cap in (300, None, -1, -2, 5, 1):                 # (not 0: the reference hands maxDstSize - 1 to its weight coder, lib/huf_compress.c:133)
+            if cap is None or (cap is not None and cap < 0):
+                if full is None:
+                    continue
+                cap = full + (0 if cap is None else cap)
+            dst = np.full(320, 0xA5, np.uint8)
+            (rg, ag), (rr, ar) = _both(hip, ref, "HUF_writeCTable", dst, SZ(cap), tree, U(msv), U(log))
+            assert rg == rr, ("HUF_writeCTable", msv, log, cap, rg, rr)
+            if rg < (1 << 64) - 200:
+                assert (ag[0][:rg] == ar[0][:rg]).all() and (ag[0][cap:] == 0xA5).all(), ("HUF_writeCTable", msv, log, cap)
+                full = rg if full is None else full
+    f = hip.lib.FSEHIP_HUF_writeCTable; f.restype = SZ
+    tree, msv, log = built[0]
+    dst = np.zeros(320, np.uint8)
+    assert int(f(_p(dst), SZ(300), _p(tree), U(msv), U(max(log - 1, 0)))) == generic                     # a length above huffLog: beyond the reference's bitsToWeight[]
+    assert int(f(_p(dst), SZ(300), _p(tree), U(256), U(log))) == (1 << 64) - 6
