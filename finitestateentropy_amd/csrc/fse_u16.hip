@@ -132,6 +132,7 @@ DEV void u16_spread_rank(U16Lds<TLMAX>& L, u32 maxSV, u32 tl, u32 lane, Emit&& e
 // blocks of up to 16,384 symbols get table log 11 or less from FSE_optimalTableLog) -- which leaves a block whose table log comes out as 12
 // marked U16_WIDE, and <12, true>, which takes only those (12.7 KB, 12 waves per CU).
 #define U16_WIDE 6u
+#define U16_SKEWED 7u            // compress side: a table for the lane-per-block encoder (one symbol holds more than 63/64 of the cells)
 template <u32 TLMAX, bool SECOND>
 __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
 {
@@ -256,7 +257,14 @@ __global__ __launch_bounds__(64) void k_u16_cprep(U16CArgs a)
         else { const u32 mbo = tl - hibit32((u32)(v - 1)); dnb = (mbo << 16) - ((u32)v << mbo); dfs = total - (u32)v; }
         tt[2 * s] = dfs; tt[2 * s + 1] = dnb;
     }
-    m.state = 1; m.hdrSize = (u32)hdr; m.tableLog = tl; m.maxSV = maxSV;
+    // Encoder choice, as k_fse_cprep makes it for the byte coder: when one symbol holds more than 63/64 of the cells a lane's share of the output does not
+    // span a byte, the wave encoder would find that out only after its warm-up, counting and link-repair work (k_u16_encode_wave, "tables that skewed")
+    // and leave the block to the lane-per-block kernel -- such blocks go there at once.  (The wave kernel still re-checks exactly.)
+    int top1 = 0;
+#pragma unroll
+    for (int i = 0; i < U16_SPL; ++i) top1 = nn[i] > top1 ? nn[i] : top1;
+    top1 = wave_max_i32(top1);
+    m.state = (u32)top1 * 64u > (63u << tl) ? U16_SKEWED : 1u; m.hdrSize = (u32)hdr; m.tableLog = tl; m.maxSV = maxSV;
     if (lane == 0) a.meta[b] = m;
 }
 
@@ -445,7 +453,7 @@ __global__ void k_u16_encode(U16CArgs a)
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.nBlocks) return;
     const U16Meta m = a.meta[b];
-    if (m.state != 1) return;
+    if (m.state != 1 && m.state != U16_SKEWED) return;
     const u16* const src = (const u16*)((const u8*)a.src + b * a.srcStrideBytes);
     const size_t n = a.srcSizes ? a.srcSizes[b] : a.uniformSrcSize;
     const u16* const st = a.stateTables + (b << U16_MAXTL);
