@@ -25,6 +25,11 @@ for f in fuzzer fuzzerHuff0 fuzzerU16; do
     LD_PRELOAD=$RT LD_LIBRARY_PATH=$LIB timeout 900 $R/oracle/_ref/$f-mi355x -s1 -i300 > $O/$f.log 2>&1 || { rc=1; echo "$f under the sanitizers: FAILED"; }
     tail -c 200 $O/$f.log; echo
 done
+# the single calls of the table glue and of the header-reading Huff0 family (round 6), through the reference's fullbench bound to the device
+for c in 4 5 6 21 22 40 41 45 80 81; do
+    LD_PRELOAD=$RT LD_LIBRARY_PATH=$LIB timeout 300 $R/oracle/_ref/fullbench-mi355x -i1 -b$c > $O/fullbench_$c.log 2>&1 || { rc=1; echo "fullbench -b$c under the sanitizers: FAILED"; }
+done
+tail -c 120 $O/fullbench_45.log; echo
 grep -l "ERROR: AddressSanitizer\|runtime error:" $O/*.log && rc=1
 # the sanitized library must really be the one that ran: its mapping shows in the driver's process
 LD_PRELOAD=$RT LD_LIBRARY_PATH=$LIB LD_DEBUG=libs $R/oracle/_ref/san_driver 1 1 2>&1 | grep -m1 "variants/san/libfsehip.so" >> $O/san_driver.log || { rc=1; echo "the sanitized library was not the one loaded"; }
