@@ -127,7 +127,8 @@ class FseHip:
                      "FSEHIP_FSE_compressU16_batch_workspaceSize", "FSEHIP_FSE_decompressU16_batch_workspaceSize",
                      "FSEHIP_FSE_buildCTable_batch_workspaceSize", "FSEHIP_FSE_buildDTable_batch_workspaceSize",
                      "FSEHIP_HUF_buildCTable_batch_workspaceSize", "FSEHIP_HUF_readDTableX1_batch_workspaceSize",
-                     "FSEHIP_compact_batch_workspaceSize", "FSEHIP_compact_batch_bound"):
+                     "FSEHIP_compact_batch_workspaceSize", "FSEHIP_compact_batch_bound", "FSEHIP_HUF_compress1X",
+                     "FSEHIP_HUF_decompress4X1", "FSEHIP_HUF_decompress1X1"):
             if hasattr(L, name):
                 getattr(L, name).restype = SZ
         L.FSEHIP_getErrorName.restype = C.c_char_p
@@ -618,6 +619,41 @@ def _huf_methods():
         dt = np.ascontiguousarray(dt, dtype=np.uint32)
         return self._single("FSEHIP_HUF_decompress1X_usingDTable", dst_size, csrc, dt.ctypes.data_as(VP))
 
+    # the Huff0 advanced flow on host pointers (lib/huf.h:141-167,204-218,288,299-304): same argument order as the reference, numpy in / out
+    def huf_build_ctable(self, count, max_sv, max_nb_bits=0):
+        """HUF_buildCTable: (table log or error, HUF_CElt[256] as uint32 -- entries beyond max_sv stay zero)"""
+        count = np.ascontiguousarray(count, dtype=np.uint32)
+        celt = np.zeros(256, dtype=np.uint32)
+        self.lib.FSEHIP_HUF_buildCTable.restype = SZ
+        return int(self.lib.FSEHIP_HUF_buildCTable(celt.ctypes.data_as(VP), count.ctypes.data_as(VP), C.c_uint(max_sv), C.c_uint(max_nb_bits))), celt
+
+    def huf_write_ctable(self, celt, max_sv, huff_log, cap=256):
+        celt = np.ascontiguousarray(celt, dtype=np.uint32)
+        out = np.full(max(cap, 1) + 8, 0xA5, dtype=np.uint8)
+        self.lib.FSEHIP_HUF_writeCTable.restype = SZ
+        r = int(self.lib.FSEHIP_HUF_writeCTable(out.ctypes.data_as(VP), SZ(cap), celt.ctypes.data_as(VP), C.c_uint(max_sv), C.c_uint(huff_log)))
+        assert (out[cap:] == 0xA5).all(), "HUF_writeCTable wrote past maxDstSize"
+        return r, out[:cap]
+
+    def huf_read_dtable_x1(self, src, max_table_log=12):
+        """HUF_readDTableX1 into a DTable made by HUF_CREATE_STATIC_DTABLEX1(DTable, max_table_log): (header size or error, DTable)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dt = np.zeros(1 + (1 << 11), dtype=np.uint32)
+        dt[0] = (max_table_log - 1) * 0x01000001
+        self.lib.FSEHIP_HUF_readDTableX1.restype = SZ
+        return int(self.lib.FSEHIP_HUF_readDTableX1(dt.ctypes.data_as(VP), src.ctypes.data_as(VP), SZ(src.size))), dt
+
+    def huf_compress1x(self, src, max_sv=255, huff_log=11, cap=None):
+        return self._single("FSEHIP_HUF_compress1X", huf_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(huff_log))
+
+    def huf_decompress4x1(self, csrc, dst_size):
+        self.lib.FSEHIP_HUF_decompress4X1.restype = SZ
+        return self._single("FSEHIP_HUF_decompress4X1", dst_size, csrc)
+
+    def huf_decompress1x1(self, csrc, dst_size):
+        self.lib.FSEHIP_HUF_decompress1X1.restype = SZ
+        return self._single("FSEHIP_HUF_decompress1X1", dst_size, csrc)
+
     # layer 1
     def huf_compress2(self, src, max_sv=255, huff_log=11, cap=None):
         return self._single("FSEHIP_HUF_compress2", huf_compress_bound(len(src)) if cap is None else cap, src, C.c_uint(max_sv), C.c_uint(huff_log))
@@ -644,7 +680,8 @@ def _huf_methods():
     for f in (huf_decompress1x1_using_dtable_batch, huf_decompress1x_using_dtable_batch, huf_decompress1x1_using_dtable, huf_decompress1x_using_dtable,
               huf_decompress_packed_batch, huf_build_ctable_batch, huf_read_dtable_x1_batch, huf_workspace, huf_compress_batch, huf_decompress_batch, huf_compress4x_using_ctable_batch, huf_compress1x_using_ctable_batch,
               huf_decompress4x1_using_dtable_batch, huf_decompress4x_using_dtable_batch, huf_compress2, huf_decompress, huf_compress1x_using_ctable,
-              huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable):
+              huf_compress4x_using_ctable, huf_decompress4x1_using_dtable, huf_decompress4x_using_dtable,
+              huf_build_ctable, huf_write_ctable, huf_read_dtable_x1, huf_compress1x, huf_decompress4x1, huf_decompress1x1):
         setattr(FseHip, f.__name__, f)
 
 

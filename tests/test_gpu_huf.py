@@ -617,3 +617,37 @@ def test_huf_compress_barely_compressible_blocks_in_two_halves(hip, oracle):
     out_h, dres_h = out.cpu().numpy(), dres.cpu().numpy()
     for i, b in enumerate(np.nonzero(coded.cpu().numpy())[0]):
         assert dres_h[i] == sz_h[b] and (out_h[i][:sz_h[b]] == blocks[b][:sz_h[b]]).all(), b
+
+
+def test_huf_advanced_flow_end_to_end_on_the_device(hip, ref):
+    """count -> HUF_buildCTable -> HUF_writeCTable -> HUF_compress4X / 1X_usingCTable | HUF_readDTableX1 -> HUF_decompress4X1 / 1X1_usingDTable, and the
+    one-call forms HUF_compress1X / HUF_decompress4X1 / HUF_decompress1X1: every step a device call under the reference's name and signature
+    (include/fsehip.h), every intermediate against the reference run on the same inputs"""
+    rng = np.random.default_rng(31)
+    for size, p in ((32768, 0.14), (32768, 0.8), (5000, 0.05), (131072, 0.3)):
+        src = np.minimum(rng.geometric(p, size) - 1, 255).astype(np.uint8)
+        mx, msv, count = hip.hist_count(src, 255)
+        log, celt = hip.huf_build_ctable(count, msv, 0)
+        rlog, rcelt = ref.huf_build_ctable(count, msv, 0)
+        assert log == rlog and (celt[:msv + 1] == rcelt[:msv + 1]).all(), (size, p)
+        h, hdr = hip.huf_write_ctable(celt, msv, log)
+        rh, rhdr = ref.huf_write_ctable(256, rcelt, msv, rlog)
+        assert h == rh and (hdr[:h] == rhdr[:h]).all(), (size, p)
+        for streams in (4, 1):
+            enc = hip.huf_compress4x_using_ctable if streams == 4 else hip.huf_compress1x_using_ctable
+            renc = ref.huf_compress4x_using_ctable if streams == 4 else ref.huf_compress1x_using_ctable
+            c, comp = enc(src, celt)
+            rc, rcomp = renc(src, rcelt)
+            assert c == rc and c > 0 and (comp[:c] == rcomp[:c]).all(), (size, p, streams)
+            block = np.concatenate([hdr[:h], comp[:c]])
+            g, dt = hip.huf_read_dtable_x1(block, 12)
+            assert g == h
+            dec = hip.huf_decompress4x1_using_dtable if streams == 4 else hip.huf_decompress1x1_using_dtable
+            d, out = dec(block[g:], dt, size)
+            assert d == size and (out[:size] == src).all(), (size, p, streams)
+            one = hip.huf_decompress4x1 if streams == 4 else hip.huf_decompress1x1
+            d, out = one(block, size)
+            assert d == size and (out[:size] == src).all(), (size, p, streams, "one call")
+        c1, comp1 = hip.huf_compress1x(src, 255, 11)
+        d, out = hip.huf_decompress1x1(comp1[:c1], size)
+        assert c1 > 1 and d == size and (out[:size] == src).all(), (size, p, "HUF_compress1X")
