@@ -238,8 +238,20 @@ DEV void fse_probe_gstore(u32 off, u32 a, u32 b)
     *(__attribute__((address_space(1))) v2*)(base + off) = (v2){ a, b };
 }
 #endif
+// Measurement aid (EXPERIMENTS.md section 1, round 6): FSE_PEEK_IN_PHASE 1 requests the service's progress words {srvFlushed, srvValidLo} the NEXT round
+// looks at HERE, a few iterations before the phase ends, instead of in the round's poll loop.  Reason to try: that loop is a do-while, and the
+// compiler waits for the words requested in it at the bottom of the loop body on the exit path too (the loop-carried copy needs the data: s_waitcnt
+// lgkmcnt(0) + v_mov_b64 in front of the loop's branch), so every round pays part of an LDS round trip that the request "one round ahead" was meant
+// to hide.  Measured: 3700 -> 3671 cycles per productive round, and the decode call 0.3 - 0.8 % SLOWER on every distribution.  0 in the product.
+#ifndef FSE_PEEK_IN_PHASE
+#define FSE_PEEK_IN_PHASE 0
+#endif
+#ifndef FSE_PEEK_AT
+#define FSE_PEEK_AT 4            // iterations before the end of the phase
+#endif
 template <int NITER>
-DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
+DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine,
+                            const u32* peekAt = nullptr, u64* peekOut = nullptr)
 {
     u32 s = sMine, P = Pref;
     u32 prev = 0;
@@ -283,6 +295,9 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
 #else
         if (it & 1) ringMine[it & ~1] = make_uint2(prev, rec); else prev = rec;
 #endif
+#if FSE_PEEK_IN_PHASE
+        if (peekOut && it == (NITER > FSE_PEEK_AT ? NITER - FSE_PEEK_AT : 0)) *peekOut = __hip_atomic_load((const u64*)peekAt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         SB;
         s = fse_chain_pad(lshl_or(__builtin_amdgcn_ubfe(lo2, dpp_swap_and(c2, maskB), c2), K - c2, (c2 >> cellShift) | tabOff));
         if (it + 1 < NITER) c = lds_cell(s);
@@ -295,10 +310,12 @@ DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cel
 #undef SB
 #else
 template <int NITER>
-DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine)
+DEV void fse_bulk_phase_rev(u32& sMine, u32& Pref, u32& PheadRef, u32 K, u32 cellShift, u32 tabOff, u32 myIn, u32 maskB, uint2* ringMine,
+                            const u32* peekAt = nullptr, u64* peekOut = nullptr)
 {
     u32 s = sMine, P = Pref;
     u32 prev = 0;
+    if (peekOut) *peekOut = __hip_atomic_load((const u64*)peekAt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __asm__ volatile("" : "+v"(myIn));                           // one register: the three window reads then differ by their immediate offsets
 #pragma unroll FSE_PHASE_UNROLL
     for (int it = 0; it < NITER; ++it) {
@@ -962,6 +979,17 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
             // stream start is ever consumed: once the ring reaches down to it (validLo <= 0) the phase may run.
             const int lowest = (int)bs.q - 4 * ((48 * (FSE_CHECK_EVERY - 1) + 31) / 32);
             const int need = lowest > 0 ? lowest : 0;
+#if FSE_PEEK_IN_PHASE
+            // srvNext was requested inside the previous phase (fse_bulk_phase_rev) and arrived long ago: the common round looks at it and goes on
+            // without an LDS round trip of its own; only a round that has to poll asks again and waits.
+            {   bool rdy = !can | ((iters + FSE_CHECK_EVERY - (u32)srvNext <= FSE_DEC_RING) & (need >= (int)(u32)(srvNext >> 32)));
+                while (!__all(rdy)) {                                            // uniform: poll until every chain of the wave may run
+                    TIMING(const unsigned long long tB = __builtin_readcyclecounter(); tWait += tB - tA; ++nWait; tA = tB;);
+                    srvNext = ctl_peek2(&ctl->srvFlushed);
+                    rdy = !can | ((iters + FSE_CHECK_EVERY - (u32)srvNext <= FSE_DEC_RING) & (need >= (int)(u32)(srvNext >> 32)));
+                }
+            }
+#else
             bool rdy;
             do {                                                                 // uniform: poll until every chain of the wave may run
                 const u32 fl = (u32)srvNext;
@@ -970,12 +998,17 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
                 rdy = !can | ((iters + FSE_CHECK_EVERY - fl <= FSE_DEC_RING) & (need >= vlo));
                 TIMING(if (!__all(rdy)) { const unsigned long long tB = __builtin_readcyclecounter(); tWait += tB - tA; ++nWait; tA = tB; });
             } while (!__all(rdy));
+#endif
             if (!__any(can)) break;                                              // uniform
             uint2* const ring = can ? myRing + rpos : dummyRing;
             u32 sN = bs.s, Pn = P, PhN = Phead;
             unsigned long long tI = 0; (void)tI;
             TIMING(tI = __builtin_readcyclecounter(););
+#if FSE_PEEK_IN_PHASE
+            fse_bulk_phase_rev<FSE_CHECK_EVERY>(sN, Pn, PhN, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring, &ctl->srvFlushed, &srvNext);
+#else
             fse_bulk_phase_rev<FSE_CHECK_EVERY>(sN, Pn, PhN, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+#endif
             TIMING(tInner += __builtin_readcyclecounter() - tI;);
             bs.s = can ? sN : bs.s; P = can ? Pn : P; Phead = can ? PhN : Phead;
             const u32 adv = can ? (u32)FSE_CHECK_EVERY : 0u;
@@ -996,14 +1029,26 @@ __global__ __launch_bounds__(FSE_DEC_THREADS) void k_fse_decode(FseDecArgs a)
         for (;;) {                                   // ---- finishing phases of FSE_FINISH_EVERY iterations (every lane is through with the long ones)
             const u32 fl = (u32)srvNext;
             const int vlo = (int)(u32)(srvNext >> 32);
+#if !FSE_PEEK_IN_PHASE
             srvNext = ctl_peek2(&ctl->srvFlushed);
+#endif
             const int lowest = (int)bs.q - 8;                                    // the second iteration's window starts at most two dwords further down
             const bool rdy = !can2 | ((iters + FSE_FINISH_EVERY - fl <= FSE_DEC_RING) & ((lowest > 0 ? lowest : 0) >= vlo));
-            if (!__all(rdy)) { TIMING(const unsigned long long tB = __builtin_readcyclecounter(); tWait += tB - tA; ++nWait; tA = tB;); continue; }
+            if (!__all(rdy)) {
+                TIMING(const unsigned long long tB = __builtin_readcyclecounter(); tWait += tB - tA; ++nWait; tA = tB;);
+#if FSE_PEEK_IN_PHASE
+                srvNext = ctl_peek2(&ctl->srvFlushed);
+#endif
+                continue;
+            }
             if (!__any(can2)) break;
             uint2* const ring = can2 ? myRing + rpos : dummyRing;
             u32 sN = bs.s, Pn = P, PhN = Phead;
+#if FSE_PEEK_IN_PHASE
+            fse_bulk_phase_rev<FSE_FINISH_EVERY>(sN, Pn, PhN, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring, &ctl->srvFlushed, &srvNext);
+#else
             fse_bulk_phase_rev<FSE_FINISH_EVERY>(sN, Pn, PhN, tl + 1u, 4u, tabOff, myIn, maskB & 31u, ring);
+#endif
             bs.s = can2 ? sN : bs.s; P = can2 ? Pn : P; Phead = can2 ? PhN : Phead;
             rpos = can2 ? (rpos + FSE_FINISH_EVERY) & (FSE_DEC_RING - 1) : rpos;
             iters += can2 ? FSE_FINISH_EVERY : 0u; grp -= can2 ? FSE_FINISH_EVERY : 0;
