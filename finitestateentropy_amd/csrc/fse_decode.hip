@@ -401,6 +401,11 @@ DEV void fse_scratch_slot_done(const FseDecArgs& a, u32* flagsSh, int lane)
         __hip_atomic_fetch_and(a.slotBitmap + (slot >> 5), ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+#ifndef FSE_SRV_READLANE
+#define FSE_SRV_READLANE 1
+#endif
+DEV u32 srv_rl(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+DEV unsigned long long srv_rl64(unsigned long long v, int l) { return (unsigned long long)srv_rl((u32)v, l) | ((unsigned long long)srv_rl((u32)(v >> 32), l) << 32); }
 template <bool TIMED, bool CALLER>
 DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 slotBytes, u32 ringOff, u32 inOff, int lane, int g0, bool rev, u32* flagsSh)
 {
@@ -480,11 +485,18 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
             }
         }
         // (2) issue the symbol gathers of every block with enough records
+        // (FSE_SRV_READLANE: the per-block values of lane l reach the wave through v_readlane -- the lane index is a constant of the unrolled loop --
+        //  instead of __shfl = ds_bpermute: eight LDS-pipe instructions per flushed block were about half of all LDS instructions of the CU)
 #pragma unroll
         for (int l = 0; l < FSE_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;               // uniform
+#if FSE_SRV_READLANE
+            const u32 cnt = srv_rl(avail, l), fp_g = srv_rl(fpos, l);
+            const gbl_u8_ptr tg = (gbl_u8_ptr)(uintptr_t)srv_rl64(tabBits, l);
+#else
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
             const gbl_u8_ptr tg = (gbl_u8_ptr)(uintptr_t)__shfl(tabBits, l, WAVE);
+#endif
             if ((u32)lane < cnt) {
                 // iteration i lives in slot pair (i >> 1): 16 bytes = lane A's {iteration 2p, 2p+1} words, then lane B's
                 u32 ri = fp_g + (u32)lane;
@@ -509,8 +521,13 @@ DEV void fse_decode_service(const FseDecArgs& a, u8* ldsb, DecCtl* ctlAll, u32 s
 #pragma unroll
         for (int l = 0; l < FSE_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;               // uniform
+#if FSE_SRV_READLANE
+            const u32 cnt = srv_rl(avail, l), fl_g = srv_rl(flushed, l);
+            gbl_u8_w_ptr const og = (gbl_u8_w_ptr)(uintptr_t)(srv_rl64(outBits, l) + 4ull * fl_g);
+#else
             const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
             gbl_u8_w_ptr const og = (gbl_u8_w_ptr)(uintptr_t)(__shfl(outBits, l, WAVE) + 4ull * fl_g);
+#endif
             if ((u32)lane < cnt) {
                 const u32 w = yq[l][0] | (yq[l][1] << 8) | (yq[l][2] << 16) | (yq[l][3] << 24);
                 gbl_store_u32(og + 4u * lane, w);

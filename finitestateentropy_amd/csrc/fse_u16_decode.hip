@@ -94,6 +94,8 @@ DEV u32 u16d_sym_g(const __attribute__((address_space(1))) u8* base, u32 state)
     const u32 bit = state * 9u;
     return ((u32)*(const __attribute__((address_space(1))) u16d_u16u*)(base + (bit >> 3)) >> (bit & 7u)) & 0x1FFu;
 }
+DEV u32 u16d_rl(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+DEV unsigned long long u16d_rl64(unsigned long long v, int l) { return (unsigned long long)u16d_rl((u32)v, l) | ((unsigned long long)u16d_rl((u32)(v >> 32), l) << 32); }
 DEV void u16d_ring_put(u32* rg, int off, u32 w)
 {
     const u32 j = (u32)off & (U16D_IN_RING - 1);
@@ -161,8 +163,10 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
 #pragma unroll
         for (int l = 0; l < U16D_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;
-            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fp_g = (u32)__shfl((int)fpos, l, WAVE);
-            const g_u8 tg = (g_u8)(uintptr_t)__shfl(symBits, l, WAVE);
+            // (v_readlane instead of __shfl = ds_bpermute: the lane index is a constant of the unrolled loop, and the LDS pipe is what the
+            //  decoder wave's chain waits on -- fse_decode.hip, FSE_SRV_READLANE)
+            const u32 cnt = u16d_rl(avail, l), fp_g = u16d_rl(fpos, l);
+            const g_u8 tg = (g_u8)(uintptr_t)u16d_rl64(symBits, l);
             if ((u32)lane < cnt) {
                 const u32 ri = (fp_g + (u32)lane) & (U16D_RING - 1);
                 const uint2 rec = *(const uint2*)(ldsb + (size_t)(g0 + l) * slotBytes + 8u * ri);
@@ -177,8 +181,8 @@ DEV void u16d_service(u8* ldsb, U16Ctl* ctlAll, u32 slotBytes, int G, int lane, 
 #pragma unroll
         for (int l = 0; l < U16D_SRV_G; ++l) {
             if (!((fm >> l) & 1ull)) continue;
-            const u32 cnt = (u32)__shfl((int)avail, l, WAVE), fl_g = (u32)__shfl((int)flushed, l, WAVE);
-            __attribute__((address_space(1))) u8* const og = (__attribute__((address_space(1))) u8*)(uintptr_t)(__shfl(outBits, l, WAVE) + 8ull * fl_g);
+            const u32 cnt = u16d_rl(avail, l), fl_g = u16d_rl(flushed, l);
+            __attribute__((address_space(1))) u8* const og = (__attribute__((address_space(1))) u8*)(uintptr_t)(u16d_rl64(outBits, l) + 8ull * fl_g);
             if ((u32)lane < cnt) {
                 const uint2 w = make_uint2(yq[l][0] | (yq[l][1] << 16), yq[l][2] | (yq[l][3] << 16));
                 *(__attribute__((address_space(1))) u64_u*)(og + 8u * lane) = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
