@@ -67,10 +67,15 @@ DEV WaveBuildLds wave_build_carve(u8* base, u32 capTs)
 DEV u32 wb_bytesum(u32 v) { return __builtin_amdgcn_sad_u8(v, 0u, 0u); }
 DEV u32 wb_scan_excl(u32 v, u32 lane, u32* total)         // exclusive prefix sum over the 64 lanes
 {
+#if FSEHIP_DPP_SCANS
+    const u32 incl = group_scan_incl<64, ScanAdd>(v, lane);
+    *total = group_last<64>(incl, lane);
+#else
     u32 incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
     *total = (u32)__shfl((int)incl, 63, WAVE);
+#endif
     return incl - v;
 }
 
@@ -136,10 +141,15 @@ DEV bool wave_spread_rank(const WaveBuildLds& w, u32 maxSV, u32 tl, u32 lane, Pa
         for (u32 j = 0; j < 8; ++j) if (i + j < nv) localMax = v[j] > localMax ? v[j] : localMax;
     }
     u32 run = localMax;                                                   // inclusive prefix maximum over the lanes ...
+#if FSEHIP_DPP_SCANS
+    run = group_scan_incl<64, ScanMax>(run, lane);
+    run = dpp_mov<0x138, 0xF, true>(0u, run);                            // ... made exclusive: wave_shr:1, lane 0 gets 0
+#else
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)run, off, WAVE); if ((int)lane >= off) run = o > run ? o : run; }
     run = (u32)__shfl_up((int)run, 1, WAVE);                             // ... made exclusive
     if (lane == 0) run = 0;
+#endif
     if (act && nv) {
         u32 u = (m0 * step) & mask, k = k0;
         u32 i = 0;

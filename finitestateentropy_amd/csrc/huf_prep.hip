@@ -89,7 +89,7 @@ DEV void hp_sort_desc(u32 (&k)[R], u32 lane)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const u32 i = lane * R + r;
-                    const u32 o = (u32)__shfl_xor((int)k[r], (int)lj, WAVE);
+                    const u32 o = lane_xor_any(k[r], lj, lane);                          // (lj is a constant of the unrolled loops: DPP / permlane, dev_common.h)
                     const bool keepMax = ((i & size) == 0) == ((i & j) == 0);
                     const u32 hi = k[r] > o ? k[r] : o, lo = k[r] > o ? o : k[r];
                     k[r] = keepMax ? hi : lo;
@@ -158,16 +158,24 @@ DEV Pk pk_rank(const u32 cls[4], u32 rank[4], u32 lane)
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (cls[i] < 14) pk_add(mine, cls[i]);
     Pk incl = mine;
+#if FSEHIP_DPP_SCANS
+    incl.a = group_scan_incl_add64<64>(incl.a, lane); incl.b = group_scan_incl_add64<64>(incl.b, lane);      // (dev_common.h: DPP instead of ds_bpermute)
+#else
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const u64 oa = (u64)__shfl_up((unsigned long long)incl.a, off, WAVE), ob = (u64)__shfl_up((unsigned long long)incl.b, off, WAVE);
         if ((int)lane >= off) { incl.a += oa; incl.b += ob; }
     }
+#endif
     Pk run = { incl.a - mine.a, incl.b - mine.b };
 #pragma unroll
     for (int i = 0; i < 4; ++i) { rank[i] = 0; if (cls[i] < 14) { rank[i] = pk_get(run, cls[i]); pk_add(run, cls[i]); } }
     Pk tot;
+#if FSEHIP_DPP_SCANS
+    tot.a = group_last64<64>(incl.a, lane); tot.b = group_last64<64>(incl.b, lane);
+#else
     tot.a = (u64)__shfl((unsigned long long)incl.a, 63, WAVE); tot.b = (u64)__shfl((unsigned long long)incl.b, 63, WAVE);
+#endif
     return tot;
 }
 

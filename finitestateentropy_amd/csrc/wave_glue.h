@@ -25,29 +25,49 @@
 
 // ---- group primitives -----------------------------------------------------------------------------------------------------
 template <int W> DEV u32 wg_sub(u32 lane) { return lane & (u32)(W - 1); }
+// (lane-invariant callers pass no lane: these primitives are called by all lanes of the wave in uniform control flow, and a group's lanes are
+//  lane & ~(W - 1) .. | (W - 1); the DPP forms need the lane id only for groups smaller than the wave)
+DEV u32 wg_lane() { return (u32)threadIdx.x & 63u; }
 template <int W> DEV u32 wg_sum(u32 v)
 {
+#if FSEHIP_DPP_SCANS
+    return group_reduce<W, ScanAdd>(v, wg_lane());
+#else
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, WAVE);
     return v;
+#endif
 }
 template <int W> DEV u64 wg_sum64(u64 v)
 {
+#if FSEHIP_DPP_SCANS
+    const u32 lane = wg_lane();
+    return group_last64<W>(group_scan_incl_add64<W>(v, lane & (u32)(W - 1)), lane);
+#else
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) v += (u64)__shfl_xor((unsigned long long)v, off, WAVE);
     return v;
+#endif
 }
 template <int W> DEV u32 wg_max(u32 v)
 {
+#if FSEHIP_DPP_SCANS
+    return group_reduce<W, ScanMax>(v, wg_lane());
+#else
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o > v ? o : v; }
     return v;
+#endif
 }
 template <int W> DEV u32 wg_min(u32 v)
 {
+#if FSEHIP_DPP_SCANS
+    return group_reduce<W, ScanMin>(v, wg_lane());
+#else
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)v, off, WAVE); v = o < v ? o : v; }
     return v;
+#endif
 }
 template <int W> DEV bool wg_any(bool p, u32 lane)          // any lane of my group
 {
@@ -58,22 +78,46 @@ template <int W> DEV bool wg_any(bool p, u32 lane)          // any lane of my gr
 template <int W> DEV u32 wg_scan_excl(u32 v, u32 lane)     // exclusive prefix sum over the lanes of my group
 {
     const u32 sub = wg_sub<W>(lane);
+#if FSEHIP_DPP_SCANS
+    return group_scan_incl<W, ScanAdd>(v, sub) - v;
+#else
     u32 incl = v;
 #pragma unroll
     for (int off = 1; off < W; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)sub >= off) incl += o; }
     return incl - v;
+#endif
 }
 template <int W> DEV u64 wg_scan_excl64(u64 v, u32 lane)
 {
     const u32 sub = wg_sub<W>(lane);
+#if FSEHIP_DPP_SCANS
+    return group_scan_incl_add64<W>(v, sub) - v;
+#else
     u64 incl = v;
 #pragma unroll
     for (int off = 1; off < W; off <<= 1) { const u64 o = (u64)__shfl_up((unsigned long long)incl, off, WAVE); if ((int)sub >= off) incl += o; }
     return incl - v;
+#endif
 }
 template <int W> DEV u32 wg_suffix_min_excl(u32 v, u32 lane)   // min over the lanes of my group above this one (0xFFFFFFFF for the last)
 {
     const u32 sub = wg_sub<W>(lane);
+#if FSEHIP_DPP_SCANS
+    if (W == 64) {
+        // inside the rows of 16: inclusive suffix minimum by row_shl:1/2/4/8 (a lane the shift does not reach keeps its value); across the rows: every
+        // row's minimum now sits in its first lane -- three v_readlane, the rows above folded on the scalar unit; then one wave_shl:1 makes it exclusive
+        u32 m = v;
+        { const u32 t = dpp_mov<0x101, 0xF, false>(0xFFFFFFFFu, m); m = t < m ? t : m; }
+        { const u32 t = dpp_mov<0x102, 0xF, false>(0xFFFFFFFFu, m); m = t < m ? t : m; }
+        { const u32 t = dpp_mov<0x104, 0xF, false>(0xFFFFFFFFu, m); m = t < m ? t : m; }
+        { const u32 t = dpp_mov<0x108, 0xF, false>(0xFFFFFFFFu, m); m = t < m ? t : m; }
+        const u32 r1 = (u32)__builtin_amdgcn_readlane((int)m, 16), r2 = (u32)__builtin_amdgcn_readlane((int)m, 32), r3 = (u32)__builtin_amdgcn_readlane((int)m, 48);
+        const u32 a2 = r3, a1 = r2 < r3 ? r2 : r3, a0 = r1 < a1 ? r1 : a1;               // minimum of the rows above row 2 / 1 / 0
+        const u32 above = lane < 16 ? a0 : lane < 32 ? a1 : lane < 48 ? a2 : 0xFFFFFFFFu;
+        m = above < m ? above : m;
+        return dpp_mov<0x130, 0xF, false>(0xFFFFFFFFu, m);                                 // wave_shl:1: lane i takes lane i + 1's, the last lane keeps all ones
+    }
+#endif
     u32 m = v;
 #pragma unroll
     for (int off = 1; off < W; off <<= 1) { const u32 o = (u32)__shfl_down((int)m, off, WAVE); if ((int)sub + off < W) m = o < m ? o : m; }
