@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : 
             for (u32 round = 0;; ++round) {
                 if (todo) { E = S; n = hpar_run_keep(arr, E, cHi, tabOff, mask2, sym, spill); }
                 HST(if (round == 0) { const unsigned long long tB = __builtin_readcyclecounter(); tP1 += tB - tA; tA = tB; })
-                const u32 prevE = (u32)__shfl_up((int)E, 1, WAVE);
+                const u32 prevE = dpp_mov<0x138, 0xF, true>(0u, E);                   // wave_shr:1 (the value of lane - 1: DPP, not ds_bpermute -- the LDS pipe is this kernel's bound)
                 const bool bad = lane > 0 && S != prevE;
                 if (!__any(bad)) break;
                 if (round == HPAR_MAX_REPAIR) { good = false; break; }              // uniform
@@ -546,10 +546,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X2CAP ? 2 : 
             if (!good) break;
             HST({ const unsigned long long tB = __builtin_readcyclecounter(); tRep += tB - tA; tA = tB; })
             // ---- verdict for this piece
-            u32 incl = n;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off, WAVE); if ((int)lane >= off) incl += o; }
-            const u32 total = (u32)__shfl((int)incl, 63, WAVE), endC = (u32)__shfl((int)E, 63, WAVE);
+            const u32 incl = group_scan_incl<64, ScanAdd>(n, lane);                  // (dev_common.h: six DPP adds instead of six ds_bpermute)
+            const u32 total = group_last<64>(incl, lane), endC = (u32)__builtin_amdgcn_readlane((int)E, 63);
             // the last piece must regenerate exactly what is left of the segment and end exactly on the stream's first bit; a piece before
             // it must leave symbols to regenerate
             if (lastPiece ? (outBase + total != want || endC != CendL) : (outBase + total >= want)) { good = false; break; }   // uniform: not a stream the reference accepts as is

@@ -17,17 +17,27 @@
 
 #define HUF_ENC_THREADS 256
 
+// (on the DPP path, dev_common.h: the row scan was seven ds_bpermute per row of 1024 symbols beside the row's ~24 table reads and ORs -- a fifth of
+//  the kernel's LDS-pipe instructions)
 DEV u32 wave_incl_scan_u32(u32 v, u32 lane)
 {
+#if FSEHIP_DPP_SCANS
+    return group_scan_incl<64, ScanAdd>(v, lane);
+#else
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)v, off, WAVE); if ((int)lane >= off) v += o; }
     return v;
+#endif
 }
 DEV u32 wave_sum_u32(u32 v)
 {
+#if FSEHIP_DPP_SCANS
+    return group_reduce<64, ScanAdd>(v, 0);
+#else
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, WAVE);
     return v;
+#endif
 }
 
 // OR `nb` (<= 48) bits of `bits` into the bit image at absolute bit position P
@@ -120,7 +130,7 @@ DEV u64 he_emit_tile(u32* img, u64 rowBase, const HeTile& t, u32 len, u32 j0, co
             }
         }
         const u32 incl = wave_incl_scan_u32(tot, lane);
-        const u32 rowBits = (u32)__shfl((int)incl, 63, WAVE);
+        const u32 rowBits = group_last<64>(incl, lane);
         if (rowBase + rowBits > limit) return HE_OVERFLOW;   // uniform
         u64 pos = rowBase + (incl - tot);
 #pragma unroll
