@@ -89,7 +89,10 @@ static int one_round(int id, int round, uint8_t* src, uint8_t* a, uint8_t* b, ui
         const size_t w1 = FSEHIP_HUF_compress1X_wksp(a, hcap, src, n, 255, 11, wk, sizeof wk), w2 = HUF_compress1X_wksp(b, hcap, src, n, 255, 11, wk, sizeof wk);
         CHECK(w1 == w2 && (w1 <= 1 || HUF_isError(w1) || !memcmp(a, b, w1)), "HUF_compress1X_wksp differs (%zu vs %zu)", w1, w2);
     }
-    if ((round % 3) == 2) CHECK(FSEHIP_releaseScratch() == 0, "releaseScratch");
+    if ((round % 3) == 2) {      /* (another worker may be inside the helper pool's release at this moment: the call then says so, fsehip.h) */
+        const int rs = FSEHIP_releaseScratch();
+        CHECK(rs == 0 || rs == FSEHIP_SCRATCH_BUSY, "releaseScratch returns %d", rs);
+    }
     return 0;
 }
 
