@@ -412,14 +412,36 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
         cend = x; bitsTot = nbits;
     }
     ETIMING(T2 = __builtin_readcyclecounter();)
-    // ---- verification / repair per chain: start[k] must equal end[k-1]; super-range 0 (and every one that ran from the block end) is exact
+    // ---- verification / repair per chain: start[k] must equal end[k-1]; super-range 0 (and every one that ran from the block end) is exact.
+    //      A lane keeps the sample it had before its last re-run (start -> end, mid, counts: WV_SAMPLE_CACHE).  For a fixed run of symbols the
+    //      map start state -> (bits, end state) is a monotone step function with a handful of steps (a composition of degree-1 circle maps;
+    //      2 .. 8 distinct values per 1024-symbol super-range on Proba80, never one: scripts/sim_repair_policies.py), so while the links
+    //      above a lane are still settling its predecessor's end flips between the same few states -- A, B, A again -- and the lane has
+    //      already walked from A: it takes the sample back instead of re-running (free rounds of look-ups between two rounds of runs;
+    //      simulated on P80: 3.9 -> 3.1 rounds per wave; P14 has one round and does not get here).
+#ifndef WV_SAMPLE_CACHE
+#define WV_SAMPLE_CACHE 1
+#endif
+    u32 oStart = 0xFFFFFFFFu, oEnd = 0, oMid = 0, oLo = 0, oTot = 0;        // the older sample (no state is 0xFFFFFFFF)
+    u32 rEnd = cend, rMid = cmid, rLo = bitsLo, rTot = bitsTot;             // the run the checkpoints describe (= the lane's last run)
     for (;;) {
-        const u32 prevEnd = (u32)__shfl_up((int)cend, 2, WAVE);
-        const bool bad = mineC && kk > 0 && cstart != prevEnd;
+        u32 prevEnd; bool bad;
+        for (;;) {
+            prevEnd = (u32)__shfl_up((int)cend, 2, WAVE);
+            bad = mineC && kk > 0 && cstart != prevEnd;
+            const bool hit = WV_SAMPLE_CACHE && bad && oStart == prevEnd;
+            if (!__any(hit)) break;
+            if (hit) {
+                u32 t;
+                t = cstart; cstart = oStart; oStart = t;  t = cend; cend = oEnd; oEnd = t;  t = cmid; cmid = oMid; oMid = t;
+                t = bitsLo; bitsLo = oLo; oLo = t;  t = bitsTot; bitsTot = oTot; oTot = t;
+            }
+        }
         if (!__any(bad)) break;
         ETIMING(if (rounds == 0) { const unsigned long long bm = __ballot(bad); nBad0 = (u32)__builtin_popcountll(bm); firstBad = (u32)__builtin_ctzll(bm); })
         if (bad) {
-            cstart = prevEnd;
+            oStart = cstart; oEnd = cend; oMid = cmid; oLo = bitsLo; oTot = bitsTot;
+            cstart = prevEnd; cend = rEnd; cmid = rMid; bitsLo = rLo; bitsTot = rTot;   // a merge continues the run the checkpoints describe
             u32 x = cstart, lo = sLo, hi = sMid, nbits = 0;
             ck.merged = false; ck.idx = 0; ck.left = ck.every;
             bool midDone = false;
@@ -429,10 +451,11 @@ __global__ __launch_bounds__(64 * FSE_WV_WAVES) void k_fse_encode_wave(FseEncArg
                 if (piece == 0 && !ck.merged) { cmid = x; bitsLo = nbits; midDone = true; }
                 lo = sMid; hi = sHi;
             }
-            if (ck.merged) {                                                // the rest of the super-range, and its end state, repeat the previous run
+            if (ck.merged) {                                                // the rest of the super-range, and its end state, repeat the recorded run
                 if (!midDone) bitsLo += ck.d;
                 bitsTot += ck.d;
             } else { cend = x; bitsTot = nbits; }
+            rEnd = cend; rMid = cmid; rLo = bitsLo; rTot = bitsTot;
         }
         ETIMING(++rounds;)
     }
