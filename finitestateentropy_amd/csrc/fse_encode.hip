@@ -31,6 +31,15 @@ __global__ __launch_bounds__(64) void k_fse_encode(FseEncArgs a)
     const u32 lane = threadIdx.x;
     const size_t first = (size_t)blockIdx.x * a.G;
 
+    // A group none of whose blocks is this kernel's (the usual case behind the wave kernel: FSE_ENC_LANE blocks are rare) leaves after ONE
+    // look at its blocks' states, lane g at block g -- the staging loop below would read them one after the other (G dependent loads per
+    // workgroup: the empty pass over 100k blocks took 59 us, now the time of its launches).  The workgroup is one wave.
+    if (a.meta) {
+        const size_t bb = first + lane;
+        const bool mine = lane < (u32)a.G && bb < a.nBlocks && !fse_enc_skip(a.meta[bb].state, a.onlyState);
+        if (!__any(mine)) return;
+    }
+
     // ---- stage the CTables of this group (wave-uniform control flow, coalesced copies)
     for (int g = 0; g < a.G; ++g) {
         const size_t b = first + g;
